@@ -1,0 +1,38 @@
+import importlib
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def manifest():
+    with open(os.path.join(GOLD, "manifest.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def schema():
+    return importlib.import_module("atm-vfi_amd.schema")
+
+
+@pytest.fixture(scope="session")
+def weights(schema):
+    cache = {}
+
+    def get(variant):
+        if variant not in cache:
+            cache[variant] = schema.synthetic_state_dict(variant, seed=1)
+        return cache[variant]
+    return get
