@@ -1,0 +1,29 @@
+// Error reporting and version of libatmvfi_hip.so.
+#include "common.h"
+
+#include <string.h>
+
+namespace atmvfi {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int check_launch(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return ATMVFI_ELAUNCH;
+    }
+    return ATMVFI_OK;
+}
+
+}  // namespace atmvfi
+
+extern "C" int atmvfi_version(void) { return (0 << 16) | (1 << 8) | 0; }
+extern "C" const char* atmvfi_last_error(void) { return atmvfi::g_err; }

@@ -1,0 +1,252 @@
+// Fused window attention for gfx950 (ATMFormer cross-attention + motion, Swin self-attention).
+//
+// One workgroup per (window, head); one wavefront per 16-query tile.
+//   S^T = K Q^T   : MFMA A = K fragment (LDS, ds_read_b128), B = Q fragment (global, once per wave)
+//                   -> lane (r = lane&15, g = lane>>4) holds S[q = 16w + r][key = 16kt + 4g + e]
+//   softmax       : lane-local over its 4*NT keys, then two __shfl_xor (16, 32) across the 4 lane groups
+//   motion        : sum_k P[q,k] * (k_xy - q_xy) from the same registers (no relative_coord table)
+//   O^T = V^T P^T : MFMA A = V^T fragment (LDS), B = P^T = the S accumulators as they stand
+//                   (key index on the register axis = the k axis of the next MFMA; no LDS round trip)
+//                   -> lane holds O[q][d = 16dt + 4g + e]: one 16-byte store per d-tile.
+// The N x N attention matrix and the 2 x N x N motion product of the reference
+// (attention.py:192-208) are never materialised.
+#include "common.h"
+
+#include <math.h>
+
+namespace {
+
+template <int NT>
+__global__ __launch_bounds__(64 * NT) void window_attn_kernel(
+    const float* __restrict__ qkv, float* __restrict__ out, float* __restrict__ motion,
+    const int* __restrict__ labels, int N, int nW, int ws, int heads, int hd, int C, int Bw, int kv_shift,
+    float scale) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NPAD = NT * 16;
+    const int stride = hd + ((hd & 7) ? 0 : 4);   // stride % 8 == 4: conflict-free V^T column reads
+    float* Ks = smem;
+    float* Vs = Ks + NPAD * stride;
+    int* Ls = reinterpret_cast<int*>(Vs + NPAD * stride);
+
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / heads;
+    const int h = blockIdx.x - b * heads;
+    const int bk = (b + kv_shift) % Bw;
+    const int C3 = 3 * C;
+
+    // ---- stage K and V of this head (zero rows for padded keys) ----
+    const int hd4 = hd >> 2;
+    for (int idx = tid; idx < NPAD * hd4; idx += 64 * NT) {
+        const int key = idx / hd4;
+        const int d = (idx - key * hd4) << 2;
+        f32x4 kv = (f32x4){0.f, 0.f, 0.f, 0.f}, vv = kv;
+        if (key < N) {
+            const float* p = qkv + ((long long)bk * N + key) * C3 + C + h * hd + d;
+            kv = *reinterpret_cast<const f32x4*>(p);
+            vv = *reinterpret_cast<const f32x4*>(p + C);
+        }
+        *reinterpret_cast<f32x4*>(Ks + key * stride + d) = kv;
+        *reinterpret_cast<f32x4*>(Vs + key * stride + d) = vv;
+    }
+    for (int idx = tid; idx < NPAD; idx += 64 * NT)
+        Ls[idx] = (labels && idx < N) ? labels[(long long)(b % nW) * N + idx] : 0;
+    __syncthreads();
+
+    const int lane = tid & 63;
+    const int w = tid >> 6;
+    const int r = lane & 15;
+    const int g = lane >> 4;
+    const int q = 16 * w + r;
+    const bool qok = q < N;
+
+    // ---- S^T = K Q^T ----
+    f32x4 s[NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* qrow = qkv + ((long long)b * N + (qok ? q : 0)) * C3 + h * hd;
+    const int nchunks = (hd + 15) >> 4;
+    for (int c = 0; c < nchunks; ++c) {
+        const int d = 16 * c + 4 * g;
+        const bool dok = d < hd;
+        f32x4 qf = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (qok && dok) qf = *reinterpret_cast<const f32x4*>(qrow + d);
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            f32x4 kf = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (dok) kf = *reinterpret_cast<const f32x4*>(Ks + (16 * kt + r) * stride + d);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[ks], qf[ks], s[kt], 0, 0, 0);
+        }
+    }
+
+    // ---- scale + mask + softmax over keys (attention.py:192-200) ----
+    const int lab_q = Ls[qok ? q : 0];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+        const int4 lk = *reinterpret_cast<const int4*>(Ls + 16 * kt + 4 * g);
+        const int lks[4] = {lk.x, lk.y, lk.z, lk.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int key = 16 * kt + 4 * g + e;
+            float v = s[kt][e] * scale;
+            if (labels && lks[e] != lab_q) v += -100.0f;
+            if (key >= N) v = -INFINITY;
+            s[kt][e] = v;
+            mx = fmaxf(mx, v);
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float p = expf(s[kt][e] - mx);
+            s[kt][e] = p;
+            sum += p;
+        }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    const float qx = (float)(q % ws), qy = (float)(q / ws);
+    float mox = 0.f, moy = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int key = 16 * kt + 4 * g + e;
+            const float p = s[kt][e] * inv;
+            s[kt][e] = p;
+            const int ky = key / ws;
+            mox += p * ((float)(key - ky * ws) - qx);
+            moy += p * ((float)ky - qy);
+        }
+    if (motion) {
+        mox += __shfl_xor(mox, 16);
+        mox += __shfl_xor(mox, 32);
+        moy += __shfl_xor(moy, 16);
+        moy += __shfl_xor(moy, 32);
+        if (g == 0 && qok) {
+            float* mp = motion + (((long long)b * N + q) * heads + h) * 2;
+            mp[0] = mox;
+            mp[1] = moy;
+        }
+    }
+
+    // ---- O^T = V^T P^T ----
+    const int ndt = (hd + 15) >> 4;
+    float* orow = out + ((long long)b * N + (qok ? q : 0)) * C + h * hd;
+    for (int dt = 0; dt < ndt; ++dt) {
+        f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int dcol = 16 * dt + r;
+        const bool cok = dcol < hd;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const float vf = cok ? Vs[(16 * kt + 4 * g + ks) * stride + dcol] : 0.f;
+                o = __builtin_amdgcn_mfma_f32_16x16x4f32(vf, s[kt][ks], o, 0, 0, 0);
+            }
+        const int d = 16 * dt + 4 * g;
+        if (qok && d < hd) *reinterpret_cast<f32x4*>(orow + d) = o;
+    }
+}
+
+__global__ void motion_head_kernel(const float* __restrict__ motion, const int* __restrict__ row_map,
+                                   const float* __restrict__ w0, const float* __restrict__ b0,
+                                   const float* __restrict__ w1, const float* __restrict__ b1,
+                                   float* __restrict__ out, int out_ld, long long out_gstride, int out_rpg,
+                                   long long rows, int heads) {
+    const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= rows) return;
+    const long long ro = row_map ? row_map[m] : m;
+    if (ro < 0) return;
+    const float* mp = motion + m * heads * 2;
+    const int hid = heads >> 1;
+    float ox = b1[0], oy = b1[0];
+    for (int j = 0; j < hid; ++j) {
+        float ax = b0[j], ay = b0[j];
+        for (int hh = 0; hh < heads; ++hh) {
+            const float wv = w0[j * heads + hh];
+            ax += wv * mp[hh * 2];
+            ay += wv * mp[hh * 2 + 1];
+        }
+        ox += w1[j] * gelu_erf(ax);
+        oy += w1[j] * gelu_erf(ay);
+    }
+    const long long off = (out_rpg > 0) ? (ro / out_rpg) * out_gstride + (ro % out_rpg) * (long long)out_ld
+                                        : ro * (long long)out_ld;
+    out[off] = ox;
+    out[off + 1] = oy;
+}
+
+template <int NT>
+int launch_attn(const float* qkv, float* out, float* motion, const int* labels, int Bw, int nW, int N, int ws,
+                int heads, int hd, int kv_shift, hipStream_t s) {
+    const int stride = hd + ((hd & 7) ? 0 : 4);
+    const size_t lds = (size_t)(2 * NT * 16 * stride + NT * 16) * sizeof(float);
+    ATMVFI_REQUIRE(lds <= 160 * 1024, ATMVFI_EINVAL,
+                   "window_attention: K/V tile of %zu bytes exceeds the 160 KiB LDS (ws %d, hd %d)", lds, ws, hd);
+    auto kern = window_attn_kernel<NT>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        ATMVFI_REQUIRE(e == hipSuccess, ATMVFI_ELAUNCH, "window_attention: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
+    const float scale = 1.0f / sqrtf((float)hd);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(Bw * heads)), dim3(64 * NT), lds, s, qkv, out, motion, labels, N, nW, ws,
+                       heads, hd, heads * hd, Bw, kv_shift, scale);
+    return atmvfi::check_launch("window_attention");
+}
+
+}  // namespace
+
+extern "C" int atmvfi_window_attention(const float* qkv, float* out, float* motion, const int32_t* labels, int Bw,
+                                        int nW, int ws, int heads, int hd, int kv_shift, void* stream) {
+    ATMVFI_REQUIRE(qkv && out, ATMVFI_EINVAL, "window_attention: null pointer");
+    ATMVFI_REQUIRE(Bw > 0 && nW > 0 && Bw % nW == 0, ATMVFI_EINVAL, "window_attention: Bw %d must be a positive multiple of nW %d", Bw, nW);
+    ATMVFI_REQUIRE(ws >= 1 && ws <= 16, ATMVFI_EINVAL, "window_attention: window size %d outside 1..16", ws);
+    ATMVFI_REQUIRE(heads > 0 && hd > 0 && hd % 4 == 0, ATMVFI_EINVAL, "window_attention: head dim %d must be a multiple of 4", hd);
+    ATMVFI_REQUIRE(kv_shift >= 0 && kv_shift < Bw, ATMVFI_EINVAL, "window_attention: kv_shift out of range");
+    ATMVFI_REQUIRE(atmvfi::aligned16(qkv) && atmvfi::aligned16(out), ATMVFI_EALIGN, "window_attention: qkv/out must be 16-byte aligned");
+    ATMVFI_REQUIRE((long long)Bw * heads < (1ll << 31), ATMVFI_EINVAL, "window_attention: grid too large");
+    const int N = ws * ws;
+    const int nt = (N + 15) / 16;
+    hipStream_t s = (hipStream_t)stream;
+#define ATMVFI_ATTN_CASE(k) \
+    case k: return launch_attn<k>(qkv, out, motion, labels, Bw, nW, N, ws, heads, hd, kv_shift, s);
+    switch (nt) {
+        ATMVFI_ATTN_CASE(1) ATMVFI_ATTN_CASE(2) ATMVFI_ATTN_CASE(3) ATMVFI_ATTN_CASE(4) ATMVFI_ATTN_CASE(5)
+        ATMVFI_ATTN_CASE(6) ATMVFI_ATTN_CASE(7) ATMVFI_ATTN_CASE(8) ATMVFI_ATTN_CASE(9) ATMVFI_ATTN_CASE(10)
+        ATMVFI_ATTN_CASE(11) ATMVFI_ATTN_CASE(12) ATMVFI_ATTN_CASE(13) ATMVFI_ATTN_CASE(14) ATMVFI_ATTN_CASE(15)
+        ATMVFI_ATTN_CASE(16)
+    }
+#undef ATMVFI_ATTN_CASE
+    atmvfi::set_error("window_attention: unsupported token count %d", N);
+    return ATMVFI_EINVAL;
+}
+
+extern "C" int atmvfi_window_attn_cross_motion(const float* qkv, float* out, float* motion, const int32_t* labels,
+                                                int Bw, int nW, int ws, int heads, int hd, void* stream) {
+    ATMVFI_REQUIRE(motion, ATMVFI_EINVAL, "window_attn_cross_motion: motion output required");
+    ATMVFI_REQUIRE(Bw % 2 == 0, ATMVFI_EINVAL, "window_attn_cross_motion: Bw must be even (two frames)");
+    return atmvfi_window_attention(qkv, out, motion, labels, Bw, nW, ws, heads, hd, Bw / 2, stream);
+}
+
+extern "C" int atmvfi_window_attn_self(const float* qkv, float* out, const int32_t* labels, int Bw, int nW, int ws,
+                                        int heads, int hd, void* stream) {
+    return atmvfi_window_attention(qkv, out, nullptr, labels, Bw, nW, ws, heads, hd, 0, stream);
+}
+
+extern "C" int atmvfi_motion_head(const float* motion, const int32_t* row_map, const float* w0, const float* b0,
+                                   const float* w1, const float* b1, float* out, int out_ld, int64_t out_gstride,
+                                   int out_rpg, int64_t rows, int heads, void* stream) {
+    ATMVFI_REQUIRE(motion && w0 && b0 && w1 && b1 && out, ATMVFI_EINVAL, "motion_head: null pointer");
+    ATMVFI_REQUIRE(rows > 0 && heads >= 2 && heads % 2 == 0, ATMVFI_EINVAL, "motion_head: bad rows/heads");
+    const unsigned blocks = (unsigned)((rows + 255) / 256);
+    hipLaunchKernelGGL(motion_head_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, motion, row_map, w0, b0, w1,
+                       b1, out, out_ld, (long long)out_gstride, out_rpg, (long long)rows, heads);
+    return atmvfi::check_launch("motion_head");
+}

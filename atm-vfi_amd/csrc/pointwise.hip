@@ -1,0 +1,451 @@
+// HBM-bound kernels of the ATM-VFI hot path for gfx950: LayerNorm (+window gather), depth-wise
+// 3x3 + GELU, backward bilinear warps, fused warp/blend synthesis, align_corners resize,
+// frame packing, final residual.  All are one-pass, 16-byte-per-lane where the layout allows.
+#include "common.h"
+
+#include <math.h>
+
+namespace {
+
+// ---------------------------------------------------------------------------------------
+// LayerNorm: one wavefront per token row, row kept in L1 between the three sweeps.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ in, int in_ld, long long in_gstride,
+                                                        int in_rpg, const int* __restrict__ src_map,
+                                                        float* __restrict__ out, int out_ld,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        long long rows, int C) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float* orow = out + row * (long long)out_ld;
+    const int c4n = C >> 2;
+    long long src = src_map ? src_map[row] : row;
+    if (src < 0) {   // zero-padded token: LayerNorm(0) == beta exactly
+        for (int i = lane; i < c4n; i += 64)
+            *reinterpret_cast<f32x4*>(orow + 4 * i) = *reinterpret_cast<const f32x4*>(beta + 4 * i);
+        return;
+    }
+    const float* irow = in + ((in_rpg > 0) ? (src / in_rpg) * in_gstride + (src % in_rpg) * (long long)in_ld
+                                           : src * (long long)in_ld);
+    float sum = 0.f;
+    for (int i = lane; i < c4n; i += 64) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(irow + 4 * i);
+        sum += (v.x + v.y) + (v.z + v.w);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum / (float)C;
+    float sq = 0.f;
+    for (int i = lane; i < c4n; i += 64) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(irow + 4 * i);
+        const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+        sq += (a * a + b * b) + (c * c + d * d);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    const float rstd = 1.0f / sqrtf(sq / (float)C + 1e-5f);
+    for (int i = lane; i < c4n; i += 64) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(irow + 4 * i);
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + 4 * i);
+        const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + 4 * i);
+        f32x4 y;
+        y.x = (v.x - mean) * rstd * gm.x + bt.x;
+        y.y = (v.y - mean) * rstd * gm.y + bt.y;
+        y.z = (v.z - mean) * rstd * gm.z + bt.z;
+        y.w = (v.w - mean) * rstd * gm.w + bt.w;
+        *reinterpret_cast<f32x4*>(orow + 4 * i) = y;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// depth-wise 3x3 (pad 1) + bias + exact GELU, NHWC, 4 channels per lane
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dwconv_gelu_kernel(const float* __restrict__ in, int in_ld,
+                                                          float* __restrict__ out, int out_ld,
+                                                          const float* __restrict__ w9, const float* __restrict__ bias,
+                                                          int N, int H, int W, int C) {
+    const int c4n = C >> 2;
+    const long long total = (long long)N * H * W * c4n;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % c4n) << 2;
+        const long long pix = idx / c4n;
+        const int x = (int)(pix % W);
+        const int y = (int)((pix / W) % H);
+        f32x4 acc = *reinterpret_cast<const f32x4*>(bias + c);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int yy = y + ky - 1;
+            if ((unsigned)yy >= (unsigned)H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int xx = x + kx - 1;
+                if ((unsigned)xx >= (unsigned)W) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(in + (pix + (long long)(ky - 1) * W + (kx - 1)) * in_ld + c);
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(w9 + (ky * 3 + kx) * C + c);
+                acc.x += v.x * wv.x;
+                acc.y += v.y * wv.y;
+                acc.z += v.z * wv.z;
+                acc.w += v.w * wv.w;
+            }
+        }
+        f32x4 o;
+        o.x = gelu_erf(acc.x);
+        o.y = gelu_erf(acc.y);
+        o.z = gelu_erf(acc.z);
+        o.w = gelu_erf(acc.w);
+        *reinterpret_cast<f32x4*>(out + pix * out_ld + c) = o;
+    }
+}
+
+__global__ void pack_dw_kernel(const float* __restrict__ src, float* __restrict__ dst, int C) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < 9 * C) {
+        const int tap = idx / C, c = idx - tap * C;
+        dst[idx] = src[c * 9 + tap];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Sampling coordinates exactly as the reference computes them (flow_warp.py:35-36 normalise,
+// then grid_sample(align_corners=True) un-normalises): the round trip is kept so that the
+// tap positions are bit-identical to the reference's.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float ref_coord(float p, int size) {
+    const float g = 2.0f * p / (float)(size - 1) - 1.0f;
+    return ((g + 1.0f) / 2.0f) * (float)(size - 1);
+}
+
+struct Taps {
+    int x0, y0;
+    float w00, w01, w10, w11;   // (y0,x0) (y0,x1) (y1,x0) (y1,x1); zero when the tap is outside
+    bool in00, in01, in10, in11;
+};
+
+__device__ __forceinline__ Taps make_taps(float px, float py, int W, int H) {
+    Taps t;
+    const float ix = ref_coord(px, W), iy = ref_coord(py, H);
+    const float fx0 = floorf(ix), fy0 = floorf(iy);
+    // clamp before the int conversion so wild flows cannot overflow
+    const float cx = fminf(fmaxf(fx0, -2.0f), (float)W + 1.0f), cy = fminf(fmaxf(fy0, -2.0f), (float)H + 1.0f);
+    t.x0 = (int)cx;
+    t.y0 = (int)cy;
+    const float ax = ix - fx0, ay = iy - fy0;   // weight of the +1 neighbour
+    const bool far = (cx != fx0) || (cy != fy0) || !(ix == ix) || !(iy == iy);
+    t.in00 = !far && t.x0 >= 0 && t.x0 < W && t.y0 >= 0 && t.y0 < H;
+    t.in01 = !far && t.x0 + 1 >= 0 && t.x0 + 1 < W && t.y0 >= 0 && t.y0 < H;
+    t.in10 = !far && t.x0 >= 0 && t.x0 < W && t.y0 + 1 >= 0 && t.y0 + 1 < H;
+    t.in11 = !far && t.x0 + 1 >= 0 && t.x0 + 1 < W && t.y0 + 1 >= 0 && t.y0 + 1 < H;
+    t.w00 = (1.0f - ax) * (1.0f - ay);
+    t.w01 = ax * (1.0f - ay);
+    t.w10 = (1.0f - ax) * ay;
+    t.w11 = ax * ay;
+    return t;
+}
+
+__device__ __forceinline__ float sample_plane(const float* __restrict__ p, const Taps& t, int W) {
+    float v = 0.f;
+    const float* b = p + (long long)t.y0 * W + t.x0;
+    if (t.in00) v += b[0] * t.w00;
+    if (t.in01) v += b[1] * t.w01;
+    if (t.in10) v += b[W] * t.w10;
+    if (t.in11) v += b[W + 1] * t.w11;
+    return v;
+}
+
+__global__ __launch_bounds__(256) void flow_warp_planar_kernel(const float* __restrict__ src, const float* __restrict__ flow,
+                                                               long long flow_bstride, int flow_pstride, int flow_cstride,
+                                                               float* __restrict__ dst, int B, int C, int H, int W) {
+    const long long hw = (long long)H * W;
+    const long long total = (long long)B * hw;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(idx / hw);
+        const long long pix = idx - (long long)b * hw;
+        const int y = (int)(pix / W), x = (int)(pix - (long long)y * W);
+        const float* fp = flow + b * flow_bstride + pix * flow_pstride;
+        const Taps t = make_taps((float)x + fp[0], (float)y + fp[flow_cstride], W, H);
+        for (int c = 0; c < C; ++c)
+            dst[((long long)b * C + c) * hw + pix] = sample_plane(src + ((long long)b * C + c) * hw, t, W);
+    }
+}
+
+__global__ __launch_bounds__(256) void flow_warp_nhwc_kernel(const float* __restrict__ src, int src_ld, long long src_bstride,
+                                                             const float* __restrict__ flow, long long flow_bstride,
+                                                             int flow_pstride, int flow_cstride, float* __restrict__ dst,
+                                                             int dst_ld, long long dst_bstride, int B, int C, int H, int W) {
+    const int c4n = C >> 2;
+    const long long hw = (long long)H * W;
+    const long long total = (long long)B * hw * c4n;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % c4n) << 2;
+        const long long bp = idx / c4n;
+        const int b = (int)(bp / hw);
+        const long long pix = bp - (long long)b * hw;
+        const int y = (int)(pix / W), x = (int)(pix - (long long)y * W);
+        const float* fp = flow + b * flow_bstride + pix * flow_pstride;
+        const Taps t = make_taps((float)x + fp[0], (float)y + fp[flow_cstride], W, H);
+        const float* sb = src + b * src_bstride + ((long long)t.y0 * W + t.x0) * src_ld + c;
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (t.in00) { const f32x4 v = *reinterpret_cast<const f32x4*>(sb); acc += v * t.w00; }
+        if (t.in01) { const f32x4 v = *reinterpret_cast<const f32x4*>(sb + src_ld); acc += v * t.w01; }
+        if (t.in10) { const f32x4 v = *reinterpret_cast<const f32x4*>(sb + (long long)W * src_ld); acc += v * t.w10; }
+        if (t.in11) { const f32x4 v = *reinterpret_cast<const f32x4*>(sb + (long long)(W + 1) * src_ld); acc += v * t.w11; }
+        *reinterpret_cast<f32x4*>(dst + b * dst_bstride + pix * dst_ld + c) = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// fused synthesis at one pyramid level
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void warp_blend_kernel(const float* __restrict__ im0, const float* __restrict__ im1,
+                                                         const float* __restrict__ motion, int motion_ld, long long motion_bstride,
+                                                         float* __restrict__ i0w, float* __restrict__ i1w, float* __restrict__ it,
+                                                         float* __restrict__ f0o, float* __restrict__ f1o,
+                                                         float* __restrict__ m1o, float* __restrict__ m2o,
+                                                         const float* __restrict__ orig0, const float* __restrict__ orig1,
+                                                         float* __restrict__ pack15, int pack_ld, int B, int H, int W) {
+    const long long hw = (long long)H * W;
+    const long long total = (long long)B * hw;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(idx / hw);
+        const long long pix = idx - (long long)b * hw;
+        const int y = (int)(pix / W), x = (int)(pix - (long long)y * W);
+        const float* mp = motion + b * motion_bstride + pix * motion_ld;
+        const float fx0 = mp[0], fy0 = mp[1], fx1 = mp[2], fy1 = mp[3];
+        const float m1 = sigmoidf_(mp[4]);
+        const float m2 = 1.0f - m1;
+        const Taps t0 = make_taps((float)x + fx0, (float)y + fy0, W, H);
+        const Taps t1 = make_taps((float)x + fx1, (float)y + fy1, W, H);
+        float a[3], c[3], o[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const long long pl = ((long long)b * 3 + ch) * hw;
+            a[ch] = sample_plane(im0 + pl, t0, W);
+            c[ch] = sample_plane(im1 + pl, t1, W);
+            o[ch] = m1 * a[ch] + m2 * c[ch];
+            i0w[pl + pix] = a[ch];
+            i1w[pl + pix] = c[ch];
+            it[pl + pix] = o[ch];
+        }
+        if (f0o) {
+            f0o[((long long)b * 2) * hw + pix] = fx0;
+            f0o[((long long)b * 2 + 1) * hw + pix] = fy0;
+            f1o[((long long)b * 2) * hw + pix] = fx1;
+            f1o[((long long)b * 2 + 1) * hw + pix] = fy1;
+        }
+        if (m1o) {
+            m1o[(long long)b * hw + pix] = m1;
+            m2o[(long long)b * hw + pix] = m2;
+        }
+        if (pack15) {
+            float* pp = pack15 + ((long long)b * hw + pix) * pack_ld;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const long long pl = ((long long)b * 3 + ch) * hw + pix;
+                pp[ch] = orig0[pl];
+                pp[3 + ch] = a[ch];
+                pp[6 + ch] = orig1[pl];
+                pp[9 + ch] = c[ch];
+                pp[12 + ch] = o[ch];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// align_corners=True bilinear resize (ATen upsample_bilinear2d arithmetic), planar
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void resize_ac_kernel(const float* __restrict__ src, long long sb, long long sc, long long sy,
+                                                        long long sx, float* __restrict__ dst, int B, int C,
+                                                        int Hi, int Wi, int Ho, int Wo, float value_scale) {
+    const float sh = (Ho > 1) ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f;
+    const float sw = (Wo > 1) ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
+    const long long ohw = (long long)Ho * Wo;
+    const long long total = (long long)B * C * ohw;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int p = (int)(idx / ohw);
+        const int pb = p / C, pc = p - pb * C;
+        const long long pix = idx - (long long)p * ohw;
+        const int oy = (int)(pix / Wo), ox = (int)(pix - (long long)oy * Wo);
+        const float ry = sh * (float)oy, rx = sw * (float)ox;
+        const int y0 = (int)ry, x0 = (int)rx;
+        const int yp = (y0 < Hi - 1) ? 1 : 0, xp = (x0 < Wi - 1) ? 1 : 0;
+        const float ly = ry - (float)y0, lx = rx - (float)x0;
+        const float hy = 1.0f - ly, hx = 1.0f - lx;
+        const float* s = src + pb * sb + pc * sc + y0 * sy + x0 * sx;
+        const float v = hy * (hx * s[0] + lx * s[xp * sx]) + ly * (hx * s[yp * sy] + lx * s[yp * sy + xp * sx]);
+        dst[idx] = v * value_scale;
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_frames_kernel(const float* __restrict__ im0, const float* __restrict__ im1,
+                                                          float* __restrict__ dst, int B, int H, int W) {
+    const long long hw = (long long)H * W;
+    const long long total = 2ll * B * hw;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int f = (int)(idx / hw);           // stacked frame index: [im0 batch..., im1 batch...]
+        const long long pix = idx - (long long)f * hw;
+        const float* s = (f < B ? im0 + (long long)f * 3 * hw : im1 + (long long)(f - B) * 3 * hw) + pix;
+        *reinterpret_cast<f32x4*>(dst + idx * 4) = (f32x4){s[0], s[hw], s[2 * hw], 0.f};
+    }
+}
+
+__global__ __launch_bounds__(256) void final_residual_kernel(const float* __restrict__ it, const float* __restrict__ r, int r_ld,
+                                                             float* __restrict__ it_sum, float* __restrict__ it_clamped,
+                                                             int B, int H, int W) {
+    const long long hw = (long long)H * W;
+    const long long total = (long long)B * hw;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(idx / hw);
+        const long long pix = idx - (long long)b * hw;
+        const float* rp = r + idx * r_ld;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const long long o = ((long long)b * 3 + ch) * hw + pix;
+            const float v = it[o] + (2.0f * sigmoidf_(rp[ch]) - 1.0f);
+            it_sum[o] = v;
+            it_clamped[o] = fminf(fmaxf(v, 0.0f), 1.0f);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void l1_mean_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                      float* __restrict__ out, long long per_sample) {
+    __shared__ float red[4];
+    const int s = blockIdx.y;
+    const float* pa = a + (long long)s * per_sample;
+    const float* pb = b + (long long)s * per_sample;
+    float acc = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < per_sample; i += (long long)gridDim.x * blockDim.x)
+        acc += fabsf(pa[i] - pb[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out + s, (red[0] + red[1] + red[2] + red[3]) / (float)per_sample);
+}
+
+inline unsigned grid_for(long long total) {
+    long long b = (total + 255) / 256;
+    if (b > 8192) b = 8192;   // 256 CUs x 32 blocks, grid-stride the rest
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int atmvfi_layernorm(const float* in, int in_ld, int64_t in_gstride, int in_rpg, const int32_t* src_row_map,
+                                 float* out, int out_ld, const float* gamma, const float* beta, int64_t rows, int C,
+                                 void* stream) {
+    ATMVFI_REQUIRE(in && out && gamma && beta, ATMVFI_EINVAL, "layernorm: null pointer");
+    ATMVFI_REQUIRE(rows > 0 && C > 0 && C % 4 == 0, ATMVFI_EINVAL, "layernorm: C %d must be a positive multiple of 4", C);
+    ATMVFI_REQUIRE(in_ld % 4 == 0 && out_ld % 4 == 0 && in_ld >= C && out_ld >= C && in_gstride % 4 == 0, ATMVFI_EALIGN,
+                   "layernorm: leading dimensions must be multiples of 4 and >= C");
+    ATMVFI_REQUIRE(atmvfi::aligned16(in) && atmvfi::aligned16(out) && atmvfi::aligned16(gamma) && atmvfi::aligned16(beta),
+                   ATMVFI_EALIGN, "layernorm: pointers must be 16-byte aligned");
+    const unsigned blocks = (unsigned)((rows + 3) / 4);
+    hipLaunchKernelGGL(layernorm_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, in_ld, (long long)in_gstride,
+                       in_rpg, src_row_map, out, out_ld, gamma, beta, (long long)rows, C);
+    return atmvfi::check_launch("layernorm");
+}
+
+extern "C" int atmvfi_dwconv3x3_gelu(const float* in, int in_ld, float* out, int out_ld, const float* weight9,
+                                      const float* bias, int N, int H, int W, int C, void* stream) {
+    ATMVFI_REQUIRE(in && out && weight9 && bias, ATMVFI_EINVAL, "dwconv3x3_gelu: null pointer");
+    ATMVFI_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, ATMVFI_EINVAL, "dwconv3x3_gelu: bad shape");
+    ATMVFI_REQUIRE(in_ld % 4 == 0 && out_ld % 4 == 0 && in_ld >= C && out_ld >= C, ATMVFI_EALIGN, "dwconv3x3_gelu: bad ld");
+    ATMVFI_REQUIRE(atmvfi::aligned16(in) && atmvfi::aligned16(out) && atmvfi::aligned16(weight9) && atmvfi::aligned16(bias),
+                   ATMVFI_EALIGN, "dwconv3x3_gelu: pointers must be 16-byte aligned");
+    const long long total = (long long)N * H * W * (C / 4);
+    hipLaunchKernelGGL(dwconv_gelu_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, in_ld, out, out_ld,
+                       weight9, bias, N, H, W, C);
+    return atmvfi::check_launch("dwconv3x3_gelu");
+}
+
+extern "C" int atmvfi_pack_dw_weight(const float* src, float* dst, int C, void* stream) {
+    ATMVFI_REQUIRE(src && dst && C > 0, ATMVFI_EINVAL, "pack_dw_weight: bad arguments");
+    hipLaunchKernelGGL(pack_dw_kernel, dim3((9 * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, dst, C);
+    return atmvfi::check_launch("pack_dw_weight");
+}
+
+extern "C" int atmvfi_flow_warp(const float* src, const float* flow, int64_t flow_bstride, int flow_pstride,
+                                 int flow_cstride, float* dst, int B, int C, int H, int W, void* stream) {
+    ATMVFI_REQUIRE(src && flow && dst, ATMVFI_EINVAL, "flow_warp: null pointer");
+    ATMVFI_REQUIRE(B > 0 && C > 0 && H > 1 && W > 1, ATMVFI_EINVAL, "flow_warp: bad shape (H, W must be > 1)");
+    hipLaunchKernelGGL(flow_warp_planar_kernel, dim3(grid_for((long long)B * H * W)), dim3(256), 0, (hipStream_t)stream, src,
+                       flow, (long long)flow_bstride, flow_pstride, flow_cstride, dst, B, C, H, W);
+    return atmvfi::check_launch("flow_warp");
+}
+
+extern "C" int atmvfi_flow_warp_nhwc(const float* src, int src_ld, int64_t src_bstride, const float* flow,
+                                      int64_t flow_bstride, int flow_pstride, int flow_cstride, float* dst, int dst_ld,
+                                      int64_t dst_bstride, int B, int C, int H, int W, void* stream) {
+    ATMVFI_REQUIRE(src && flow && dst, ATMVFI_EINVAL, "flow_warp_nhwc: null pointer");
+    ATMVFI_REQUIRE(B > 0 && C > 0 && C % 4 == 0 && H > 1 && W > 1, ATMVFI_EINVAL, "flow_warp_nhwc: bad shape");
+    ATMVFI_REQUIRE(src_ld % 4 == 0 && dst_ld % 4 == 0 && src_bstride % 4 == 0 && dst_bstride % 4 == 0 &&
+                       atmvfi::aligned16(src) && atmvfi::aligned16(dst),
+                   ATMVFI_EALIGN, "flow_warp_nhwc: views must be 16-byte aligned");
+    hipLaunchKernelGGL(flow_warp_nhwc_kernel, dim3(grid_for((long long)B * H * W * (C / 4))), dim3(256), 0,
+                       (hipStream_t)stream, src, src_ld, (long long)src_bstride, flow, (long long)flow_bstride, flow_pstride,
+                       flow_cstride, dst, dst_ld, (long long)dst_bstride, B, C, H, W);
+    return atmvfi::check_launch("flow_warp_nhwc");
+}
+
+extern "C" int atmvfi_warp_blend(const float* im0, const float* im1, const float* motion, int motion_ld,
+                                  int64_t motion_bstride, float* i0w, float* i1w, float* it, float* flow0_out,
+                                  float* flow1_out, float* mask1_out, float* mask2_out, const float* orig0,
+                                  const float* orig1, float* pack15, int pack_ld, int B, int H, int W, void* stream) {
+    ATMVFI_REQUIRE(im0 && im1 && motion && i0w && i1w && it, ATMVFI_EINVAL, "warp_blend: null pointer");
+    ATMVFI_REQUIRE(B > 0 && H > 1 && W > 1 && motion_ld >= 5, ATMVFI_EINVAL, "warp_blend: bad shape");
+    ATMVFI_REQUIRE((flow0_out == nullptr) == (flow1_out == nullptr) && (mask1_out == nullptr) == (mask2_out == nullptr),
+                   ATMVFI_EINVAL, "warp_blend: flow/mask outputs come in pairs");
+    if (pack15) ATMVFI_REQUIRE(orig0 && orig1 && pack_ld >= 15, ATMVFI_EINVAL, "warp_blend: pack15 needs orig0/orig1 and ld >= 15");
+    hipLaunchKernelGGL(warp_blend_kernel, dim3(grid_for((long long)B * H * W)), dim3(256), 0, (hipStream_t)stream, im0, im1,
+                       motion, motion_ld, (long long)motion_bstride, i0w, i1w, it, flow0_out, flow1_out, mask1_out, mask2_out,
+                       orig0, orig1, pack15, pack_ld, B, H, W);
+    return atmvfi::check_launch("warp_blend");
+}
+
+extern "C" int atmvfi_resize_bilinear_ac(const float* src, int64_t src_bstride, int64_t src_cstride, int64_t src_ystride,
+                                          int64_t src_xstride, float* dst, int B, int C, int Hi, int Wi, int Ho, int Wo,
+                                          float value_scale, void* stream) {
+    ATMVFI_REQUIRE(src && dst, ATMVFI_EINVAL, "resize_bilinear_ac: null pointer");
+    ATMVFI_REQUIRE(B > 0 && C > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, ATMVFI_EINVAL, "resize_bilinear_ac: bad shape");
+    hipLaunchKernelGGL(resize_ac_kernel, dim3(grid_for((long long)B * C * Ho * Wo)), dim3(256), 0, (hipStream_t)stream, src,
+                       (long long)src_bstride, (long long)src_cstride, (long long)src_ystride, (long long)src_xstride, dst,
+                       B, C, Hi, Wi, Ho, Wo, value_scale);
+    return atmvfi::check_launch("resize_bilinear_ac");
+}
+
+extern "C" int atmvfi_pack_frames(const float* im0, const float* im1, float* dst, int B, int H, int W, void* stream) {
+    ATMVFI_REQUIRE(im0 && im1 && dst && B > 0 && H > 0 && W > 0, ATMVFI_EINVAL, "pack_frames: bad arguments");
+    ATMVFI_REQUIRE(atmvfi::aligned16(dst), ATMVFI_EALIGN, "pack_frames: dst must be 16-byte aligned");
+    hipLaunchKernelGGL(pack_frames_kernel, dim3(grid_for(2ll * B * H * W)), dim3(256), 0, (hipStream_t)stream, im0, im1, dst,
+                       B, H, W);
+    return atmvfi::check_launch("pack_frames");
+}
+
+extern "C" int atmvfi_final_residual(const float* it, const float* r, int r_ld, float* it_sum, float* it_clamped, int B,
+                                      int H, int W, void* stream) {
+    ATMVFI_REQUIRE(it && r && it_sum && it_clamped && B > 0 && H > 0 && W > 0 && r_ld >= 3, ATMVFI_EINVAL,
+                   "final_residual: bad arguments");
+    hipLaunchKernelGGL(final_residual_kernel, dim3(grid_for((long long)B * H * W)), dim3(256), 0, (hipStream_t)stream, it, r,
+                       r_ld, it_sum, it_clamped, B, H, W);
+    return atmvfi::check_launch("final_residual");
+}
+
+extern "C" int atmvfi_l1_mean(const float* a, const float* b, float* out, int B, int64_t per_sample, void* stream) {
+    ATMVFI_REQUIRE(a && b && out && B > 0 && per_sample > 0, ATMVFI_EINVAL, "l1_mean: bad arguments");
+    long long bx = (per_sample + 256 * 16 - 1) / (256 * 16);
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(l1_mean_kernel, dim3((unsigned)bx, (unsigned)B), dim3(256), 0, (hipStream_t)stream, a, b, out,
+                       (long long)per_sample);
+    return atmvfi::check_launch("l1_mean");
+}

@@ -1,0 +1,392 @@
+"""ctypes binding of ``libatmvfi_hip.so`` (C ABI in ``include/atmvfi.h``).
+
+PyTorch is plumbing here: it owns device memory and the stream; every arithmetic
+operation of the hot path is a hand-written HIP kernel reached through this module.
+There is NO fallback: if the shared library is missing, or a tensor is not a CUDA
+(= HIP) fp32 tensor, the call raises.
+
+Tensors are passed as strided *views*: a channel slice ``buf[..., a:b]`` of an NHWC
+buffer is a view with ``ld = buf.stride(-2)``; a frame-stacked token matrix is a 3-D
+view ``[groups, rows, C]``.  The helpers below turn such views into the raw
+(pointer, ld, group stride) triples of the C ABI and validate them on the host.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libatmvfi_hip.so")
+
+GEMM_CONV, GEMM_LINEAR, GEMM_DECONV = 0, 1, 2
+
+c_f = ctypes.c_void_p      # device pointers travel as void*
+c_i = ctypes.c_int
+c_l = ctypes.c_int64
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+class GemmParams(ctypes.Structure):
+    _fields_ = [
+        ("mode", ctypes.c_int32),
+        ("in_", c_f), ("in_ld", ctypes.c_int32), ("N", ctypes.c_int32), ("H", ctypes.c_int32),
+        ("W", ctypes.c_int32), ("Cin", ctypes.c_int32),
+        ("in_gstride", ctypes.c_int64), ("in_rpg", ctypes.c_int32),
+        ("weight", c_f),
+        ("Cout", ctypes.c_int32), ("kh", ctypes.c_int32), ("kw", ctypes.c_int32), ("stride", ctypes.c_int32),
+        ("pad", ctypes.c_int32), ("dil", ctypes.c_int32),
+        ("Ho", ctypes.c_int32), ("Wo", ctypes.c_int32),
+        ("M", ctypes.c_int64),
+        ("out", c_f), ("out_ld", ctypes.c_int32),
+        ("out_gstride", ctypes.c_int64), ("out_rpg", ctypes.c_int32),
+        ("out_row_map", c_f),
+        ("bias", c_f), ("prelu", c_f), ("in_prelu", c_f), ("residual", c_f),
+        ("res_ld", ctypes.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); also the list of symbols the header declares (checked by the CPU tests)
+SIGNATURES = {
+    "atmvfi_version": (c_i, []),
+    "atmvfi_last_error": (ctypes.c_char_p, []),
+    "atmvfi_gemm": (c_i, [ctypes.POINTER(GemmParams), c_f]),
+    "atmvfi_conv2d": (c_i, [ctypes.POINTER(GemmParams), c_f]),
+    "atmvfi_linear": (c_i, [ctypes.POINTER(GemmParams), c_f]),
+    "atmvfi_deconv2x2": (c_i, [ctypes.POINTER(GemmParams), c_f]),
+    "atmvfi_packed_weight_floats": (c_l, [c_i, c_i, c_i, c_i, c_i]),
+    "atmvfi_pack_weight": (c_i, [c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
+    "atmvfi_layernorm": (c_i, [c_f, c_i, c_l, c_i, c_f, c_f, c_i, c_f, c_f, c_l, c_i, c_f]),
+    "atmvfi_dwconv3x3_gelu": (c_i, [c_f, c_i, c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
+    "atmvfi_pack_dw_weight": (c_i, [c_f, c_f, c_i, c_f]),
+    "atmvfi_window_attention": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f]),
+    "atmvfi_window_attn_cross_motion": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
+    "atmvfi_window_attn_self": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
+    "atmvfi_motion_head": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_l, c_i, c_l, c_i, c_f]),
+    "atmvfi_flow_warp": (c_i, [c_f, c_f, c_l, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_f]),
+    "atmvfi_flow_warp_nhwc": (c_i, [c_f, c_i, c_l, c_f, c_l, c_i, c_i, c_f, c_i, c_l, c_i, c_i, c_i, c_i, c_f]),
+    "atmvfi_warp_blend": (c_i, [c_f, c_f, c_f, c_i, c_l, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i,
+                                c_i, c_i, c_i, c_f]),
+    "atmvfi_resize_bilinear_ac": (c_i, [c_f, c_l, c_l, c_l, c_l, c_f, c_i, c_i, c_i, c_i, c_i, c_i, ctypes.c_float, c_f]),
+    "atmvfi_pack_frames": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_f]),
+    "atmvfi_final_residual": (c_i, [c_f, c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_f]),
+    "atmvfi_l1_mean": (c_i, [c_f, c_f, c_f, c_i, c_l, c_f]),
+}
+
+
+def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
+    if not os.path.exists(path):
+        raise HipLibraryMissing(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+@dataclass
+class PackedWeight:
+    mode: int
+    cout: int
+    cin: int
+    kh: int
+    kw: int
+    orig: torch.Tensor                 # the parameter (OIHW / [out,in] / IOHW)
+    packed: Optional[torch.Tensor]     # GEMM layout on the device (None only for test doubles)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _chk(t: torch.Tensor, what: str):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.float32:
+        raise TypeError(f"{what}: expected a CUDA/HIP float32 tensor, got "
+                        f"{getattr(t, 'device', None)} {getattr(t, 'dtype', None)}")
+
+
+def nhwc_view(t: torch.Tensor, what: str):
+    """-> (ld, N, H, W, C) of an NHWC view (channel slice of a contiguous NHWC buffer)."""
+    _chk(t, what)
+    if t.dim() != 4:
+        raise ValueError(f"{what}: expected [N,H,W,C], got {tuple(t.shape)}")
+    n, h, w, c = t.shape
+    ld = t.stride(2)
+    if (c > 1 and t.stride(3) != 1) or (h > 1 and t.stride(1) != w * ld) or (n > 1 and t.stride(0) != h * w * ld):
+        raise ValueError(f"{what}: not an NHWC pixel-contiguous view: shape {tuple(t.shape)} strides {t.stride()}")
+    return ld, n, h, w, c
+
+
+def rows_view(t: torch.Tensor, what: str):
+    """-> (ld, M, C, gstride, rpg) of a token matrix [M,C] or a grouped one [G,R,C]."""
+    _chk(t, what)
+    if t.dim() == 2:
+        if t.stride(1) != 1:
+            raise ValueError(f"{what}: rows must be channel-contiguous")
+        return t.stride(0), t.shape[0], t.shape[1], 0, 0
+    if t.dim() == 3:
+        if t.stride(2) != 1:
+            raise ValueError(f"{what}: rows must be channel-contiguous")
+        g, r, c = t.shape
+        return t.stride(1), g * r, c, t.stride(0), r
+    raise ValueError(f"{what}: expected [M,C] or [G,R,C], got {tuple(t.shape)}")
+
+
+def flow_view(flow: torch.Tensor, h: int, w: int, what: str):
+    """[B,2,H,W] view (planar, or a permuted channel pair of an NHWC map) -> (bstride, pstride, cstride)."""
+    _chk(flow, what)
+    if flow.dim() != 4 or flow.shape[1] != 2 or flow.shape[2] != h or flow.shape[3] != w:
+        raise ValueError(f"{what}: expected [B,2,{h},{w}], got {tuple(flow.shape)}")
+    ps = flow.stride(3)
+    if flow.stride(2) != w * ps:
+        raise ValueError(f"{what}: rows of the flow view must be pixel-contiguous")
+    return flow.stride(0), ps, flow.stride(1)
+
+
+def _planar(t: torch.Tensor, c: int, what: str):
+    _chk(t, what)
+    if t.dim() != 4 or t.shape[1] != c or not t.is_contiguous():
+        raise ValueError(f"{what}: expected contiguous [B,{c},H,W], got {tuple(t.shape)} strides {t.stride()}")
+
+
+class HipOps:
+    """The op vocabulary of the hot path, each a single HIP kernel launch."""
+
+    def __init__(self, device: torch.device):
+        self.lib = load_library()
+        self.device = device
+        self.profile: Optional[List] = None      # when a list: (name, meta, start_evt, end_evt) per launch
+
+    # ------------------------------------------------------------------ utils
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _check(self, rc: int, name: str):
+        if rc != 0:
+            raise RuntimeError(f"{name} failed ({rc}): {self.lib.atmvfi_last_error().decode()}")
+
+    def _run(self, name: str, meta: dict, fn, *args):
+        if self.profile is None:
+            self._check(fn(*args), name)
+            return
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        s.record()
+        self._check(fn(*args), name)
+        e.record()
+        self.profile.append((name, meta, s, e))
+
+    def empty(self, *shape) -> torch.Tensor:
+        return torch.empty(*shape, dtype=torch.float32, device=self.device)
+
+    def to_device_int(self, t: torch.Tensor) -> torch.Tensor:
+        return t.to(device=self.device, dtype=torch.int32).contiguous()
+
+    # ---------------------------------------------------------------- weights
+    def pack_weight(self, mode: int, w: torch.Tensor) -> PackedWeight:
+        _chk(w, "pack_weight")
+        w = w.detach().contiguous()
+        if mode == GEMM_DECONV:
+            cin, cout, kh, kw = w.shape
+        elif mode == GEMM_LINEAR:
+            cout, cin = w.shape[0], w.shape[1]
+            kh = kw = 1
+        else:
+            cout, cin, kh, kw = w.shape
+        n = self.lib.atmvfi_packed_weight_floats(mode, cout, cin, kh, kw)
+        dst = self.empty(n)
+        self._check(self.lib.atmvfi_pack_weight(mode, _ptr(w), _ptr(dst), cout, cin, kh, kw, self._stream()), "pack_weight")
+        return PackedWeight(mode, cout, cin, kh, kw, w, dst)
+
+    def pack_dw_weight(self, w: torch.Tensor) -> torch.Tensor:
+        _chk(w, "pack_dw_weight")
+        w = w.detach().contiguous()
+        c = w.shape[0]
+        dst = self.empty(9 * c)
+        self._check(self.lib.atmvfi_pack_dw_weight(_ptr(w), _ptr(dst), c, self._stream()), "pack_dw_weight")
+        return dst
+
+    def pad_channels(self, v: torch.Tensor, mult: int = 16) -> torch.Tensor:
+        """Per-channel vector padded with zeros to a multiple of ``mult`` (in_prelu contract)."""
+        c = v.shape[0]
+        out = torch.zeros((c + mult - 1) // mult * mult, dtype=torch.float32, device=self.device)
+        out[:c] = v.detach()
+        return out
+
+    # ------------------------------------------------------------------ GEMMs
+    def conv(self, x, w: PackedWeight, out, stride=1, pad=1, dil=1, bias=None, prelu=None, in_prelu=None):
+        ld, n, h, wd, cin = nhwc_view(x, "conv.in")
+        old, on, oh, ow, cout = nhwc_view(out, "conv.out")
+        if cin != w.cin or cout != w.cout or on != n or w.mode != GEMM_CONV:
+            raise ValueError(f"conv: shape mismatch in {tuple(x.shape)} w ({w.cout},{w.cin},{w.kh},{w.kw}) out {tuple(out.shape)}")
+        p = GemmParams(mode=GEMM_CONV, in_=x.data_ptr(), in_ld=ld, N=n, H=h, W=wd, Cin=cin, in_gstride=0, in_rpg=0,
+                       weight=w.packed.data_ptr(), Cout=cout, kh=w.kh, kw=w.kw, stride=stride, pad=pad, dil=dil,
+                       Ho=oh, Wo=ow, M=n * oh * ow, out=out.data_ptr(), out_ld=old, out_gstride=0, out_rpg=0,
+                       out_row_map=None, bias=_ptr(bias), prelu=_ptr(prelu), in_prelu=_ptr(in_prelu), residual=None, res_ld=0)
+        meta = {"flops": 2.0 * n * oh * ow * cout * cin * w.kh * w.kw,
+                "bytes": 4.0 * (n * h * wd * cin + n * oh * ow * cout + cout * cin * w.kh * w.kw),
+                "shape": f"M{n * oh * ow} N{cout} K{cin * w.kh * w.kw}"}
+        self._run("conv2d", meta, self.lib.atmvfi_conv2d, ctypes.byref(p), self._stream())
+
+    def deconv(self, x, w: PackedWeight, out, bias=None, prelu=None, in_prelu=None):
+        ld, n, h, wd, cin = nhwc_view(x, "deconv.in")
+        old, on, oh, ow, cout = nhwc_view(out, "deconv.out")
+        if cin != w.cin or cout != w.cout or on != n or w.mode != GEMM_DECONV or oh != 2 * h or ow != 2 * wd:
+            raise ValueError(f"deconv: shape mismatch in {tuple(x.shape)} w ({w.cin},{w.cout}) out {tuple(out.shape)}")
+        p = GemmParams(mode=GEMM_DECONV, in_=x.data_ptr(), in_ld=ld, N=n, H=h, W=wd, Cin=cin, in_gstride=0, in_rpg=0,
+                       weight=w.packed.data_ptr(), Cout=cout, kh=2, kw=2, stride=2, pad=0, dil=1, Ho=oh, Wo=ow,
+                       M=n * h * wd, out=out.data_ptr(), out_ld=old, out_gstride=0, out_rpg=0, out_row_map=None,
+                       bias=_ptr(bias), prelu=_ptr(prelu), in_prelu=_ptr(in_prelu), residual=None, res_ld=0)
+        meta = {"flops": 2.0 * n * h * wd * 4 * cout * cin, "bytes": 4.0 * (n * h * wd * cin + n * oh * ow * cout + 4 * cout * cin),
+                "shape": f"M{n * h * wd} N{4 * cout} K{cin}"}
+        self._run("deconv2x2", meta, self.lib.atmvfi_deconv2x2, ctypes.byref(p), self._stream())
+
+    def linear(self, x, w: PackedWeight, out, bias=None, residual=None, out_row_map=None):
+        ld, m, cin, gs, rpg = rows_view(x, "linear.in")
+        old, mo, cout, ogs, orpg = rows_view(out, "linear.out")
+        if cin != w.cin or cout != w.cout or w.kh != 1 or w.mode == GEMM_DECONV:
+            raise ValueError(f"linear: shape mismatch in {tuple(x.shape)} w ({w.cout},{w.cin}) out {tuple(out.shape)}")
+        if out_row_map is None and mo != m:
+            raise ValueError("linear: row count mismatch")
+        if out_row_map is not None and (out_row_map.numel() != m or out_row_map.dtype != torch.int32 or not out_row_map.is_cuda):
+            raise ValueError("linear: out_row_map must be a CUDA int32 tensor with one entry per GEMM row")
+        res_ld = 0
+        if residual is not None:
+            res_ld, rm, rc, rgs, _ = rows_view(residual, "linear.residual")
+            if rm != m or rc != cout or rgs != 0:
+                raise ValueError("linear: residual must be a plain [M,Cout] view")
+        p = GemmParams(mode=GEMM_LINEAR, in_=x.data_ptr(), in_ld=ld, N=1, H=1, W=1, Cin=cin, in_gstride=gs, in_rpg=rpg,
+                       weight=w.packed.data_ptr(), Cout=cout, kh=1, kw=1, stride=1, pad=0, dil=1, Ho=1, Wo=1, M=m,
+                       out=out.data_ptr(), out_ld=old, out_gstride=ogs, out_rpg=orpg, out_row_map=_ptr(out_row_map),
+                       bias=_ptr(bias), prelu=None, in_prelu=None, residual=_ptr(residual), res_ld=res_ld)
+        meta = {"flops": 2.0 * m * cout * cin, "bytes": 4.0 * (m * cin + m * cout + cout * cin), "shape": f"M{m} N{cout} K{cin}"}
+        self._run("linear", meta, self.lib.atmvfi_linear, ctypes.byref(p), self._stream())
+
+    # ------------------------------------------------------------- transformer
+    def layernorm(self, x, out, gamma, beta, src_row_map=None):
+        ld, m, c, gs, rpg = rows_view(x, "layernorm.in")
+        old, mo, co, ogs, _ = rows_view(out, "layernorm.out")
+        if co != c or ogs != 0:
+            raise ValueError("layernorm: output must be a plain [rows,C] view")
+        if src_row_map is None and mo != m:
+            raise ValueError("layernorm: row count mismatch")
+        if src_row_map is not None and src_row_map.numel() != mo:
+            raise ValueError("layernorm: src_row_map needs one entry per output row")
+        meta = {"bytes": 4.0 * 2 * mo * c}
+        self._run("layernorm", meta, self.lib.atmvfi_layernorm, _ptr(x), ld, gs, rpg, _ptr(src_row_map), _ptr(out), old,
+                  _ptr(gamma), _ptr(beta), mo, c, self._stream())
+
+    def dwconv_gelu(self, x, out, w9, bias):
+        ld, n, h, w, c = nhwc_view(x, "dwconv.in")
+        old, on, oh, ow, oc = nhwc_view(out, "dwconv.out")
+        if (on, oh, ow, oc) != (n, h, w, c):
+            raise ValueError("dwconv: shape mismatch")
+        meta = {"bytes": 4.0 * 2 * n * h * w * c}
+        self._run("dwconv3x3_gelu", meta, self.lib.atmvfi_dwconv3x3_gelu, _ptr(x), ld, _ptr(out), old, _ptr(w9), _ptr(bias),
+                  n, h, w, c, self._stream())
+
+    def window_attention(self, qkv, out, motion, labels, bw, nw, ws, heads, hd, kv_shift):
+        _chk(qkv, "attn.qkv"); _chk(out, "attn.out")
+        n = ws * ws
+        c = heads * hd
+        if tuple(qkv.shape) != (bw * n, 3 * c) or not qkv.is_contiguous() or tuple(out.shape) != (bw * n, c) or not out.is_contiguous():
+            raise ValueError(f"window_attention: qkv {tuple(qkv.shape)} / out {tuple(out.shape)} do not match Bw {bw} N {n} C {c}")
+        if motion is not None and (tuple(motion.shape) != (bw * n, heads, 2) or not motion.is_contiguous()):
+            raise ValueError("window_attention: motion must be contiguous [Bw*N, heads, 2]")
+        if labels is not None and (tuple(labels.shape) != (nw, n) or labels.dtype != torch.int32 or not labels.is_cuda):
+            raise ValueError("window_attention: labels must be CUDA int32 [nW, N]")
+        meta = {"flops": 4.0 * bw * heads * n * n * hd, "bytes": 4.0 * bw * n * 4 * c}
+        self._run("window_attention", meta, self.lib.atmvfi_window_attention, _ptr(qkv), _ptr(out), _ptr(motion), _ptr(labels),
+                  bw, nw, ws, heads, hd, kv_shift, self._stream())
+
+    def motion_head(self, motion, row_map, w0, b0, w1, b1, out):
+        old, mo, co, ogs, orpg = rows_view(out, "motion_head.out")
+        rows = motion.shape[0]
+        if co != 2:
+            raise ValueError("motion_head: output view must have 2 channels")
+        self._run("motion_head", {"bytes": 4.0 * rows * 18}, self.lib.atmvfi_motion_head, _ptr(motion), _ptr(row_map), _ptr(w0),
+                  _ptr(b0), _ptr(w1), _ptr(b1), _ptr(out), old, ogs, orpg, rows, motion.shape[1], self._stream())
+
+    # ------------------------------------------------------------------ warps
+    def flow_warp(self, src, flow, dst):
+        _chk(src, "flow_warp.src"); _chk(dst, "flow_warp.dst")
+        b, c, h, w = src.shape
+        if not src.is_contiguous() or not dst.is_contiguous() or tuple(dst.shape) != (b, c, h, w):
+            raise ValueError("flow_warp: src/dst must be contiguous NCHW of equal shape")
+        bs, ps, cs = flow_view(flow, h, w, "flow_warp.flow")
+        meta = {"bytes": 4.0 * b * h * w * (2 * c + 2)}
+        self._run("flow_warp", meta, self.lib.atmvfi_flow_warp, _ptr(src), _ptr(flow), bs, ps, cs, _ptr(dst), b, c, h, w, self._stream())
+
+    def flow_warp_nhwc(self, src, flow, dst):
+        ld, b, h, w, c = nhwc_view(src, "flow_warp_nhwc.src")
+        old, ob, oh, ow, oc = nhwc_view(dst, "flow_warp_nhwc.dst")
+        if (ob, oh, ow, oc) != (b, h, w, c):
+            raise ValueError("flow_warp_nhwc: shape mismatch")
+        bs, ps, cs = flow_view(flow, h, w, "flow_warp_nhwc.flow")
+        meta = {"bytes": 4.0 * b * h * w * (2 * c + 2)}
+        self._run("flow_warp_nhwc", meta, self.lib.atmvfi_flow_warp_nhwc, _ptr(src), ld, src.stride(0), _ptr(flow), bs, ps, cs,
+                  _ptr(dst), old, dst.stride(0), b, c, h, w, self._stream())
+
+    def warp_blend(self, im0, im1, motion, i0w, i1w, it, flow0=None, flow1=None, mask1=None, mask2=None,
+                   orig0=None, orig1=None, pack15=None):
+        _planar(im0, 3, "warp_blend.im0"); _planar(im1, 3, "warp_blend.im1")
+        b, _, h, w = im0.shape
+        mld, mb, mh, mw, mc = nhwc_view(motion, "warp_blend.motion")
+        if (mb, mh, mw, mc) != (b, h, w, 5):
+            raise ValueError(f"warp_blend: motion view {tuple(motion.shape)} != [{b},{h},{w},5]")
+        for t in (i0w, i1w, it):
+            _planar(t, 3, "warp_blend.out")
+        pld = 0
+        if pack15 is not None:
+            pld, pb, ph, pw, pc = nhwc_view(pack15, "warp_blend.pack15")
+            if (pb, ph, pw, pc) != (b, h, w, 15):
+                raise ValueError("warp_blend: pack15 view must be [B,H,W,15]")
+            _planar(orig0, 3, "warp_blend.orig0"); _planar(orig1, 3, "warp_blend.orig1")
+        meta = {"bytes": 4.0 * b * h * w * (6 + 5 + 9)}
+        self._run("warp_blend", meta, self.lib.atmvfi_warp_blend, _ptr(im0), _ptr(im1), _ptr(motion), mld, motion.stride(0),
+                  _ptr(i0w), _ptr(i1w), _ptr(it), _ptr(flow0), _ptr(flow1), _ptr(mask1), _ptr(mask2), _ptr(orig0), _ptr(orig1),
+                  _ptr(pack15), pld, b, h, w, self._stream())
+
+    def resize(self, src, dst, value_scale=1.0):
+        """src: any [B,C,Hi,Wi] strided view; dst: contiguous planar [B,C,Ho,Wo]."""
+        _chk(src, "resize.src"); _chk(dst, "resize.dst")
+        b, c, hi, wi = src.shape
+        if not dst.is_contiguous() or dst.shape[0] != b or dst.shape[1] != c:
+            raise ValueError("resize: dst must be contiguous [B,C,Ho,Wo]")
+        meta = {"bytes": 4.0 * b * c * (hi * wi + dst.shape[2] * dst.shape[3])}
+        self._run("resize_bilinear_ac", meta, self.lib.atmvfi_resize_bilinear_ac, _ptr(src), src.stride(0), src.stride(1),
+                  src.stride(2), src.stride(3), _ptr(dst), b, c, hi, wi, dst.shape[2], dst.shape[3], float(value_scale), self._stream())
+
+    def pack_frames(self, im0, im1, dst):
+        _planar(im0, 3, "pack_frames.im0"); _planar(im1, 3, "pack_frames.im1")
+        b, _, h, w = im0.shape
+        if tuple(dst.shape) != (2 * b, h, w, 4) or not dst.is_contiguous():
+            raise ValueError("pack_frames: dst must be contiguous [2B,H,W,4]")
+        self._run("pack_frames", {"bytes": 4.0 * 2 * b * h * w * 7}, self.lib.atmvfi_pack_frames, _ptr(im0), _ptr(im1), _ptr(dst),
+                  b, h, w, self._stream())
+
+    def final_residual(self, it, r, it_sum, it_clamped):
+        _planar(it, 3, "final_residual.it"); _planar(it_sum, 3, "final_residual.sum"); _planar(it_clamped, 3, "final_residual.clamped")
+        b, _, h, w = it.shape
+        rld, rb, rh, rw, rc = nhwc_view(r, "final_residual.r")
+        if (rb, rh, rw, rc) != (b, h, w, 3):
+            raise ValueError("final_residual: r must be a [B,H,W,3] view")
+        self._run("final_residual", {"bytes": 4.0 * b * h * w * 12}, self.lib.atmvfi_final_residual, _ptr(it), _ptr(r), rld,
+                  _ptr(it_sum), _ptr(it_clamped), b, h, w, self._stream())
+
+    def l1_mean(self, a, b, out):
+        _chk(a, "l1_mean.a"); _chk(b, "l1_mean.b")
+        if not a.is_contiguous() or not b.is_contiguous() or a.shape != b.shape:
+            raise ValueError("l1_mean: inputs must be contiguous and of equal shape")
+        out.zero_()
+        n = a.shape[0]
+        self._run("l1_mean", {"bytes": 8.0 * a.numel()}, self.lib.atmvfi_l1_mean, _ptr(a), _ptr(b), _ptr(out), n, a.numel() // n, self._stream())

@@ -1,0 +1,496 @@
+"""``Network``: the drop-in replacement for the reference's model class.
+
+Same constructor, attributes, methods, ``state_dict`` and ``forward(im0, im1) -> dict`` as
+``network/network_base.py:88-546`` / ``network/network_lite.py``, but
+``forward`` is a sequence of hand-written HIP kernel launches (``hip_ops.HipOps`` ->
+``libatmvfi_hip.so``) over an NHWC workspace:
+
+* feature maps live channel-last; every ``torch.cat`` / ``einops.rearrange`` of the
+  reference is realised by letting the producer write into a channel slice ("view") of
+  the consumer's buffer, so none of them moves data;
+* ``pad_if_needed`` / ``torch.roll`` / ``window_partition`` and their inverses are int32
+  row maps (``windows.py``) consumed by the LayerNorm gather and the GEMM scatter;
+* warps generate their coordinates in-kernel; flows and masks are read straight from the
+  last five channels of the decoder maps.
+
+The module holds parameters exactly like the reference (236 entries, same names), so
+``load_state_dict(strict=True)`` of published checkpoints works; GEMM-layout copies of
+the weights are derived lazily and refreshed when a parameter changes.
+
+There is no CPU path: ``forward`` requires CUDA(HIP) tensors and the built library.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import schema as S
+from .hip_ops import GEMM_CONV, GEMM_DECONV, GEMM_LINEAR, HipOps, PackedWeight
+from .windows import WindowGeometry, build_window_geometry
+
+
+class _Node(nn.Module):
+    """Anonymous container used to reproduce the reference's dotted parameter names."""
+
+
+def _r4(c: int) -> int:
+    return (c + 3) // 4 * 4
+
+
+class Network(nn.Module):
+    VARIANT = "base"
+
+    def __init__(self, global_motion: bool = True, ensemble_global_motion: bool = False, variant: Optional[str] = None):
+        super().__init__()
+        self.variant_name = variant or self.VARIANT
+        v = S.VARIANTS[self.variant_name]
+        self._v = v
+        # ---- attributes the reference exposes (network_base.py:91-201) ----
+        self.pyramid_level = S.PYRAMID_LEVELS
+        self.hidden_dims = list(v.hidden_dims)
+        self.global_motion = global_motion
+        self.ensemble_global_motion = ensemble_global_motion
+        self.local_motion_args = {"window_size": v.local_window, "num_heads": S.NUM_HEADS, "patch_size": 1,
+                                  "dim": v.local_dim, "enhance_window": 8}
+        self.global_motion_args = {"window_size": v.global_window, "num_heads": S.NUM_HEADS, "patch_size": 1,
+                                   "dim": v.global_dim}
+        if self.variant_name == "lite":
+            self.local_motion_args["mlp_ratio"] = v.mlp_ratio
+            self.global_motion_args["mlp_ratio"] = v.mlp_ratio
+        self.fused_dim = v.fused_dim
+        self.motion_out_dim = S.MOTION_OUT
+        self.fused_dim1, self.fused_dim2, self.fused_dim3 = v.decoder_widths
+        self.fused_dims = [self.fused_dim1, self.fused_dim2, self.fused_dim3, 2 * self.fused_dim1]
+        # ---- parameters / buffers under the reference's names ----
+        gen = torch.Generator().manual_seed(torch.initial_seed() % (2 ** 31))
+        for sp in S.param_schema(v):
+            t = S.init_tensor(sp, gen)
+            parts = sp.key.split(".")
+            node: nn.Module = self
+            for name in parts[:-1]:
+                if name not in node._modules:
+                    node.add_module(name, _Node())
+                node = node._modules[name]
+            if sp.is_buffer:
+                node.register_buffer(parts[-1], t)
+            else:
+                node.register_parameter(parts[-1], nn.Parameter(t))
+        # ---- runtime state (not part of the state dict) ----
+        self._ops_obj = None
+        self._prepared: Dict[str, object] = {}
+        self._prepared_sig = None
+        self._bufs: Dict[Tuple, torch.Tensor] = {}
+        self._geo: Dict[Tuple, Tuple[WindowGeometry, torch.Tensor, Optional[torch.Tensor]]] = {}
+
+    # ------------------------------------------------------------------ API parity
+    def __set_local_window_size__(self, window_size):       # network_base.py:262-265
+        self.local_motion_args["window_size"] = window_size
+        self._reset_relative_coord("local_motion_atmformer", window_size)
+
+    def __set_global_window_size__(self, window_size):      # network_base.py:267-270
+        self.global_motion_args["window_size"] = window_size
+        self._reset_relative_coord("global_motion_atmformer", window_size)
+
+    def _reset_relative_coord(self, branch: str, ws: int):
+        # attention.py:167-170 re-registers the table for the new window
+        for b in range(2):
+            attn = self._modules[branch]._modules[str(b)]._modules["attn"]
+            dev = attn._buffers["relative_coord"].device
+            attn._buffers["relative_coord"] = S.relative_coord_table(ws).to(dev)
+
+    _GLOBAL_PARTS = ("last_feat_extract", "global_feature_fusion", "global_motion_atmformer", "global_motion_mlp")
+    _REFINE_PARTS = ("proj", "down1", "down2", "down3", "up1", "up2", "up3", "refine_head")
+    _LOCAL_PARTS = ("feat_extracts", "cross_scale_feature_fusion", "local_motion_atmformer", "local_motion_mlp",
+                    "feat_enhance_transformer", "upsample_pyramid") + _REFINE_PARTS
+
+    def _grad(self, parts, flag):
+        for p in parts:
+            self._modules[p].requires_grad_(flag)
+
+    def __freeze_global_motion__(self):       # network_base.py:272-276
+        self._grad(self._GLOBAL_PARTS, False)
+
+    def __finetune_global_motion__(self):     # :278-282
+        self._grad(self._GLOBAL_PARTS, True)
+
+    def __freeze_local_motion__(self):        # :284-298
+        self._grad(self._LOCAL_PARTS, False)
+
+    def __finetune_local_motion__(self):      # :300-314
+        self._grad(self._LOCAL_PARTS, True)
+
+    def __finetune_refinenet_only__(self):    # :316-334 (base only in the reference)
+        self._grad(self._GLOBAL_PARTS, False)
+        self._grad([p for p in self._LOCAL_PARTS if p not in self._REFINE_PARTS], False)
+        self._grad(self._REFINE_PARTS, True)
+
+    # ------------------------------------------------------------------ plumbing
+    def set_ops(self, ops):
+        """Inject the op backend (tests inject a CPU double to check host logic; the
+        default is the HIP library and nothing else)."""
+        self._ops_obj = ops
+        self._prepared_sig = None
+        self._bufs.clear()
+        self._geo.clear()
+
+    def _ops(self, device: torch.device):
+        if self._ops_obj is None:
+            if device.type != "cuda":
+                raise RuntimeError("atm-vfi_amd.Network.forward runs on MI355X only: move the model and its inputs to "
+                                   "'cuda' (HIP). There is no CPU implementation in the product; the CPU oracle lives in oracle/.")
+            self._ops_obj = HipOps(device)
+        return self._ops_obj
+
+    def buf(self, name: str, *shape) -> torch.Tensor:
+        key = (name,) + tuple(shape)
+        t = self._bufs.get(key)
+        if t is None:
+            t = self._ops_obj.empty(*shape)
+            self._bufs[key] = t
+        return t
+
+    def release_workspace(self):
+        self._bufs.clear()
+
+    def geometry(self, frames, h, w, ws, shift):
+        key = (frames, h, w, ws, shift)
+        g = self._geo.get(key)
+        if g is None:
+            geo = build_window_geometry(frames, h, w, ws, shift)
+            ops = self._ops_obj
+            g = (geo, ops.to_device_int(geo.row_map), None if geo.labels is None else ops.to_device_int(geo.labels))
+            self._geo[key] = g
+        return g
+
+    # ------------------------------------------------------------------ weights
+    def _prepare(self, ops):
+        sd = {k: v for k, v in self.named_parameters()}
+        sig = tuple((p.data_ptr(), p._version) for p in sd.values())
+        if sig == self._prepared_sig:
+            return self._prepared
+        P: Dict[str, object] = {}
+        for k, p in sd.items():
+            P[k] = p.detach()
+        for sp in S.param_schema(self._v):
+            k, shp = sp.key, sp.shape
+            if sp.is_buffer or not k.endswith(".weight"):
+                continue
+            w = sd[k].detach()
+            if len(shp) == 4 and "dwconv" in k:
+                P["pk:" + k] = ops.pack_dw_weight(w)
+            elif len(shp) == 4 and shp[2] == 2:                      # ConvTranspose2d (Cin,Cout,2,2)
+                P["pk:" + k] = ops.pack_weight(GEMM_DECONV, w)
+            elif len(shp) == 4 and shp[2] == 1 and ".proj." in k:    # fusion 1x1 conv used as a row GEMM
+                P["pk:" + k] = ops.pack_weight(GEMM_LINEAR, w.reshape(shp[0], shp[1]))
+            elif len(shp) == 4:
+                P["pk:" + k] = ops.pack_weight(GEMM_CONV, w)
+            elif len(shp) == 2 and ".attn.mlp." not in k:
+                if k.endswith("attn.kv.weight"):
+                    continue
+                if k.endswith("attn.q.weight"):                      # [Wq; Wkv] -> one [3C,C] projection
+                    kv = sd[k.replace(".q.weight", ".kv.weight")].detach()
+                    P["pk:" + k.replace(".q.weight", ".qkv.weight")] = ops.pack_weight(GEMM_LINEAR, torch.cat([w, kv], 0))
+                else:
+                    P["pk:" + k] = ops.pack_weight(GEMM_LINEAR, w)
+        for st in (1, 2):     # leading PReLU of decoder stages 1-2, applied on the deconv's input load
+            P[f"inprelu:{st}"] = ops.pad_channels(sd[f"upsample_pyramid.{st}.0.weight"])
+        self._prepared = P
+        self._prepared_sig = sig
+        return P
+
+    # ------------------------------------------------------------------ layers
+    def _conv_act(self, ops, P, p, x, out, stride=1):
+        ops.conv(x, P[f"pk:{p}.0.weight"], out, stride=stride, pad=1, dil=1, bias=P[f"{p}.0.bias"], prelu=P[f"{p}.1.weight"])
+
+    def _conv_plain(self, ops, P, p, x, out, stride=1, pad=1, dil=1):
+        ops.conv(x, P[f"pk:{p}.weight"], out, stride=stride, pad=pad, dil=dil, bias=P[f"{p}.bias"])
+
+    def _deconv_act(self, ops, P, p, x, out, in_prelu=None):
+        ops.deconv(x, P[f"pk:{p}.0.weight"], out, bias=P[f"{p}.0.bias"], prelu=P[f"{p}.1.weight"], in_prelu=in_prelu)
+
+    def _encoder(self, ops, P, x0, tag: str):
+        """shared_feat_extraction + cross-scale fusion buffers.  x0: [F,H,W,4].  Returns (e1, e2, fuse_l)
+        with s3 already written into fuse_l[..., -d3:] (network_base.py:342-352)."""
+        d = self._v.hidden_dims
+        f, h, w, _ = x0.shape
+        a = self.buf(f"{tag}e0a", f, h, w, d[0]); self._conv_act(ops, P, "feat_extracts.0.0", x0[..., :3], a)
+        e0 = self.buf(f"{tag}e0", f, h, w, d[0]); self._conv_act(ops, P, "feat_extracts.0.1", a, e0)
+        a = self.buf(f"{tag}e1a", f, h // 2, w // 2, d[1]); self._conv_act(ops, P, "feat_extracts.1.0", e0, a, 2)
+        e1 = self.buf(f"{tag}e1", f, h // 2, w // 2, d[1]); self._conv_act(ops, P, "feat_extracts.1.1", a, e1)
+        a = self.buf(f"{tag}e2a", f, h // 4, w // 4, d[2]); self._conv_act(ops, P, "feat_extracts.2.0", e1, a, 2)
+        e2 = self.buf(f"{tag}e2", f, h // 4, w // 4, d[2]); self._conv_act(ops, P, "feat_extracts.2.1", a, e2)
+        a = self.buf(f"{tag}e3a", f, h // 8, w // 8, d[3]); self._conv_act(ops, P, "feat_extracts.3.0", e2, a, 2)
+        fuse = self.buf(f"{tag}fuse_l", f, h // 8, w // 8, self._v.local_dim)
+        self._conv_act(ops, P, "feat_extracts.3.1", a, fuse[..., self._v.local_dim - d[3]:])
+        return e1, e2, fuse
+
+    def _fusion(self, ops, P, p, fine, mid, fuse, c_mid, c_fine, tag):
+        """CrossScaleFeatureFusion (network_base.py:73-85); the coarsest scale is already in
+        fuse[..., c_mid+2*c_fine:].  Returns LayerNorm'ed tokens [F*h*w, C]."""
+        f, h, w, c = fuse.shape
+        self._conv_plain(ops, P, f"{p}.layers.0", mid, fuse[..., 0:c_mid], stride=2, pad=1, dil=1)
+        self._conv_plain(ops, P, f"{p}.layers.1", fine, fuse[..., c_mid:c_mid + c_fine], stride=4, pad=1, dil=1)
+        self._conv_plain(ops, P, f"{p}.layers.2", fine, fuse[..., c_mid + c_fine:c_mid + 2 * c_fine], stride=4, pad=2, dil=2)
+        t = self.buf(f"{tag}fproj", f * h * w, c)
+        ops.linear(fuse.reshape(f * h * w, c), P[f"pk:{p}.proj.weight"], t, bias=P[f"{p}.proj.bias"])
+        out = self.buf(f"{tag}fnorm", f * h * w, c)
+        ops.layernorm(t, out, P[f"{p}.norm.weight"], P[f"{p}.norm.bias"])
+        return out
+
+    def _block(self, ops, P, p, x, frames, h, w, ws, shift, cross, out, motion_dst, tag):
+        """One shifted-window transformer block (ATMFormer attention.py:265-334 when ``cross``,
+        RefineBottleneck :433-495 otherwise).  x/out: token-matrix views in image order."""
+        c = x.shape[-1]
+        heads = S.NUM_HEADS
+        hd = c // heads
+        geo, row_map, labels = self.geometry(frames, h, w, ws, shift)
+        mw = frames * geo.n_windows * geo.tokens
+        bw = frames * geo.n_windows
+        xn = self.buf(f"{tag}xn", mw, c)
+        ops.layernorm(x, xn, P[f"{p}.norm1.weight"], P[f"{p}.norm1.bias"], src_row_map=row_map)
+        qkv = self.buf(f"{tag}qkv", mw, 3 * c)
+        ops.linear(xn, P[f"pk:{p}.attn.qkv.weight"], qkv)
+        ao = self.buf(f"{tag}ao", mw, c)
+        mo = self.buf(f"{tag}mo", mw, heads, 2) if cross else None
+        ops.window_attention(qkv, ao, mo, labels, bw, geo.n_windows, ws, heads, hd, bw // 2 if cross else 0)
+        xb = self.buf(f"{tag}xb", frames * h * w, c)
+        ops.linear(ao, P[f"pk:{p}.attn.proj.weight"], xb, bias=P[f"{p}.attn.proj.bias"], residual=xn, out_row_map=row_map)
+        if cross:
+            ops.motion_head(mo, row_map, P[f"{p}.attn.mlp.0.weight"], P[f"{p}.attn.mlp.0.bias"],
+                            P[f"{p}.attn.mlp.2.weight"], P[f"{p}.attn.mlp.2.bias"], motion_dst)
+        y = self.buf(f"{tag}ln2", frames * h * w, c)
+        ops.layernorm(xb, y, P[f"{p}.norm2.weight"], P[f"{p}.norm2.bias"])
+        hid = P[f"{p}.mlp.fc1.bias"].shape[0]
+        f1 = self.buf(f"{tag}fc1", frames, h, w, hid)
+        ops.linear(y, P[f"pk:{p}.mlp.fc1.weight"], f1.reshape(frames * h * w, hid), bias=P[f"{p}.mlp.fc1.bias"])
+        f2 = self.buf(f"{tag}dw", frames, h, w, hid)
+        ops.dwconv_gelu(f1, f2, P[f"pk:{p}.mlp.dwconv.dwconv.weight"], P[f"{p}.mlp.dwconv.dwconv.bias"])
+        ops.linear(f2.reshape(frames * h * w, hid), P[f"pk:{p}.mlp.fc2.weight"], out, bias=P[f"{p}.mlp.fc2.bias"], residual=xb)
+
+    @staticmethod
+    def _stacked(buf, off, c):
+        """View the channel range [off, off+2c) of an [B,h,w,LD] buffer as the frame-stacked token
+        matrix [2, B*h*w, c]: '(N B) (H W) C -> B (N C) H W' of the reference without moving data."""
+        b, h, w, ld = buf.shape
+        flat = buf.reshape(b * h * w, ld)[:, off:off + 2 * c]
+        return flat.unflatten(1, (2, c)).permute(1, 0, 2)
+
+    def _motion_branch(self, ops, P, branch, mlp, x_tokens, b, h, w, ws, tag):
+        """Two ATMFormer blocks + motion MLP (estimate_{local,global}_motion, network_base.py:367-415).
+        Returns (mlp_in buffer, last hidden map) -- the caller runs the 1x1 head into its own slice."""
+        c = x_tokens.shape[-1]
+        cin = 8 + 2 * c
+        mlp_in = self.buf(f"{tag}mlp_in", b, h, w, cin)
+        flat = mlp_in.reshape(b * h * w, cin)
+        x = x_tokens
+        for blk in range(2):
+            mdst = flat[:, 4 * blk:4 * blk + 4].unflatten(1, (2, 2)).permute(1, 0, 2)       # '(N B) L K -> B L (N K)'
+            out = self._stacked(mlp_in, 8, c) if blk == 1 else self.buf(f"{tag}blk0", 2 * b * h * w, c)
+            self._block(ops, P, f"{branch}.{blk}", x, 2 * b, h, w, ws, 0 if blk == 0 else ws // 2, True, out, mdst, tag)
+            x = out
+        hid = P[f"{mlp}.0.0.bias"].shape[0]
+        t1 = self.buf(f"{tag}mm1", b, h, w, hid); self._conv_act(ops, P, f"{mlp}.0", mlp_in, t1)
+        t2 = self.buf(f"{tag}mm2", b, h, w, hid); self._conv_act(ops, P, f"{mlp}.1", t1, t2)
+        return mlp_in, t2
+
+    def _global_motion(self, ops, P, e2, fuse_l, b, tag):
+        """estimate_global_motion (network_base.py:391-415): returns the raw 5-channel map [B,h_,w_,5]."""
+        v = self._v
+        d = v.hidden_dims
+        f, h8, w8, _ = fuse_l.shape
+        h_, w_ = h8 // 2, w8 // 2
+        s3 = fuse_l[..., v.local_dim - d[3]:]
+        fuse_g = self.buf(f"{tag}fuse_g", f, h_, w_, v.global_dim)
+        a = self.buf(f"{tag}ga", f, h_, w_, v.last_feat_dim)
+        self._conv_act(ops, P, "last_feat_extract.0", s3, a, 2)
+        self._conv_act(ops, P, "last_feat_extract.1", a, fuse_g[..., d[3] + 2 * d[2]:])
+        tokens = self._fusion(ops, P, "global_feature_fusion", e2, s3, fuse_g, d[3], d[2], tag + "g")
+        mlp_in, t2 = self._motion_branch(ops, P, "global_motion_atmformer", "global_motion_mlp", tokens, b, h_, w_,
+                                         self.global_motion_args["window_size"], tag + "g")
+        gout = self.buf(f"{tag}gout", b, h_, w_, 8)
+        self._conv_plain(ops, P, "global_motion_mlp.2", t2, gout[..., :5], pad=0)
+        return gout
+
+    def _ensemble_flows(self, ops, P, im0, im1):
+        """multiscale_global_motion_ensemble (network_base.py:564-605): global flows from the x1, x1/2
+        and x1/4 inputs; per sample keep the one whose warped full-resolution frames agree best."""
+        b, _, h, w = im0.shape
+        cands, losses = [], []
+        c0, c1 = im0, im1
+        for lvl in range(3):
+            if lvl:
+                n0 = self.buf(f"ens{lvl}i0", b, 3, h >> lvl, w >> lvl); ops.resize(c0, n0)
+                n1 = self.buf(f"ens{lvl}i1", b, 3, h >> lvl, w >> lvl); ops.resize(c1, n1)
+                c0, c1 = n0, n1
+            hh, ww = h >> lvl, w >> lvl
+            if hh % 16 or ww % 16:
+                raise ValueError(f"ensemble_global_motion needs H, W divisible by 64 (level {lvl} is {hh}x{ww})")
+            x0 = self.buf(f"ens{lvl}x0", 2 * b, hh, ww, 4); ops.pack_frames(c0, c1, x0)
+            _, e2, fuse = self._encoder(ops, P, x0, f"ens{lvl}")
+            gout = self._global_motion(ops, P, e2, fuse, b, f"ens{lvl}")
+            f0 = gout[..., 0:2].permute(0, 3, 1, 2)
+            f1 = gout[..., 2:4].permute(0, 3, 1, 2)
+            factor = 16 << lvl
+            u0 = self.buf(f"ens{lvl}u0", b, 2, h, w); ops.resize(f0, u0, float(factor))      # global_alignmentness (:548-562)
+            u1 = self.buf(f"ens{lvl}u1", b, 2, h, w); ops.resize(f1, u1, float(factor))
+            wa = self.buf("ens_wa", b, 3, h, w); ops.flow_warp(im0, u0, wa)
+            wb = self.buf("ens_wb", b, 3, h, w); ops.flow_warp(im1, u1, wb)
+            loss = self.buf(f"ens{lvl}loss", b); ops.l1_mean(wa, wb, loss)
+            # candidate at the level-0 flow resolution (H/16): x1, x2, x4 up-sampling of the coarser flows
+            if lvl == 0:
+                k0 = self.buf("ens_c0_0", b, 2, h // 16, w // 16); ops.resize(f0, k0, 1.0)
+                k1 = self.buf("ens_c1_0", b, 2, h // 16, w // 16); ops.resize(f1, k1, 1.0)
+            else:
+                k0 = self.buf(f"ens_c0_{lvl}", b, 2, h // 16, w // 16); ops.resize(f0, k0, float(1 << lvl))
+                k1 = self.buf(f"ens_c1_{lvl}", b, 2, h // 16, w // 16); ops.resize(f1, k1, float(1 << lvl))
+            cands.append((k0, k1)); losses.append(loss)
+        ls = torch.stack(losses, 0)                        # [3,B]; first minimum wins like the reference's if/elif chain
+        pick = ls.argmin(dim=0)
+        sel0 = torch.stack([c[0] for c in cands], 0)       # [3,B,2,h_,w_]
+        sel1 = torch.stack([c[1] for c in cands], 0)
+        idx = torch.arange(b, device=pick.device)
+        return sel0[pick, idx].contiguous(), sel1[pick, idx].contiguous()
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, im0: torch.Tensor, im1: torch.Tensor):
+        if im0.shape != im1.shape or im0.dim() != 4 or im0.shape[1] != 3:
+            raise ValueError(f"expected two [B,3,H,W] frames, got {tuple(im0.shape)} and {tuple(im1.shape)}")
+        ops = self._ops(im0.device)
+        b, _, H, W = im0.shape
+        need = 16 if self.global_motion else 8
+        if H % need or W % need:
+            raise ValueError(f"H and W must be multiples of {need} (got {H}x{W}); pad with InputPadder as the reference's callers do")
+        v = self._v
+        d = v.hidden_dims
+        C = v.local_dim
+        with torch.no_grad():
+            im0 = im0.detach().contiguous().float()
+            im1 = im1.detach().contiguous().float()
+            P = self._prepare(ops)
+            h, w = H // 8, W // 8
+            # image pyramids (network_base.py:444-448)
+            pyr0, pyr1 = [im0], [im1]
+            for l in range(1, 4):
+                t0 = self.buf(f"pyr0_{l}", b, 3, H >> l, W >> l); ops.resize(pyr0[-1], t0)
+                t1 = self.buf(f"pyr1_{l}", b, 3, H >> l, W >> l); ops.resize(pyr1[-1], t1)
+                pyr0.append(t0); pyr1.append(t1)
+            # encoder + local fusion (:451-455)
+            x0 = self.buf("x0", 2 * b, H, W, 4); ops.pack_frames(im0, im1, x0)
+            e1, e2, fuse_l = self._encoder(ops, P, x0, "")
+            feat = self._fusion(ops, P, "cross_scale_feature_fusion", e1, e2, fuse_l, d[2], d[1], "l")   # [2B*h*w, C]
+            it_list: List[torch.Tensor] = []
+            w0_list: List[torch.Tensor] = []
+            w1_list: List[torch.Tensor] = []
+            x_tokens = feat
+            if self.global_motion:                                                        # (:457-485)
+                h_, w_ = H // 16, W // 16
+                if self.ensemble_global_motion:
+                    g0, g1 = self._ensemble_flows(ops, P, im0, im1)
+                else:
+                    gout = self._global_motion(ops, P, e2, fuse_l, b, "")
+                    i0_16 = self.buf("im0_16", b, 3, h_, w_); ops.resize(pyr0[3], i0_16)
+                    i1_16 = self.buf("im1_16", b, 3, h_, w_); ops.resize(pyr1[3], i1_16)
+                    a, c, t = (ops.empty(b, 3, h_, w_) for _ in range(3))
+                    ops.warp_blend(i0_16, i1_16, gout[..., :5], a, c, t)
+                    w0_list.insert(0, a); w1_list.insert(0, c); it_list.insert(0, t)
+                    g0 = gout[..., 0:2].permute(0, 3, 1, 2)
+                    g1 = gout[..., 2:4].permute(0, 3, 1, 2)
+                gf0 = self.buf("gf0_3", b, 2, h, w); ops.resize(g0, gf0, 2.0)
+                gf1 = self.buf("gf1_3", b, 2, h, w); ops.resize(g1, gf1, 2.0)
+                featw = self.buf("featw", 2 * b, h, w, C)
+                f4 = feat.reshape(2 * b, h, w, C)
+                ops.flow_warp_nhwc(f4[:b], gf0, featw[:b])
+                ops.flow_warp_nhwc(f4[b:], gf1, featw[b:])
+                x_tokens = featw.reshape(2 * b * h * w, C)
+                for i in (3, 2, 1, 0):
+                    n0 = self.buf(f"pw0_{i}", b, 3, H >> i, W >> i); ops.flow_warp(pyr0[i], gf0, n0)
+                    n1 = self.buf(f"pw1_{i}", b, 3, H >> i, W >> i); ops.flow_warp(pyr1[i], gf1, n1)
+                    pyr0[i], pyr1[i] = n0, n1
+                    if i:
+                        u0 = self.buf(f"gf0_{i - 1}", b, 2, H >> (i - 1), W >> (i - 1)); ops.resize(gf0, u0, 2.0)
+                        u1 = self.buf(f"gf1_{i - 1}", b, 2, H >> (i - 1), W >> (i - 1)); ops.resize(gf1, u1, 2.0)
+                        gf0, gf1 = u0, u1
+            # local motion (:490) -> raw motion map goes straight into the decoder input
+            cdec = 2 * C + S.MOTION_OUT
+            dec_in = self.buf("dec_in", b, h, w, _r4(cdec))
+            mlp_in, t2 = self._motion_branch(ops, P, "local_motion_atmformer", "local_motion_mlp", x_tokens, b, h, w,
+                                             self.local_motion_args["window_size"], "l")
+            motion8 = dec_in[..., 2 * C:2 * C + 5]
+            self._conv_plain(ops, P, "local_motion_mlp.2", t2, motion8, pad=0)
+            # feature enhancement (:493-494)
+            x = self._stacked(mlp_in, 8, C)
+            e_mid = self.buf("enh0", 2 * b * h * w, C)
+            self._block(ops, P, "feat_enhance_transformer.0", x, 2 * b, h, w, 8, 0, False, e_mid, None, "e")
+            enh = self.buf("enh1", 2 * b, h, w, C)
+            self._block(ops, P, "feat_enhance_transformer.1", e_mid, 2 * b, h, w, 8, 4, False, enh.reshape(2 * b * h * w, C), None, "e")
+            # synthesis at H/8 and warped features (:496-506)
+            fl0 = motion8[..., 0:2].permute(0, 3, 1, 2)
+            fl1 = motion8[..., 2:4].permute(0, 3, 1, 2)
+            a, c, t = (ops.empty(b, 3, h, w) for _ in range(3))
+            ops.warp_blend(pyr0[3], pyr1[3], motion8, a, c, t)
+            w0_list.insert(0, a); w1_list.insert(0, c); it_list.insert(0, t)
+            ops.flow_warp_nhwc(enh[:b], fl0, dec_in[..., 0:C])
+            ops.flow_warp_nhwc(enh[b:], fl1, dec_in[..., C:2 * C])
+            # decoder (:511-528) writing into the U-Net's skip buffers
+            rh = v.refine_hidden
+            w1d, w2d, w3d = v.decoder_widths
+            bufC = self.buf("bufC", b, H // 4, W // 4, 4 * rh + _r4(w1d + 5))      # [feat2_ | feat2 | dec0]
+            bufB = self.buf("bufB", b, H // 2, W // 2, 2 * rh + _r4(w2d + 5))      # [feat1_ | feat1 | dec1]
+            bufA = self.buf("bufA", b, H, W, 2 * rh)                               # [feat0_ | feat0]
+            rin = self.buf("refine_in", b, H, W, v.refine_in)                      # [dec2 | im0 I0 im1 I1 It]
+            dsts = (bufC[..., 4 * rh:4 * rh + w1d + 5], bufB[..., 2 * rh:2 * rh + w2d + 5], rin[..., 0:w3d + 5])
+            x = dec_in[..., 0:cdec]
+            flow0 = flow1 = m1 = m2 = None
+            for st, scale in enumerate((2, 1, 0)):
+                pfx = f"upsample_pyramid.{st}"
+                o = 1 if st else 0
+                cout = dsts[st].shape[-1]
+                hs, wsz = H >> scale, W >> scale
+                t1 = self.buf(f"dec_t1_{st}", b, hs, wsz, _r4(cout))[..., :cout]
+                self._deconv_act(ops, P, f"{pfx}.{o}", x, t1, in_prelu=P[f"inprelu:{st}"] if st else None)
+                t2b = self.buf(f"dec_t2_{st}", b, hs, wsz, _r4(cout))[..., :cout]
+                self._conv_act(ops, P, f"{pfx}.{o + 1}", t1, t2b)
+                self._conv_plain(ops, P, f"{pfx}.{o + 2}", t2b, dsts[st])
+                x = dsts[st]
+                mot = x[..., cout - 5:cout]
+                a, c, t = (ops.empty(b, 3, hs, wsz) for _ in range(3))
+                if scale == 0:
+                    flow0, flow1 = ops.empty(b, 2, H, W), ops.empty(b, 2, H, W)
+                    m1, m2 = ops.empty(b, 1, H, W), ops.empty(b, 1, H, W)
+                    ops.warp_blend(pyr0[0], pyr1[0], mot, a, c, t, flow0, flow1, m1, m2, im0, im1, rin[..., w3d + 5:w3d + 20])
+                else:
+                    ops.warp_blend(pyr0[scale], pyr1[scale], mot, a, c, t)
+                w0_list.insert(0, a); w1_list.insert(0, c); it_list.insert(0, t)
+            # residual refinement U-Net (:417-431)
+            feat0 = bufA[..., rh:2 * rh]; self._conv_act(ops, P, "proj", rin, feat0)
+            feat1 = bufB[..., rh:2 * rh]; self._conv_act(ops, P, "down1.0", feat0, feat1, 2)
+            d2a = self.buf("d2a", b, H // 4, W // 4, 2 * rh); self._conv_act(ops, P, "down2.0", bufB[..., rh:2 * rh + w2d], d2a, 2)
+            feat2 = bufC[..., 2 * rh:4 * rh]; self._conv_act(ops, P, "down2.1", d2a, feat2)
+            d3a = self.buf("d3a", b, h, w, 4 * rh); self._conv_act(ops, P, "down3.0", bufC[..., 2 * rh:4 * rh + w1d], d3a, 2)
+            d3b = self.buf("d3b", b, h, w, 4 * rh); self._conv_act(ops, P, "down3.1", d3a, d3b)
+            feat3 = self.buf("d3c", b, h, w, 4 * rh); self._conv_act(ops, P, "down3.2", d3b, feat3)
+            u1a = self.buf("u1a", b, H // 4, W // 4, 2 * rh); self._deconv_act(ops, P, "up1.0", feat3, u1a)
+            self._conv_act(ops, P, "up1.1", u1a, bufC[..., 0:2 * rh])
+            u2a = self.buf("u2a", b, H // 2, W // 2, 2 * rh); self._deconv_act(ops, P, "up2.0", bufC[..., 0:4 * rh], u2a)
+            self._conv_act(ops, P, "up2.1", u2a, bufB[..., 0:rh])
+            self._deconv_act(ops, P, "up3.0", bufB[..., 0:2 * rh], bufA[..., 0:rh])
+            r1 = self.buf("r1", b, H, W, rh); self._conv_act(ops, P, "refine_head.0", bufA, r1)
+            r = self.buf("r", b, H, W, 4); self._conv_act(ops, P, "refine_head.1", r1, r[..., :3])
+            it_sum, it_final = ops.empty(b, 3, H, W), ops.empty(b, 3, H, W)
+            ops.final_residual(it_list[0], r[..., :3], it_sum, it_final)
+            i_t_0, i_t_1 = w0_list[0], w1_list[0]
+            it_list[0] = it_sum          # the reference adds the residual in place (network_base.py:532)
+        return {"I_t": it_final, "im_t_list": it_list, "im0_warped_list": w0_list, "im1_warped_list": w1_list,
+                "opt_flow_0": flow0, "opt_flow_1": flow1, "I_t_0": i_t_0, "I_t_1": i_t_1,
+                "occ_mask1": m1, "occ_mask2": m2}
+
+
+class NetworkBase(Network):
+    VARIANT = "base"
+
+
+class NetworkLite(Network):
+    VARIANT = "lite"

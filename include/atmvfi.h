@@ -1,0 +1,202 @@
+/*
+ * atmvfi.h -- C ABI of libatmvfi_hip.so: the MI355X (gfx950) kernels underneath the
+ * ATM-VFI `Network.forward` hot path.
+ *
+ * The reference (Gancheekim/ATM-VFI) has no FFI seam: every device op is an implicit
+ * ATen call issued from Python.  Each entry point below therefore
+ * cites the reference *call site(s)* whose arithmetic it replaces.  The Python host
+ * (atm-vfi_amd/hip_ops.py) binds these with ctypes; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to fp32 unless stated; the library allocates
+ *    nothing, owns nothing and keeps no mutable global state (re-entrant per stream);
+ *  - `stream` is a hipStream_t passed as void* (0 = default stream);
+ *  - feature maps are NHWC "views": (ptr, ld) with ptr already advanced to the first
+ *    channel of the view and `ld` = floats between consecutive pixels.  Views let a
+ *    producer write straight into a slice of a wider concat buffer, so torch.cat /
+ *    einops.rearrange of the reference never materialise.  ld % 4 == 0 and 16-byte
+ *    aligned pointers are required (checked; ATMVFI_EALIGN);
+ *  - image-like tensors (3-channel frames, 2-channel flows, 1-channel masks) are
+ *    planar NCHW, exactly as the reference's API returns them;
+ *  - return value: 0 on success, negative ATMVFI_E* otherwise; atmvfi_last_error()
+ *    gives a thread-local message.  Shapes are validated on the host BEFORE launch.
+ */
+#ifndef ATMVFI_H
+#define ATMVFI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ATMVFI_OK        0
+#define ATMVFI_EINVAL   -1   /* bad shape / null pointer / unsupported configuration */
+#define ATMVFI_EALIGN   -2   /* pointer or leading dimension not 16-byte aligned */
+#define ATMVFI_ELAUNCH  -3   /* HIP launch error */
+
+int         atmvfi_version(void);            /* (major<<16)|(minor<<8)|patch */
+const char* atmvfi_last_error(void);
+
+/* ------------------------------------------------------------------------------------
+ * Implicit-GEMM contraction engine on fp32 MFMA (v_mfma_f32_16x16x4_f32).
+ *
+ * One kernel family serves the three contraction shapes of the hot path:
+ *   ATMVFI_GEMM_CONV   Conv2d k in {1,3}, stride {1,2,4}, dilation {1,2}, zero pad
+ *                      (network_base.py:20-25 conv(); :42-48 fusion convs; :158,:195 heads)
+ *   ATMVFI_GEMM_LINEAR nn.Linear over token rows (attention.py:138-141,349-351 q/kv/qkv/proj;
+ *                      :93-96 fc1/fc2), with optional row groups / row scatter map
+ *   ATMVFI_GEMM_DECONV ConvTranspose2d(k2,s2,p0) (network_base.py:27-32 deconv()) as a GEMM to
+ *                      4*Cout columns with a pixel-shuffle store
+ * Epilogue, in order: + bias[co]; PReLU(slope[co]) if `prelu`; + residual if `residual`.
+ * `in_prelu` applies a per-input-channel PReLU while loading the input (the leading
+ * nn.PReLU of upsample_pyramid stages 1-2, network_base.py:209,215).
+ * ---------------------------------------------------------------------------------- */
+#define ATMVFI_GEMM_CONV   0
+#define ATMVFI_GEMM_LINEAR 1
+#define ATMVFI_GEMM_DECONV 2
+
+typedef struct atmvfi_gemm_params {
+    int32_t mode;
+    /* input view.  CONV/DECONV: NHWC [N,H,W,Cin].  LINEAR: rows; row m lives at
+       in + (m / in_rpg) * in_gstride + (m % in_rpg) * in_ld   (in_rpg == 0: m * in_ld) */
+    const float* in;
+    int32_t in_ld, N, H, W, Cin;
+    int64_t in_gstride; int32_t in_rpg;
+    /* weights packed by atmvfi_pack_*: [Nrows16][taps][CinPad16] fp32, zero padded */
+    const float* weight;
+    int32_t Cout, kh, kw, stride, pad, dil;
+    int32_t Ho, Wo;            /* CONV: output size; DECONV: 2H,2W; LINEAR: ignored */
+    int64_t M;                 /* LINEAR: number of rows; others: N*Ho*Wo (CONV) / N*H*W (DECONV) */
+    /* output view; row r at out + (r / out_rpg) * out_gstride + (r % out_rpg) * out_ld */
+    float* out;
+    int32_t out_ld;
+    int64_t out_gstride; int32_t out_rpg;
+    const int32_t* out_row_map;   /* optional [M]: destination row per GEMM row, <0 = drop */
+    const float* bias;            /* [Cout] or NULL */
+    const float* prelu;           /* [Cout] or NULL */
+    const float* in_prelu;        /* [Cin]  or NULL */
+    const float* residual;        /* optional, indexed by GEMM row m (before out_row_map) */
+    int32_t res_ld;
+} atmvfi_gemm_params;
+
+int atmvfi_gemm(const atmvfi_gemm_params* p, void* stream);
+
+/* Convenience wrappers with the reference-layer names (thin shims over atmvfi_gemm). */
+int atmvfi_conv2d(const atmvfi_gemm_params* p, void* stream);
+int atmvfi_linear(const atmvfi_gemm_params* p, void* stream);
+int atmvfi_deconv2x2(const atmvfi_gemm_params* p, void* stream);
+
+/* Weight re-layout (device -> device, run once per checkpoint load).
+ *  conv  : OIHW [Cout,Cin,kh,kw]  -> [rows16(Cout)][kh*kw][CinPad16]
+ *  linear: [Cout,Cin]             -> same with one tap
+ *  deconv: IOHW [Cin,Cout,2,2]    -> [rows16(4*CoutP4)][1][CinPad16], row = (a*2+b)*CoutP4 + co
+ * `dst` must hold atmvfi_packed_weight_floats(...) floats. */
+int64_t atmvfi_packed_weight_floats(int mode, int Cout, int Cin, int kh, int kw);
+int atmvfi_pack_weight(int mode, const float* src, float* dst, int Cout, int Cin, int kh, int kw, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * LayerNorm over the channel axis of token rows (eps 1e-5, affine), optional gather.
+ * Replaces nn.LayerNorm at attention.py:316 (norm1 on windowed tokens), :333 (norm2) and
+ * network_base.py:84 (fusion norm).  With `src_row_map` (length `rows`), output row r reads
+ * source row src_row_map[r]; a negative entry denotes a zero-padded token, whose
+ * LayerNorm is exactly `beta` (attention.py:58-61 pads with zeros BEFORE norm1).
+ * The map fuses pad_if_needed + torch.roll + window_partition (attention.py:273-313).
+ * ---------------------------------------------------------------------------------- */
+int atmvfi_layernorm(const float* in, int in_ld, int64_t in_gstride, int in_rpg,
+                     const int32_t* src_row_map, float* out, int out_ld,
+                     const float* gamma, const float* beta, int64_t rows, int C, void* stream);
+
+/* Depth-wise 3x3 conv (pad 1, bias) + exact GELU on NHWC tokens: DWConv + act of
+ * attention.py:74-85,118-119.  weight9 is [9][C] (tap-major), see atmvfi_pack_dw_weight. */
+int atmvfi_dwconv3x3_gelu(const float* in, int in_ld, float* out, int out_ld,
+                          const float* weight9, const float* bias,
+                          int N, int H, int W, int C, void* stream);
+int atmvfi_pack_dw_weight(const float* src /*[C,1,3,3]*/, float* dst /*[9][C]*/, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Fused window attention (attention.py:187-213 AttentionToMotion.forward, :370-390
+ * WindowAttention.forward).  qkv: [Bw*N, 3C] rows in window order, columns [q | k | v],
+ * head h at columns h*hd.  One workgroup per (window, head): K/V tiles staged in LDS,
+ * S^T = K Q^T and O^T = V^T P^T on fp32 MFMA, softmax by wavefront reductions; the
+ * N x N attention matrix never reaches HBM.
+ *   labels : optional [nW, N] int32 per-token region label; additive mask is
+ *            -100 * (label_q != label_k)  (attention.py:54-57, 296-303); window index of
+ *            block b is b % nW.
+ *   kv_shift: K/V are read from window (b + kv_shift) % Bw -- Bw/2 for the cross-frame
+ *            attention of ATMFormer (attention.py:318), 0 for self attention.
+ *   motion : optional [Bw, N, heads, 2]: per-head expected key offset
+ *            sum_k A[q,k] * (k_xy - q_xy)   (attention.py:207-208)
+ * ---------------------------------------------------------------------------------- */
+int atmvfi_window_attention(const float* qkv, float* out /*[Bw*N, C]*/, float* motion,
+                            const int32_t* labels, int Bw, int nW, int ws, int heads, int hd,
+                            int kv_shift, void* stream);
+/* Named entry points of SURVEY.md section 8b (shims over atmvfi_window_attention). */
+int atmvfi_window_attn_cross_motion(const float* qkv, float* out, float* motion, const int32_t* labels,
+                                    int Bw, int nW, int ws, int heads, int hd, void* stream);
+int atmvfi_window_attn_self(const float* qkv, float* out, const int32_t* labels,
+                            int Bw, int nW, int ws, int heads, int hd, void* stream);
+
+/* Head read-out of the motion (attention.py:143-146, 209-211): Linear(heads->heads/2), GELU,
+ * Linear(heads/2->1) over the head axis, separately for dx and dy, then scatter from window
+ * order to image order (window_reverse + roll back + de-pad, attention.py:324-331) and into
+ * the channel-stacked motion map of the motion MLP input (network_base.py:377-382):
+ * destination = out + (r / out_rpg) * out_gstride + (r % out_rpg) * out_ld + {0,1}, r = row_map[m]. */
+int atmvfi_motion_head(const float* motion /*[rows, heads, 2]*/, const int32_t* row_map,
+                       const float* w0 /*[heads/2, heads]*/, const float* b0, const float* w1 /*[1, heads/2]*/,
+                       const float* b1, float* out, int out_ld, int64_t out_gstride, int out_rpg,
+                       int64_t rows, int heads, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Backward bilinear warp, zero padding (flow_warp.py:50-60 -> grid_sample(bilinear, zeros,
+ * align_corners=True)); coordinates are generated in-kernel (the reference builds the
+ * grid on the CPU on every call, flow_warp.py:57).
+ * Flow is addressed as fx = flow[b*flow_bstride + pix*flow_pstride], fy = fx[flow_cstride],
+ * which covers planar [B,2,H,W] (pstride 1, cstride H*W) and the last-5-channel NHWC
+ * motion maps (pstride ld, cstride 1).
+ * ---------------------------------------------------------------------------------- */
+int atmvfi_flow_warp(const float* src /*[B,C,H,W]*/, const float* flow, int64_t flow_bstride,
+                     int flow_pstride, int flow_cstride, float* dst, int B, int C, int H, int W, void* stream);
+int atmvfi_flow_warp_nhwc(const float* src, int src_ld, int64_t src_bstride,
+                          const float* flow, int64_t flow_bstride, int flow_pstride, int flow_cstride,
+                          float* dst, int dst_ld, int64_t dst_bstride, int B, int C, int H, int W, void* stream);
+
+/* Fused per-level synthesis (network_base.py:464-466, 496-498, 523-525): warp both frames with
+ * their flows, mask = sigmoid(logit), I_t = mask*I0w + (1-mask)*I1w.  `motion` is a 5-channel
+ * map [flow0.xy, flow1.xy, mask logit] with pixel stride `motion_ld` (NHWC slice).  Optional
+ * outputs (NULL to skip): planar flows/masks for the returned dict, and a 15-channel NHWC
+ * pack [im0, I0w, im1, I1w, I_t] into the refiner input (network_base.py:418; im0/im1 there
+ * are the ORIGINAL frames `orig0/orig1`). */
+int atmvfi_warp_blend(const float* im0, const float* im1 /*[B,3,H,W] (pre-warped pyramids)*/,
+                      const float* motion, int motion_ld, int64_t motion_bstride,
+                      float* i0w, float* i1w, float* it /*[B,3,H,W]*/,
+                      float* flow0_out, float* flow1_out /*[B,2,H,W]*/, float* mask1_out, float* mask2_out /*[B,1,H,W]*/,
+                      const float* orig0, const float* orig1, float* pack15, int pack_ld,
+                      int B, int H, int W, void* stream);
+#define atmvfi_blend atmvfi_warp_blend   /* SURVEY.md section 8b name */
+
+/* Bilinear resize with align_corners=True, src = dst*(in-1)/(out-1), values * value_scale:
+ * F.interpolate(scale 0.5) of the image pyramid (network_base.py:445-446,461-462) and
+ * upsample_flow (network_base.py:11-18, value_scale = factor).  Source element (b,c,y,x) is
+ * src[b*sb + c*sc + y*sy + x*sx] (planar NCHW or a channel slice of an NHWC motion map);
+ * dst is planar contiguous [B,C,Ho,Wo]. */
+int atmvfi_resize_bilinear_ac(const float* src, int64_t src_bstride, int64_t src_cstride, int64_t src_ystride,
+                              int64_t src_xstride, float* dst, int B, int C, int Hi, int Wi, int Ho, int Wo,
+                              float value_scale, void* stream);
+
+/* torch.cat([im0, im1], 0) (network_base.py:451) fused with NCHW -> NHWC4 (4th channel 0). */
+int atmvfi_pack_frames(const float* im0, const float* im1, float* dst /*[2B,H,W,4]*/, int B, int H, int W, void* stream);
+
+/* I_t += 2*sigmoid(r) - 1; clamp(0,1) (network_base.py:429,532-533).  `r` is the NHWC 3-channel
+ * output of refine_head; writes the unclamped sum (the tensor the reference leaves in
+ * im_t_list[0]) and the clamped frame. */
+int atmvfi_final_residual(const float* it /*[B,3,H,W]*/, const float* r, int r_ld,
+                          float* it_sum, float* it_clamped, int B, int H, int W, void* stream);
+
+/* mean |a - b| per sample: global_alignmentness (network_base.py:560-561).  out[B] must be zeroed by the caller. */
+int atmvfi_l1_mean(const float* a, const float* b, float* out, int B, int64_t per_sample, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ATMVFI_H */

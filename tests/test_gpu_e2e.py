@@ -1,0 +1,164 @@
+"""GPU: the whole hot path (``Network.forward`` -> libatmvfi_hip.so) against
+ (1) the reference's own outputs committed under tests/golden,
+ (2) the CPU oracle on the same seeded inputs, up to BASELINE.json's full sizes,
+ (3) size-independent properties at full size (run-to-run determinism, per-pair independence).
+Tolerance is the north star's: max|d| <= 1e-3 per pixel on fp32 ``I_t``."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as G
+import pairs
+from oracle import atmvfi_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3            # BASELINE.json north_star: |d| <= 1e-3 per pixel (fp32)
+TOL_FLOW = 2e-3       # flows are O(1..10) px; same relative budget
+
+pkg = importlib.import_module("atm-vfi_amd")
+host_io = importlib.import_module("atm-vfi_amd.host_io")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def nets(dev):
+    torch.set_grad_enabled(False)
+    out = {}
+    for v, cls in (("lite", pkg.NetworkLite), ("base", pkg.NetworkBase)):
+        net = cls()
+        net.load_state_dict(pkg.synthetic_state_dict(v, seed=1), strict=True)
+        out[v] = net.to(dev).eval()
+    return out
+
+
+def run(net, case_global, ens, im0, im1, dev):
+    net.global_motion = case_global
+    net.ensemble_global_motion = ens
+    out = net(im0.to(dev), im1.to(dev))
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("case", G.e2e_cases(), ids=lambda c: c["name"])
+def test_forward_vs_reference_golden(case, nets, dev):
+    gold = G.load_npz(case["name"])
+    im0, im1 = G.case_inputs(case)
+    G.check_inputs_match(case, gold, im0, im1)
+    out = run(nets[case["variant"]], case["global"], case["ensemble"], im0, im1, dev)
+    assert len(out["im_t_list"]) == case["n_lists"]
+    assert set(out.keys()) == {"I_t", "im_t_list", "im0_warped_list", "im1_warped_list", "opt_flow_0", "opt_flow_1",
+                               "I_t_0", "I_t_1", "occ_mask1", "occ_mask2"}
+    errs = G.compare_e2e(out, gold, case["step"], TOL, TOL_FLOW)
+    print(case["name"], {k: f"{v:.1e}" for k, v in errs.items()})
+
+
+@pytest.mark.parametrize("case", G.demo_cases(), ids=lambda c: c["name"])
+def test_inference_2frame_uint8(case, nets, dev):
+    gold = G.load_npz(case["name"])
+    f0, f1 = pairs.uint8_pair(case["H"], case["W"], seed=case["seed"])
+    net = nets[case["variant"]]
+    net.global_motion = case["global"]
+    net.ensemble_global_motion = False
+    pred = host_io.inference_2frame(f0, f1, net, isBGR=True)
+    d = np.abs(pred.astype(np.int32) - gold["pred"].astype(np.int32))
+    assert pred.shape == gold["pred"].shape and pred.dtype == np.uint8
+    assert d.max() <= 1 and (d > 0).mean() < 5e-3      # |d| <= 1e-3 in fp32 can flip a rounding, never more than one level
+
+
+def test_asset_crop_natural_image(nets, dev):
+    gold = G.load_npz("demo_lite_asset_crop")
+    net = nets["lite"]
+    net.global_motion = True
+    net.ensemble_global_motion = False
+    pred = host_io.inference_2frame(gold["f0"], gold["f1"], net, isBGR=True)
+    d = np.abs(pred.astype(np.int32) - gold["pred"].astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 5e-3
+
+
+FULL = [
+    # BASELINE.json configs at their full sizes, checked against the CPU oracle
+    ("C1 lite 256x256 global on", "lite", 1, 256, 256, True),
+    ("C2 lite 256x448 global off", "lite", 1, 256, 448, False),
+    ("C3 base 540x960->576x960 global on", "base", 1, 576, 960, True),
+    ("C4 base 1080x1920->1088x1920 global on", "base", 1, 1088, 1920, True),
+]
+
+
+@pytest.mark.parametrize("cfg", FULL, ids=lambda c: c[0].split()[0] + "_" + c[1])
+def test_full_size_vs_oracle(cfg, nets, dev, weights):
+    name, v, b, h, w, g = cfg
+    im0, im1 = pairs.smooth_pair(b, h, w, seed=41)
+    out = run(nets[v], g, False, im0, im1, dev)
+    ref = O.forward(weights(v), im0, im1, global_motion=g)
+    errs = {}
+    for k in ("I_t", "I_t_0", "I_t_1", "occ_mask1"):
+        errs[k] = (out[k].cpu() - ref[k]).abs().max().item()
+        assert errs[k] <= TOL, f"{name}: {k} max|d| {errs[k]:.3e}"
+    for k in ("opt_flow_0", "opt_flow_1"):
+        errs[k] = (out[k].cpu() - ref[k]).abs().max().item()
+        assert errs[k] <= TOL_FLOW, f"{name}: {k} max|d| {errs[k]:.3e}"
+    for a, r in zip(out["im_t_list"], ref["im_t_list"]):
+        assert (a.cpu() - r).abs().max().item() <= TOL
+    mse = ((out["I_t"].cpu() - ref["I_t"]) ** 2).mean().item()
+    psnr = float("inf") if mse == 0 else -10 * np.log10(mse)
+    print(f"{name}: " + " ".join(f"{k}={e:.1e}" for k, e in errs.items()) + f" PSNR-vs-oracle={psnr:.1f} dB")
+    assert psnr > 80.0
+
+
+def test_full_size_properties_1080p(nets, dev):
+    """Size-independent properties at the benchmark size: bitwise run-to-run determinism, and
+    per-pair independence (a batch of two pairs == the two pairs run separately)."""
+    net = nets["base"]
+    a0, a1 = pairs.smooth_pair(1, 1088, 1920, seed=51)
+    b0, b1 = pairs.random_pair(1, 1088, 1920, seed=52)
+    oa = run(net, True, False, a0, a1, dev)["I_t"].clone()
+    oa2 = run(net, True, False, a0, a1, dev)["I_t"].clone()
+    assert torch.equal(oa, oa2)
+    ob = run(net, True, False, b0, b1, dev)["I_t"].clone()
+    both = run(net, True, False, torch.cat([a0, b0]), torch.cat([a1, b1]), dev)["I_t"]
+    assert (both[0] - oa[0]).abs().max().item() <= 1e-5
+    assert (both[1] - ob[0]).abs().max().item() <= 1e-5
+    assert both.min().item() >= 0.0 and both.max().item() <= 1.0
+    net.release_workspace()
+
+
+def test_window_size_knob_and_state_dict_roundtrip(nets, dev, weights):
+    """__set_{local,global}_window_size__ (network_base.py:262-270) and checkpoint reload."""
+    net = pkg.NetworkLite()
+    sd = weights("lite")
+    net.load_state_dict(sd, strict=True)
+    net.to(dev).eval()
+    net.__set_global_window_size__(8)
+    net.__set_local_window_size__(4)
+    im0, im1 = pairs.smooth_pair(1, 128, 192, seed=61)
+    out = net(im0.to(dev), im1.to(dev))
+    ref = O.forward(sd, im0, im1, global_motion=True, local_window=4, global_window=8)
+    assert (out["I_t"].cpu() - ref["I_t"]).abs().max().item() <= TOL
+    assert net.state_dict()["global_motion_atmformer.0.attn.relative_coord"].shape[-1] == 64
+    # a saved-and-stripped checkpoint (lazy attn_mask/HW keys) loads back bit-identically
+    polluted = dict(net.state_dict())
+    polluted["local_motion_atmformer.1.attn_mask"] = torch.zeros(3)
+    polluted["local_motion_atmformer.1.HW"] = torch.zeros(1)
+    net2 = pkg.NetworkLite()
+    net2.__set_global_window_size__(8)
+    net2.__set_local_window_size__(4)
+    net2.load_state_dict(host_io.strip_lazy_buffers(polluted), strict=True)
+    net2.to(dev).eval()
+    out2 = net2(im0.to(dev), im1.to(dev))
+    assert torch.equal(out2["I_t"], out["I_t"])
+
+
+def test_rejects_cpu_inputs_and_bad_shapes(nets, dev):
+    net = nets["lite"]
+    with pytest.raises((RuntimeError, TypeError)):
+        net(torch.rand(1, 3, 64, 64), torch.rand(1, 3, 64, 64))
+    net.global_motion = True
+    with pytest.raises(ValueError):
+        net(torch.rand(1, 3, 72, 64, device=dev), torch.rand(1, 3, 72, 64, device=dev))

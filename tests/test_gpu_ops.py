@@ -1,0 +1,362 @@
+"""GPU: every HIP kernel through the C ABI against a plain PyTorch fp32 restatement of the
+same op contract (tests/cpu_ops.py) on seeded inputs, including ragged channel counts,
+channel-slice views, row groups, scatter maps, padded/shifted windows and out-of-range flows.
+Tolerances are absolute on O(1) data: 2e-5 for bandwidth ops, 1e-4 for contractions
+(fp32 MFMA = k-ordered fmaf chain vs oneDNN's blocked summation)."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as G
+from cpu_ops import CpuOps
+
+pytestmark = pytest.mark.gpu
+
+hip_ops = importlib.import_module("atm-vfi_amd.hip_ops")
+windows = importlib.import_module("atm-vfi_amd.windows")
+GEMM_CONV, GEMM_LINEAR, GEMM_DECONV = 0, 1, 2
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def hip(dev):
+    return hip_ops.HipOps(dev)
+
+
+@pytest.fixture(scope="module")
+def cpu():
+    return CpuOps()
+
+
+def rnd(gen, *shape, scale=1.0):
+    return (torch.rand(*shape, generator=gen) * 2 - 1) * scale
+
+
+def maxdiff(a, b):
+    return (a.detach().float().cpu() - b.detach().float().cpu()).abs().max().item()
+
+
+# ------------------------------------------------------------------ contractions
+CONV_CASES = [
+    # cin, cout, k, stride, pad, dil, H, W, in_off, in_ld, out_off, out_ld, N
+    (3, 24, 3, 1, 1, 1, 20, 28, 0, 4, 0, 24, 2),          # first layer: NHWC4 input, Cin=3
+    (24, 48, 3, 2, 1, 1, 20, 28, 0, 24, 0, 48, 2),
+    (48, 48, 3, 4, 1, 1, 24, 40, 0, 48, 96, 384, 2),       # fusion conv, stride 4, writes a slice
+    (48, 48, 3, 4, 2, 2, 24, 40, 0, 48, 144, 384, 2),      # stride 4, dilation 2
+    (13, 21, 3, 1, 1, 1, 9, 11, 4, 24, 8, 40, 1),          # ragged Cin/Cout, offsets
+    (101, 101, 3, 1, 1, 1, 16, 24, 0, 104, 0, 116, 1),     # decoder tail shape (7 n-tiles)
+    (197, 197, 3, 1, 1, 1, 8, 12, 0, 200, 128, 328, 1),    # 13 n-tiles -> two n-blocks
+    (389, 389, 3, 1, 1, 1, 6, 6, 0, 392, 256, 648, 1),     # 25 n-tiles -> five n-blocks
+    (64, 5, 1, 1, 0, 1, 10, 14, 0, 64, 768, 776, 2),       # 1x1 motion head into the decoder input
+    (116, 64, 3, 1, 1, 1, 12, 20, 0, 116, 64, 128, 1),
+    (256, 128, 3, 2, 1, 1, 12, 20, 64, 328, 0, 128, 1),    # down2: reads [feat1 | dec1[:192]] slice
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: f"cin{c[0]}_cout{c[1]}_k{c[2]}_s{c[3]}_d{c[5]}")
+def test_conv2d(case, hip, cpu, dev):
+    cin, cout, k, stride, pad, dil, H, W, ioff, ild, ooff, old, N = case
+    g = torch.Generator().manual_seed(cin * 131 + cout)
+    buf = rnd(g, N, H, W, ild)
+    w = rnd(g, cout, cin, k, k, scale=1.0 / np.sqrt(cin * k * k))
+    bias = rnd(g, cout, scale=0.2)
+    slope = torch.rand(cout, generator=g) * 0.4
+    Ho = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    Wo = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    for use_prelu in (True, False):
+        obuf_c = torch.full((N, Ho, Wo, old), 7.0)
+        cpu.conv(buf[..., ioff:ioff + cin], cpu.pack_weight(GEMM_CONV, w), obuf_c[..., ooff:ooff + cout], stride, pad, dil,
+                 bias, slope if use_prelu else None)
+        dbuf = buf.to(dev)
+        obuf_g = torch.full((N, Ho, Wo, old), 7.0, device=dev)
+        pw = hip.pack_weight(GEMM_CONV, w.to(dev))
+        hip.conv(dbuf[..., ioff:ioff + cin], pw, obuf_g[..., ooff:ooff + cout], stride, pad, dil, bias.to(dev),
+                 slope.to(dev) if use_prelu else None)
+        torch.cuda.synchronize()
+        # the whole buffer is compared: channels outside the view must stay untouched (7.0)
+        assert maxdiff(obuf_g, obuf_c) <= 1e-4
+
+
+DECONV_CASES = [(773, 389, 5, 7, 776, 392, 1), (13, 21, 6, 5, 16, 24, 2), (256, 128, 6, 10, 256, 128, 1), (128, 64, 4, 4, 328, 128, 2)]
+
+
+@pytest.mark.parametrize("case", DECONV_CASES, ids=lambda c: f"cin{c[0]}_cout{c[1]}")
+def test_deconv2x2(case, hip, cpu, dev):
+    cin, cout, H, W, ild, old, N = case
+    g = torch.Generator().manual_seed(cin + 7 * cout)
+    buf = rnd(g, N, H, W, ild)
+    w = rnd(g, cin, cout, 2, 2, scale=1.0 / np.sqrt(cin))
+    bias = rnd(g, cout, scale=0.2)
+    slope = torch.rand(cout, generator=g) * 0.4
+    inslope = torch.rand(cin, generator=g) * 0.4
+    for use_in in (False, True):
+        oc = torch.full((N, 2 * H, 2 * W, old), 7.0)
+        cpu.deconv(buf[..., :cin], cpu.pack_weight(GEMM_DECONV, w), oc[..., :cout], bias, slope,
+                   cpu.pad_channels(inslope) if use_in else None)
+        og = torch.full((N, 2 * H, 2 * W, old), 7.0, device=dev)
+        hip.deconv(buf.to(dev)[..., :cin], hip.pack_weight(GEMM_DECONV, w.to(dev)), og[..., :cout], bias.to(dev), slope.to(dev),
+                   hip.pad_channels(inslope.to(dev)) if use_in else None)
+        torch.cuda.synchronize()
+        assert maxdiff(og, oc) <= 1e-4
+
+
+def test_linear_groups_scatter_residual(hip, cpu, dev):
+    g = torch.Generator().manual_seed(3)
+    frames, h, w, ws, shift, C = 4, 6, 10, 4, 2, 48
+    geo = windows.build_window_geometry(frames, h, w, ws, shift)
+    mw = geo.row_map.numel()
+    x = rnd(g, mw, C)
+    res = rnd(g, mw, C)
+    wt = rnd(g, 72, C, scale=0.2)
+    bias = rnd(g, 72, scale=0.2)
+    # (a) scatter through the window map into a frame-stacked (grouped) destination slice
+    B = frames // 2
+    dst_c = torch.full((B, h, w, 8 + 2 * 72), 7.0)
+    dst_g = dst_c.to(dev)
+
+    def stacked(buf):
+        b, hh, ww, ld = buf.shape
+        return buf.reshape(b * hh * ww, ld)[:, 8:8 + 144].unflatten(1, (2, 72)).permute(1, 0, 2)
+    cpu.linear(x, cpu.pack_weight(GEMM_LINEAR, wt), stacked(dst_c), bias, None, geo.row_map)
+    hip.linear(x.to(dev), hip.pack_weight(GEMM_LINEAR, wt.to(dev)), stacked(dst_g), bias.to(dev), None, geo.row_map.to(dev))
+    torch.cuda.synchronize()
+    assert not torch.isnan(dst_c).any()
+    assert maxdiff(dst_g, dst_c) <= 1e-4
+    # (b) grouped input + residual, plain output
+    wt2 = rnd(g, C, 72, scale=0.2)
+    res2 = rnd(g, 2 * B * h * w, C)
+    out_c = torch.empty(2 * B * h * w, C)
+    out_g = torch.empty(2 * B * h * w, C, device=dev)
+    cpu.linear(stacked(dst_c), cpu.pack_weight(GEMM_LINEAR, wt2), out_c, None, res2)
+    hip.linear(stacked(dst_g), hip.pack_weight(GEMM_LINEAR, wt2.to(dev)), out_g, None, res2.to(dev))
+    torch.cuda.synchronize()
+    assert maxdiff(out_g, out_c) <= 1e-4
+
+
+def test_gemm_rejects_bad_views(hip, dev):
+    w = hip.pack_weight(GEMM_CONV, torch.rand(8, 6, 3, 3, device=dev))
+    x = torch.rand(1, 8, 8, 7, device=dev)          # ld = 7: not a multiple of 4
+    with pytest.raises(RuntimeError):
+        hip.conv(x[..., :6], w, torch.empty(1, 8, 8, 8, device=dev), 1, 1, 1)
+    with pytest.raises(TypeError):
+        hip.conv(torch.rand(1, 8, 8, 8)[..., :6], w, torch.empty(1, 8, 8, 8, device=dev), 1, 1, 1)
+
+
+# ------------------------------------------------------------------ transformer pieces
+def test_layernorm_gather_groups(hip, cpu, dev):
+    g = torch.Generator().manual_seed(5)
+    frames, h, w, ws, shift, C = 2, 5, 6, 4, 2, 224
+    geo = windows.build_window_geometry(frames, h, w, ws, shift)
+    assert (geo.row_map < 0).any()
+    src = rnd(g, 1, h, w, 8 + 2 * C, scale=3.0)
+    gamma, beta = 1 + rnd(g, C, scale=0.2), rnd(g, C, scale=0.2)
+
+    def stacked(buf):
+        return buf.reshape(h * w, 8 + 2 * C)[:, 8:].unflatten(1, (2, C)).permute(1, 0, 2)
+    out_c = torch.empty(geo.row_map.numel(), C)
+    out_g = torch.empty(geo.row_map.numel(), C, device=dev)
+    cpu.layernorm(stacked(src), out_c, gamma, beta, geo.row_map)
+    hip.layernorm(stacked(src.to(dev)), out_g, gamma.to(dev), beta.to(dev), geo.row_map.to(dev))
+    torch.cuda.synchronize()
+    assert maxdiff(out_g, out_c) <= 2e-5
+    plain = rnd(g, 37, 672, scale=2.0)
+    g2, b2 = 1 + rnd(g, 672, scale=0.2), rnd(g, 672, scale=0.2)
+    oc, og = torch.empty(37, 672), torch.empty(37, 672, device=dev)
+    cpu.layernorm(plain, oc, g2, b2)
+    hip.layernorm(plain.to(dev), og, g2.to(dev), b2.to(dev))
+    assert maxdiff(og, oc) <= 2e-5
+
+
+def test_dwconv_gelu(hip, cpu, dev):
+    g = torch.Generator().manual_seed(6)
+    x = rnd(g, 2, 7, 9, 448, scale=2.0)
+    w = rnd(g, 448, 1, 3, 3, scale=0.5)
+    b = rnd(g, 448, scale=0.3)
+    oc, og = torch.empty(2, 7, 9, 448), torch.empty(2, 7, 9, 448, device=dev)
+    cpu.dwconv_gelu(x, oc, w, b)
+    hip.dwconv_gelu(x.to(dev), og, hip.pack_dw_weight(w.to(dev)), b.to(dev))
+    assert maxdiff(og, oc) <= 2e-5
+
+
+ATTN_CASES = [
+    # ws, hd, frames, h, w, shift, cross
+    (8, 48, 2, 16, 24, 0, True), (8, 48, 2, 16, 24, 4, True), (8, 28, 2, 12, 20, 4, True),     # 12x20 -> pad 16x24 + shift
+    (12, 84, 2, 12, 20, 6, True), (12, 44, 4, 4, 4, 0, True), (12, 44, 4, 4, 4, 6, True),      # 4x4 -> 12x12
+    (8, 48, 4, 16, 16, 4, False), (7, 16, 2, 32, 32, 3, True), (16, 24, 2, 16, 32, 8, False),
+    (4, 8, 2, 8, 8, 2, True),
+]
+
+
+@pytest.mark.parametrize("case", ATTN_CASES, ids=lambda c: f"ws{c[0]}_hd{c[1]}_{c[3]}x{c[4]}_s{c[5]}_{'x' if c[6] else 'self'}")
+def test_window_attention(case, hip, cpu, dev):
+    ws, hd, frames, h, w, shift, cross = case
+    heads = 8
+    C = heads * hd
+    g = torch.Generator().manual_seed(ws * 100 + hd + shift)
+    geo = windows.build_window_geometry(frames, h, w, ws, shift)
+    bw = frames * geo.n_windows
+    n = ws * ws
+    qkv = rnd(g, bw * n, 3 * C, scale=1.5)
+    oc, og = torch.empty(bw * n, C), torch.full((bw * n, C), 9.0, device=dev)
+    mc = torch.empty(bw * n, heads, 2) if cross else None
+    mg = torch.full((bw * n, heads, 2), 9.0, device=dev) if cross else None
+    kv_shift = bw // 2 if cross else 0
+    cpu.window_attention(qkv, oc, mc, geo.labels, bw, geo.n_windows, ws, heads, hd, kv_shift)
+    hip.window_attention(qkv.to(dev), og, mg, None if geo.labels is None else geo.labels.to(dev), bw, geo.n_windows, ws,
+                         heads, hd, kv_shift)
+    torch.cuda.synchronize()
+    assert maxdiff(og, oc) <= 1e-4
+    if cross:
+        assert maxdiff(mg, mc) <= 1e-4
+
+
+def test_motion_head(hip, cpu, dev):
+    g = torch.Generator().manual_seed(8)
+    frames, h, w, ws, shift = 4, 6, 10, 4, 2
+    geo = windows.build_window_geometry(frames, h, w, ws, shift)
+    rows = geo.row_map.numel()
+    mo = rnd(g, rows, 8, 2, scale=3.0)
+    w0, b0, w1, b1 = rnd(g, 4, 8), rnd(g, 4), rnd(g, 1, 4), rnd(g, 1)
+    B = frames // 2
+    dc = torch.full((B * h * w, 24), 7.0)
+    dg = dc.to(dev)
+
+    def view(buf):
+        return buf[:, 4:8].unflatten(1, (2, 2)).permute(1, 0, 2)
+    cpu.motion_head(mo, geo.row_map, w0, b0, w1, b1, view(dc))
+    hip.motion_head(mo.to(dev), geo.row_map.to(dev), w0.to(dev), b0.to(dev), w1.to(dev), b1.to(dev), view(dg))
+    torch.cuda.synchronize()
+    assert maxdiff(dg, dc) <= 2e-5
+
+
+# ------------------------------------------------------------------ warps / resampling
+def test_flow_warp_golden_and_random(hip, cpu, dev):
+    gold = G.load_npz("op_flow_warp")
+    feat, flow = torch.from_numpy(gold["feat"]), torch.from_numpy(gold["flow"])
+    out = torch.empty_like(feat, device=dev)
+    hip.flow_warp(feat.to(dev), flow.to(dev), out)
+    assert np.abs(out.cpu().numpy() - gold["out"]).max() <= 2e-6          # the reference's own output
+    g = torch.Generator().manual_seed(9)
+    src = rnd(g, 2, 3, 33, 47)
+    fl = rnd(g, 2, 2, 33, 47, scale=6.0)
+    fl[0, :, :3] = 500.0            # far outside: must be exactly zero
+    fl[1, 0, 5:8] = -1e9
+    fl[1, 1, 9, 9] = float("inf")
+    oc, og = torch.empty_like(src), torch.empty_like(src, device=dev)
+    cpu.flow_warp(src, torch.nan_to_num(fl, posinf=1e9), oc)
+    hip.flow_warp(src.to(dev), fl.to(dev), og)
+    assert not torch.isnan(og).any()
+    assert maxdiff(og, oc) <= 2e-5
+    assert og[0, :, :3].abs().max().item() == 0.0
+
+
+def test_flow_warp_nhwc_views(hip, cpu, dev):
+    g = torch.Generator().manual_seed(10)
+    B, H, W, C = 2, 12, 20, 224
+    src = rnd(g, 2 * B, H, W, C)
+    motion = rnd(g, B, H, W, 2 * C + 8, scale=4.0)     # flows live in channels 2C..2C+4 of the destination buffer
+    dst_c = motion.clone()
+    dst_g = motion.to(dev)
+    for which, lo in ((0, 0), (1, C)):
+        f_c = dst_c[..., 2 * C + 2 * which:2 * C + 2 * which + 2].permute(0, 3, 1, 2)
+        f_g = dst_g[..., 2 * C + 2 * which:2 * C + 2 * which + 2].permute(0, 3, 1, 2)
+        cpu.flow_warp_nhwc(src[which * B:(which + 1) * B], f_c, dst_c[..., lo:lo + C])
+        hip.flow_warp_nhwc(src.to(dev)[which * B:(which + 1) * B], f_g, dst_g[..., lo:lo + C])
+    torch.cuda.synchronize()
+    assert maxdiff(dst_g, dst_c) <= 2e-5
+
+
+def test_warp_blend_all_outputs(hip, cpu, dev):
+    g = torch.Generator().manual_seed(11)
+    B, H, W = 2, 24, 40
+    im0, im1, o0, o1 = (torch.rand(B, 3, H, W, generator=g) for _ in range(4))
+    buf = rnd(g, B, H, W, 116, scale=3.0)
+    outs_c = [torch.empty(B, 3, H, W) for _ in range(3)] + [torch.empty(B, 2, H, W) for _ in range(2)] + [torch.empty(B, 1, H, W) for _ in range(2)]
+    outs_g = [torch.empty_like(t, device=dev) for t in outs_c]
+    bc, bg = buf.clone(), buf.to(dev)
+    cpu.warp_blend(im0, im1, bc[..., 96:101], *outs_c, o0, o1, bc[..., 101:116])
+    hip.warp_blend(im0.to(dev), im1.to(dev), bg[..., 96:101], *outs_g, o0.to(dev), o1.to(dev), bg[..., 101:116])
+    torch.cuda.synchronize()
+    for a, b in zip(outs_g, outs_c):
+        assert maxdiff(a, b) <= 2e-5
+    assert maxdiff(bg, bc) <= 2e-5
+    # minimal form (coarse levels)
+    outs_c = [torch.empty(B, 3, H, W) for _ in range(3)]
+    outs_g = [torch.empty_like(t, device=dev) for t in outs_c]
+    cpu.warp_blend(im0, im1, bc[..., 96:101], *outs_c)
+    hip.warp_blend(im0.to(dev), im1.to(dev), bg[..., 96:101], *outs_g)
+    for a, b in zip(outs_g, outs_c):
+        assert maxdiff(a, b) <= 2e-5
+
+
+def test_resize_align_corners(hip, cpu, dev):
+    g = torch.Generator().manual_seed(12)
+    x = rnd(g, 2, 3, 34, 50)
+    for (oh, ow, sc) in ((17, 25, 1.0), (68, 100, 2.0), (34, 50, 1.0)):
+        oc, og = torch.empty(2, 3, oh, ow), torch.empty(2, 3, oh, ow, device=dev)
+        cpu.resize(x, oc, sc)
+        hip.resize(x.to(dev), og, sc)
+        assert maxdiff(og, oc) <= 2e-5
+    nh = rnd(g, 2, 9, 11, 8, scale=4.0)           # flow pair inside an NHWC motion map
+    v_c = nh[..., 2:4].permute(0, 3, 1, 2)
+    v_g = nh.to(dev)[..., 2:4].permute(0, 3, 1, 2)
+    oc, og = torch.empty(2, 2, 18, 22), torch.empty(2, 2, 18, 22, device=dev)
+    cpu.resize(v_c, oc, 2.0)
+    hip.resize(v_g, og, 2.0)
+    assert maxdiff(og, oc) <= 2e-5
+
+
+def test_pack_final_l1(hip, cpu, dev):
+    g = torch.Generator().manual_seed(13)
+    B, H, W = 2, 10, 14
+    im0, im1 = torch.rand(B, 3, H, W, generator=g), torch.rand(B, 3, H, W, generator=g)
+    pc, pg = torch.empty(2 * B, H, W, 4), torch.empty(2 * B, H, W, 4, device=dev)
+    cpu.pack_frames(im0, im1, pc)
+    hip.pack_frames(im0.to(dev), im1.to(dev), pg)
+    assert maxdiff(pg, pc) == 0.0
+    r = rnd(g, B, H, W, 4, scale=3.0)
+    sc, cc = torch.empty(B, 3, H, W), torch.empty(B, 3, H, W)
+    sg, cg = torch.empty(B, 3, H, W, device=dev), torch.empty(B, 3, H, W, device=dev)
+    cpu.final_residual(im0, r[..., :3], sc, cc)
+    hip.final_residual(im0.to(dev), r.to(dev)[..., :3], sg, cg)
+    assert maxdiff(sg, sc) <= 2e-6 and maxdiff(cg, cc) <= 2e-6
+    lc, lg = torch.empty(B), torch.empty(B, device=dev)
+    cpu.l1_mean(im0, im1, lc)
+    hip.l1_mean(im0.to(dev), im1.to(dev), lg)
+    assert maxdiff(lg, lc) <= 1e-6
+
+
+# ------------------------------------------------------------------ a whole ATMFormer block (reference fixture)
+@pytest.mark.parametrize("shift", [0, 3])
+def test_atm_block_reference_fixture(shift, hip, dev):
+    """The reference's own smoke shape (attention.py:512-534): C=128, window 7 (N=49, padded to 64
+    inside the kernel), 32x32 -> canvas 35x35, shift 3; expected values from the reference itself."""
+    pkg = importlib.import_module("atm-vfi_amd")
+    gold = G.load_npz(f"op_atm_ws7_shift{shift}")
+    net = pkg.NetworkLite()
+    net.set_ops(hip)
+    P = {}
+    for k in gold.files:
+        if k.startswith("w."):
+            P["b." + k[2:]] = torch.from_numpy(gold[k]).to(dev)
+    qkv = torch.cat([P["b.attn.q.weight"], P["b.attn.kv.weight"]], 0)
+    P["pk:b.attn.qkv.weight"] = hip.pack_weight(GEMM_LINEAR, qkv)
+    for nm in ("attn.proj", "mlp.fc1", "mlp.fc2"):
+        P[f"pk:b.{nm}.weight"] = hip.pack_weight(GEMM_LINEAR, P[f"b.{nm}.weight"])
+    P["pk:b.mlp.dwconv.dwconv.weight"] = hip.pack_dw_weight(P["b.mlp.dwconv.dwconv.weight"])
+    x = torch.from_numpy(gold["x"]).to(dev)               # [4, 1024, 128]
+    out = torch.empty(4 * 1024, 128, device=dev)
+    mdst = torch.empty(2, 2 * 1024, 2, device=dev)      # [frame, B*hw, 2]
+    net._block(hip, P, "b", x.reshape(4 * 1024, 128), 4, 32, 32, 7, shift, True, out, mdst, "t")
+    torch.cuda.synchronize()
+    y = out.reshape(4, 1024, 128)[:, ::4].cpu().numpy()
+    assert np.abs(y - gold["y"]).max() <= 2e-4
+    mo = mdst.reshape(4, 1024, 2).cpu().numpy()
+    assert np.abs(mo - gold["motion"]).max() <= 2e-4

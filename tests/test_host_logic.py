@@ -1,0 +1,188 @@
+"""CPU: host logic of the product without a GPU.
+
+* ``Network.forward``'s orchestration (concat-free buffer slicing, window maps, quirk order)
+  driven through the CPU *test double* of the op vocabulary (tests/cpu_ops.py) must
+  reproduce the reference's golden outputs -- this isolates host bugs from kernel bugs;
+* window row maps / labels against the oracle's pad/roll/partition;
+* the C-ABI library exports every symbol ``include/atmvfi.h`` declares (no compute call);
+* the product refuses to run without the HIP path.
+"""
+import ctypes
+import importlib
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as G
+from cpu_ops import CpuOps
+from oracle import atmvfi_oracle as O
+
+pkg = importlib.import_module("atm-vfi_amd")
+hip_ops = importlib.import_module("atm-vfi_amd.hip_ops")
+windows = importlib.import_module("atm-vfi_amd.windows")
+host_io = importlib.import_module("atm-vfi_amd.host_io")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def nets():
+    torch.set_grad_enabled(False)
+    out = {}
+    for v, cls in (("lite", pkg.NetworkLite), ("base", pkg.NetworkBase)):
+        net = cls()
+        net.load_state_dict(pkg.synthetic_state_dict(v, seed=1), strict=True)
+        net.set_ops(CpuOps())
+        out[v] = net
+    return out
+
+
+SMALL = [c for c in G.e2e_cases() if c["H"] * c["W"] * c["B"] <= 192 * 320]
+
+
+@pytest.mark.parametrize("case", SMALL, ids=lambda c: c["name"])
+def test_host_orchestration_vs_golden(case, nets):
+    net = nets[case["variant"]]
+    net.global_motion = case["global"]
+    net.ensemble_global_motion = case["ensemble"]
+    im0, im1 = G.case_inputs(case)
+    out = net(im0, im1)
+    for k in ("I_t", "opt_flow_0", "occ_mask1", "occ_mask2"):
+        assert not torch.isnan(out[k]).any(), f"{k} has elements the host never produced"
+    G.compare_e2e(out, G.load_npz(case["name"]), case["step"], 1e-4)
+    assert len(out["im_t_list"]) == case["n_lists"] == len(out["im0_warped_list"]) == len(out["im1_warped_list"])
+    assert torch.equal(out["occ_mask2"], 1 - out["occ_mask1"])
+    # the reference leaves the refined, unclamped frame in im_t_list[0] (network_base.py:532)
+    assert torch.equal(out["I_t"], out["im_t_list"][0].clamp(0, 1))
+
+
+def test_ensemble_host_path(nets):
+    case = [c for c in G.e2e_cases() if c["ensemble"]][0]
+    net = nets[case["variant"]]
+    net.global_motion, net.ensemble_global_motion = True, True
+    im0, im1 = G.case_inputs(case)
+    out = net(im0, im1)
+    net.ensemble_global_motion = False
+    G.compare_e2e(out, G.load_npz(case["name"]), case["step"], 1e-4)
+
+
+@pytest.mark.parametrize("geo", [(2, 16, 24, 8, 0), (2, 16, 24, 8, 4), (2, 12, 20, 8, 4), (4, 4, 4, 12, 6),
+                                 (2, 32, 32, 7, 3), (2, 17, 30, 12, 6), (2, 5, 6, 4, 0)])
+def test_window_maps_match_pad_roll_partition(geo):
+    frames, h, w, ws, shift = geo
+    g = windows.build_window_geometry(frames, h, w, ws, shift)
+    x = torch.arange(frames * h * w, dtype=torch.float32).reshape(frames, h, w, 1) + 1.0
+    xw, og = O.to_windows(x, ws, shift)
+    want = (xw.reshape(-1) - 1).long()              # zero padding -> -1
+    assert torch.equal(g.row_map.long(), want)
+    assert (og[0], og[1]) == (g.hp, g.wp)
+    labels, *_ = O.window_labels(h, w, ws, shift)
+    if labels is None:
+        assert g.labels is None
+    else:
+        m_ref = labels[:, :, None] != labels[:, None, :]
+        m_mine = g.labels[:, :, None] != g.labels[:, None, :]
+        assert torch.equal(m_ref, m_mine)
+    # scatter direction: every image token is written exactly once
+    rm = g.row_map[g.row_map >= 0].long()
+    assert torch.equal(torch.sort(rm).values, torch.arange(frames * h * w))
+
+
+def test_state_dict_contract_and_api_surface(schema):
+    for v, cls in (("base", pkg.NetworkBase), ("lite", pkg.NetworkLite)):
+        net = cls()
+        got = [(k, tuple(t.shape)) for k, t in net.state_dict().items()]
+        assert got == schema.schema_signature(v)
+        assert not any("attn_mask" in k or k.endswith("HW") for k, _ in got)
+        assert net.pyramid_level == 4 and net.motion_out_dim == 5 and net.global_motion and not net.ensemble_global_motion
+        for m in ("__set_local_window_size__", "__set_global_window_size__", "__freeze_global_motion__",
+                  "__finetune_global_motion__", "__freeze_local_motion__", "__finetune_local_motion__"):
+            assert callable(getattr(net, m))
+        net.__freeze_global_motion__()
+        assert not net.global_motion_mlp._modules["2"].weight.requires_grad and net.proj._modules["0"].weight.requires_grad
+        net.__finetune_global_motion__()
+        net.__set_global_window_size__(16)
+        assert net.state_dict()["global_motion_atmformer.1.attn.relative_coord"].shape == (1, 1, 2, 256, 256)
+        assert net.global_motion_args["window_size"] == 16
+    torch.manual_seed(5)
+    a = pkg.NetworkLite().state_dict()
+    torch.manual_seed(5)
+    b = pkg.NetworkLite().state_dict()
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    rc = a["local_motion_atmformer.0.attn.relative_coord"]
+    assert rc[0, 0, 0, 9, 20].item() == (20 % 8) - (9 % 8) and rc[0, 0, 1, 9, 20].item() == (20 // 8) - (9 // 8)
+
+
+def test_product_fails_loudly_without_hip():
+    net = pkg.NetworkLite()
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        net(torch.rand(1, 3, 64, 64), torch.rand(1, 3, 64, 64))
+    with pytest.raises(hip_ops.HipLibraryMissing):
+        hip_ops.load_library("/nonexistent/libatmvfi_hip.so")
+    # the product package never imports the oracle
+    for fn in os.listdir(os.path.join(ROOT, "atm-vfi_amd")):
+        if fn.endswith(".py"):
+            src = open(os.path.join(ROOT, "atm-vfi_amd", fn)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), fn
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """include/atmvfi.h <-> libatmvfi_hip.so <-> ctypes signatures agree (no compute call)."""
+    header = open(os.path.join(ROOT, "include", "atmvfi.h")).read()
+    declared = set(re.findall(r"\b(atmvfi_[a-z0-9_]+)\s*\(", header)) - {"atmvfi_blend"}
+    assert declared == set(hip_ops.SIGNATURES), declared ^ set(hip_ops.SIGNATURES)
+    if not os.path.exists(hip_ops.LIB_PATH):
+        import __graft_entry__ as ge
+        ge.build()
+    lib = ctypes.CDLL(hip_ops.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} is declared in include/atmvfi.h but not exported"
+    lib.atmvfi_version.restype = ctypes.c_int
+    assert lib.atmvfi_version() >= 0x000100
+    lib.atmvfi_packed_weight_floats.restype = ctypes.c_int64
+    assert lib.atmvfi_packed_weight_floats(0, 101, 101, 3, 3) == 112 * 9 * 112
+    assert lib.atmvfi_packed_weight_floats(2, 389, 773, 2, 2) == 1568 * 784
+    # argument validation happens on the host before any launch: usable without a GPU
+    lib.atmvfi_last_error.restype = ctypes.c_char_p
+    assert lib.atmvfi_layernorm(None, 4, 0, 0, None, None, 4, None, None, 1, 4, None) == -1
+    assert b"null pointer" in lib.atmvfi_last_error()
+    p = hip_ops.GemmParams(mode=7)
+    assert lib.atmvfi_gemm(ctypes.byref(p), None) == -1
+
+
+def test_input_padder_and_checkpoint_io(tmp_path, manifest):
+    for key, pad in manifest["input_padder"].items():
+        hw, dv = key.split("/")
+        h, w = map(int, hw.split("x"))
+        p = host_io.InputPadder((1, 3, h, w), divisor=int(dv))
+        assert p._pad == pad
+        x = torch.rand(1, 3, min(h, 40), min(w, 40))
+        q = host_io.InputPadder(x.shape, divisor=16)
+        a, b = q.pad(x, x)
+        assert a.shape[-1] % 16 == 0 and a.shape[-2] % 16 == 0 and torch.equal(q.unpad(a), x)
+    net = pkg.NetworkLite()
+    sd = dict(net.state_dict())
+    sd["local_motion_atmformer.1.attn_mask"] = torch.zeros(2)
+    sd["local_motion_atmformer.1.HW"] = torch.zeros(1)
+    path = tmp_path / "ck.pt"
+    torch.save({"model_state_dict": sd, "optimizer_state_dict": {"o": 1}, "meta_data": {}, "train_metric": {}, "val_metric": {}}, path)
+    net2 = pkg.NetworkLite()
+    assert host_io.load_model_checkpoint(net2, str(path)) == {"o": 1}
+    assert all(torch.equal(net2.state_dict()[k], net.state_dict()[k]) for k in net.state_dict())
+    torch.save({k: v for k, v in net.state_dict().items()}, path)       # bare state dict (the reference crashes here)
+    host_io.load_model_checkpoint(pkg.NetworkLite(), str(path))
+
+
+def test_demo_host_path_on_double(nets):
+    """inference_2frame: BGR flip, /255, replicate pad to /64, forward, unpad, round -> uint8."""
+    import pairs
+    case = [c for c in G.demo_cases() if c["name"] == "demo_base_100x180_nog"][0]
+    net = nets["base"]
+    net.global_motion = False
+    f0, f1 = pairs.uint8_pair(case["H"], case["W"], seed=0)
+    pred = host_io.inference_2frame(f0, f1, net, isBGR=True)
+    gold = G.load_npz(case["name"])["pred"]
+    d = np.abs(pred.astype(np.int32) - gold.astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3
