@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Benchmark of the ATM-VFI forward hot path on MI355X (contract: see the task brief).
+
+Workload (BASELINE.json `metric`): network_base, 1080p frames replicate-padded to 1088x1920,
+batch 1 per GPU, global + local branches on, fp32.  One step = one ``Network.forward`` on one
+synthetic frame pair that is already resident in HBM, producing one interpolated frame.
+With N GPUs every rank interpolates its own pair per step (frame-batch sharding, weak scaling)
+and the N output frames are all-gathered over RCCL/xGMI -- the only collective on the path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+Rank 0 prints ONE JSON line.  Besides the contract's fields it carries
+  roofline     : the dominant kernel family (implicit-GEMM fp32-MFMA engine: conv2d + linear + deconv2x2),
+                 achieved = sum of algorithmic FLOPs / sum of launch durations, measured live with HIP
+                 events on the launch stream in a separate instrumented pass after the timed region;
+  cpu_baseline : the CPU oracle (oracle/atmvfi_oracle.py, a port of the reference's algorithm) timed on this
+                 node's host cores on a bounded sample (rank 0, N=1 only);
+  kernels      : per-kernel-family time split of one forward (ms), for DESIGN.md / profiles/.
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+FLOPS_PER_PAIR = {  # SURVEY.md section 8d, algorithmic FLOPs per frame pair (2 FLOP/MAC)
+    ("base", 1088, 1920, True): 5925.0e9,
+    ("base", 576, 960, True): 1566.3e9,
+    ("lite", 256, 448, False): 87.8e9,
+    ("lite", 256, 256, True): 56.2e9,
+}
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, dense fp32 matrix peak
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--variant", default="base", choices=["base", "lite"])
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--global-off", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch.distributed as dist
+
+    import pairs
+    pkg = importlib.import_module("atm-vfi_amd")
+    host_io = importlib.import_module("atm-vfi_amd.host_io")
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.set_grad_enabled(False)
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
+
+    # ---- model + synthetic inputs (resident in HBM before the timed region) ----
+    variant = args.variant
+    sd = pkg.synthetic_state_dict(variant, seed=1)
+    net = (pkg.NetworkBase if variant == "base" else pkg.NetworkLite)()
+    net.load_state_dict(sd, strict=True)
+    net.to(dev).eval()
+    net.global_motion = not args.global_off
+    padder = host_io.InputPadder((1, 3, args.height, args.width), divisor=64)
+    n_in = 4
+    frames = []
+    for i in range(n_in):
+        a, b = pairs.random_pair(1, args.height, args.width, seed=1000 + 17 * rank + i)
+        a, b = padder.pad(a.to(dev), b.to(dev))
+        frames.append((a.contiguous(), b.contiguous()))
+    H, W = frames[0][0].shape[-2:]
+
+    gathered = [torch.empty(1, 3, H, W, device=dev) for _ in range(world)] if world > 1 else None
+
+    def step(i):
+        a, b = frames[i % n_in]
+        out = net(a, b)["I_t"]
+        if world > 1:
+            dist.all_gather(gathered, out)      # per-rank output frames only
+        return out
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        fps = world * args.steps / elapsed
+        key = (variant, H, W, net.global_motion)
+        flops = FLOPS_PER_PAIR.get(key)
+        result = {
+            "metric": "interpolated frames/s at 1080p (network_base, bs=1)" if key == ("base", 1088, 1920, True)
+            else f"interpolated frames/s ({variant} {args.height}x{args.width})",
+            "value": round(fps, 4), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"network_{variant} {args.height}x{args.width} (padded {H}x{W}) bs=1 per GPU, "
+                                   f"global {'on' if net.global_motion else 'off'}, fp32, random frame pairs, stress weights seed 1",
+                       "pairs_per_step": world, "parallelism": f"frame-batch dp{world} + all-gather" if world > 1 else "single GPU"},
+        }
+        if flops:
+            result["forward_tflops"] = round(flops * fps / world / 1e12, 2)     # per-GPU algorithmic rate of the whole forward
+            result["forward_frac_of_f32_mfma_peak"] = round(flops * fps / world / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
+        # ---- instrumented pass: per-launch HIP events on the launch stream ----
+        if not args.no_profile:
+            ops = net._ops_obj
+            for rep in range(2):          # second pass is the one reported (first warms the event pool)
+                ops.profile = []
+                step(0)
+                torch.cuda.synchronize()
+                prof = ops.profile
+                ops.profile = None
+            agg = {}
+            for name, meta, s, e in prof:
+                d = agg.setdefault(name, {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0})
+                d["ms"] += s.elapsed_time(e)
+                d["launches"] += 1
+                d["flops"] += meta.get("flops", 0.0)
+                d["bytes"] += meta.get("bytes", 0.0)
+            gemm = {"ms": 0.0, "launches": 0, "flops": 0.0}
+            for k in ("conv2d", "linear", "deconv2x2"):
+                if k in agg:
+                    for f in gemm:
+                        gemm[f] += agg[k][f]
+            total_ms = sum(d["ms"] for d in agg.values())
+            if gemm["ms"] > 0:
+                ach = gemm["flops"] / (gemm["ms"] * 1e-3) / 1e12
+                result["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                      "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                                      "kernel": "gemm_mfma_f32 (conv2d + linear + deconv2x2)",
+                                      "launches": gemm["launches"], "avg_launch_ms": round(gemm["ms"] / gemm["launches"], 4),
+                                      "algorithmic_gflop_per_forward": round(gemm["flops"] / 1e9, 1),
+                                      "share_of_forward_time": round(gemm["ms"] / total_ms, 4)}
+            result["kernels"] = {k: {"ms": round(d["ms"], 3), "launches": d["launches"],
+                                     **({"tflops": round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 2)} if d["flops"] and d["ms"] > 0 else {}),
+                                     **({"gbs": round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1)} if d["bytes"] and d["ms"] > 0 else {})}
+                                 for k, d in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+            result["kernels"]["_sum_ms"] = round(total_ms, 3)
+        # ---- CPU baseline: the oracle on this node's host cores, bounded sample ----
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import atmvfi_oracle as O
+            a, b = frames[0]
+            a, b = a.cpu(), b.cpu()
+            tc = time.perf_counter()
+            O.forward(sd, a, b, global_motion=net.global_motion)
+            tc = time.perf_counter() - tc
+            result["cpu_baseline"] = {"value": round(1.0 / tc, 5), "unit": "frames/s", "cores": torch.get_num_threads(),
+                                      "kind": "port", "sample": f"1 frame pair of the same workload ({H}x{W}), single run, no warm-up, {tc:.1f} s"}
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

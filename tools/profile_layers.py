@@ -1,0 +1,37 @@
+"""Per-launch timing table of one forward (HIP events on the launch stream): which layer shapes are slow."""
+import importlib, sys, os
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import pairs
+pkg = importlib.import_module("atm-vfi_amd")
+torch.set_grad_enabled(False)
+dev = torch.device("cuda:0")
+H, W = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1088, 1920)
+variant = sys.argv[3] if len(sys.argv) > 3 else "base"
+net = (pkg.NetworkBase if variant == "base" else pkg.NetworkLite)()
+net.load_state_dict(pkg.synthetic_state_dict(variant, seed=1))
+net.to(dev).eval()
+a, b = pairs.random_pair(1, H, W, seed=3)
+a, b = a.to(dev), b.to(dev)
+for _ in range(2):
+    net(a, b)
+ops = net._ops_obj
+best = None
+for rep in range(3):
+    ops.profile = []
+    net(a, b)
+    torch.cuda.synchronize()
+    prof = [(n, m, s.elapsed_time(e)) for n, m, s, e in ops.profile]
+    ops.profile = None
+    if best is None:
+        best = prof
+    else:
+        best = [(n, m, min(t, t2)) for (n, m, t), (_, _, t2) in zip(best, prof)]
+tot = sum(t for _, _, t in best)
+print(f"total {tot:.2f} ms over {len(best)} launches")
+for n, m, t in best:
+    if t < 0.15: continue
+    tf = m.get("flops", 0) / (t * 1e-3) / 1e12
+    gb = m.get("bytes", 0) / (t * 1e-3) / 1e9
+    print(f"{n:18s} {m.get('shape', ''):28s} {t:8.3f} ms {tf:7.1f} TF/s {gb:8.1f} GB/s")
