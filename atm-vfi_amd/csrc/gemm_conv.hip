@@ -367,12 +367,16 @@ extern "C" int atmvfi_gemm(const atmvfi_gemm_params* p, void* stream) {
     d.bias = p->bias; d.prelu = p->prelu; d.in_prelu = p->in_prelu; d.residual = p->residual; d.res_ld = p->res_ld;
     ATMVFI_REQUIRE(d.M < (1ll << 40), ATMVFI_EINVAL, "gemm: M too large");
 
-    // choose the wave tile width: least padded N, ties to the wider tile
+    // choose the wave tile width WN (block = 128 x 16*WN): MFMA work scales with the padded tile
+    // count, operand traffic per MFMA with (1/BM + 1/BN) -- a narrow tile re-reads the activation
+    // panel once per n-block (measured: N=197 as 13 x WN=1 ran at 30 TF/s, as 2 x WN=7 at ~90).
     const int ntiles = (ngemm + 15) / 16;
-    int best = 1, best_pad = 1 << 30;
+    int best = 1;
+    float best_cost = 1e30f;
     for (int wn = 1; wn <= 8; ++wn) {
         const int padded = (ntiles + wn - 1) / wn * wn;
-        if (padded <= best_pad) { best_pad = padded; best = wn; }
+        const float cost = (float)padded * (1.0f + 1.0f / (float)wn);
+        if (cost <= best_cost) { best_cost = cost; best = wn; }
     }
     hipStream_t s = (hipStream_t)stream;
     switch (best) {
