@@ -1,0 +1,360 @@
+// 3x3 / stride 1 / pad 1 convolution for gfx950 with an LDS-resident input halo and
+// split-precision MFMA ("f16x3").
+//
+// Why: the generic implicit-GEMM kernel re-reads every input pixel once per tap (9x) from
+// L2 and runs on the exact-fp32 MFMA, which is 1/16 of the 16-bit MFMA rate.  3x3 s1 convs
+// are two thirds of the network's FLOPs, so this kernel
+//   * stages the (16+2)x(16+2) input halo of a 16x16 output tile ONCE per 32-channel chunk
+//     and walks the 9 taps by shifting the fragment base address inside LDS;
+//   * splits every fp32 operand as x = hi + lo'/1024 (hi = fp16(x), lo' = fp16((x - hi)*1024)) while
+//     staging, and accumulates hi*hi into one fp32 accumulator and hi*lo' + lo'*hi into a second
+//     one (folded in with 2^-10 in the epilogue) on v_mfma_f32_16x16x32_f16: 3 MFMAs at 16x the
+//     fp32-MFMA rate = 5.3x, ~22 significand bits at any operand magnitude (the dropped lo*lo
+//     term is 2^-22 relative).  Weights are split once at pack time.
+//
+// Block = 512 threads = 8 wavefronts; output tile = 16x16 pixels (wave w owns output rows
+// 2w, 2w+1 = two 16-pixel MFMA column tiles) x 16*WN output channels.
+// LDS (one __shared__ array): halo hi/lo planes [2 buffers][324 px][32 halves] and weight
+// hi/lo planes [2 buffers][16*WN rows][32 halves]; rows are 64 bytes and 16-byte slots are
+// XOR-swizzled with ((row>>2)&1)<<1, which keeps ds_read_b128 fragment reads conflict-free
+// for EVERY base row (the tap shift moves the base).  One barrier per (chunk, tap) stage;
+// the next stage's weights and one third of the next chunk's halo are fetched into
+// registers before the MFMA phase and written to the other LDS buffer after it.
+#include "common.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+struct Conv3Dev {
+    const float* in;
+    int in_ld, N, H, W, Cin;
+    const _Float16* w_hi;
+    const _Float16* w_lo;
+    int wrows;      // packed weight rows (multiple of 16)
+    int cin_pad;    // Cin rounded up to 32
+    int Cout;
+    float* out;
+    int out_ld;
+    const float* bias;
+    const float* prelu;
+    int tiles_x, tiles_y;
+};
+
+constexpr int TW = 16, TH = 16, HW_ = TW + 2, HH_ = TH + 2, NPIX = HW_ * HH_;   // 18 x 18 = 324 halo pixels
+constexpr int HALO_TASKS = NPIX * 4;                                            // (pixel, 8-channel group)
+constexpr int HALO_TPT = (HALO_TASKS + 511) / 512;                              // 3 tasks per thread
+
+__device__ __forceinline__ int swz64(int row) { return ((row >> 2) & 1) << 1; }
+
+// x = hi + lo'/1024 with hi = fp16(x) and lo' = fp16((x - hi) * 1024): scaling keeps lo' a NORMAL fp16
+// whenever hi is (|lo'| <= |x|), so the pair carries ~22 significand bits at any magnitude down to
+// fp16's normal range.  Both conversions clamp to +-65504 first, so finite fp32 never becomes inf.
+constexpr float LO_SCALE = 1024.0f;
+constexpr float LO_UNSCALE = 1.0f / 1024.0f;
+__device__ __forceinline__ _Float16 sat_half(float v) { return (_Float16)fminf(fmaxf(v, -65504.0f), 65504.0f); }
+
+__device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, f16x8& hi, f16x8& lo) {
+    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const _Float16 h = sat_half(x[e]);
+        hi[e] = h;
+        lo[e] = sat_half((x[e] - (float)h) * LO_SCALE);
+    }
+}
+
+template <int WN>
+__global__ __launch_bounds__(512) void conv3x3_f16x3_kernel(const Conv3Dev a) {
+    constexpr int BN = 16 * WN;
+    constexpr int BP = BN * 8;                      // 16-byte weight pieces per stage (hi + lo)
+    constexpr int B_PPT = (BP + 511) / 512;
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
+    _Float16* halo_hi = smem;                           // [2][NPIX][32]
+    _Float16* halo_lo = halo_hi + 2 * NPIX * 32;
+    _Float16* b_hi = halo_lo + 2 * NPIX * 32;           // [2][BN][32]
+    _Float16* b_lo = b_hi + 2 * BN * 32;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int r = lane & 15;
+    const int g = lane >> 4;
+
+    int bid = blockIdx.x;
+    const int txb = bid % a.tiles_x;
+    bid /= a.tiles_x;
+    const int tyb = bid % a.tiles_y;
+    const int img = bid / a.tiles_y;
+    const int ox0 = txb * TW, oy0 = tyb * TH;
+    const int n0 = blockIdx.y * BN;
+
+    // ---- halo task bookkeeping: task T = tid + 512*k -> (halo pixel, 8-channel group) ----
+    const float* hsrc[HALO_TPT];
+    int hdst[HALO_TPT];       // halves offset inside one halo plane buffer
+    bool hok[HALO_TPT], hact[HALO_TPT];
+    int hq[HALO_TPT];
+#pragma unroll
+    for (int k = 0; k < HALO_TPT; ++k) {
+        const int T = tid + 512 * k;
+        hact[k] = T < HALO_TASKS;
+        const int hp = hact[k] ? (T >> 2) : 0;
+        const int q = T & 3;
+        const int hy = hp / HW_, hx = hp - hy * HW_;
+        const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+        hok[k] = hact[k] && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        hsrc[k] = a.in + (((long long)img * a.H + (hok[k] ? iy : 0)) * a.W + (hok[k] ? ix : 0)) * a.in_ld + q * 8;
+        hdst[k] = hp * 32 + ((q ^ swz64(hp)) << 3);
+        hq[k] = q;
+    }
+    // ---- weight piece bookkeeping: piece P = tid + 512*k -> (plane, row, slot) ----
+    const _Float16* wsrc[B_PPT];
+    int wdst[B_PPT];
+    bool wok[B_PPT], wact[B_PPT], wlo[B_PPT];
+    const long long ktot = 9ll * a.cin_pad;
+#pragma unroll
+    for (int k = 0; k < B_PPT; ++k) {
+        const int P = tid + 512 * k;
+        wact[k] = P < BP;
+        const int plane = (P >= BN * 4) ? 1 : 0;
+        const int rem = P - plane * BN * 4;
+        const int row = wact[k] ? (rem >> 2) : 0;
+        const int slot = rem & 3;
+        wlo[k] = plane == 1;
+        wok[k] = wact[k] && (n0 + row) < a.wrows;
+        wsrc[k] = (plane ? a.w_lo : a.w_hi) + (long long)(wok[k] ? n0 + row : 0) * ktot + slot * 8;
+        wdst[k] = row * 32 + ((slot ^ swz64(row)) << 3);
+    }
+
+    f32x4 acc[2][WN], cor[2][WN];      // hi*hi terms / (hi*lo' + lo'*hi) terms, the latter scaled by 1024
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            cor[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+
+    const int nchunks = a.cin_pad >> 5;
+    const int nstages = nchunks * 9;
+
+    f32x4 hra, hrb;        // one halo task in flight
+    f16x8 wr[B_PPT];
+
+    auto halo_load = [&](int k, int chunk) {
+        const int c = chunk * 32 + hq[k] * 8;
+        hra = (f32x4){0.f, 0.f, 0.f, 0.f};
+        hrb = hra;
+        if (hok[k] && c < a.Cin) {
+            const float* p = hsrc[k] + chunk * 32;
+            hra = *reinterpret_cast<const f32x4*>(p);
+            if (c + 4 < a.Cin) hrb = *reinterpret_cast<const f32x4*>(p + 4);
+            const int nv = a.Cin - c;          // valid channels in this group of 8 (>= 1)
+            if (nv < 8) {
+                if (nv < 2) hra.y = 0.f;
+                if (nv < 3) hra.z = 0.f;
+                if (nv < 4) hra.w = 0.f;
+                if (nv < 6) hrb.y = 0.f;
+                if (nv < 7) hrb.z = 0.f;
+                hrb.w = 0.f;
+                if (nv < 5) hrb.x = 0.f;
+            }
+        }
+    };
+    auto halo_store = [&](int k, int buf) {
+        if (hact[k]) {
+            f16x8 hi, lo;
+            split8(hra, hrb, hi, lo);
+            *reinterpret_cast<f16x8*>(halo_hi + buf * NPIX * 32 + hdst[k]) = hi;
+            *reinterpret_cast<f16x8*>(halo_lo + buf * NPIX * 32 + hdst[k]) = lo;
+        }
+    };
+    auto w_load = [&](int stage) {
+        const int chunk = stage / 9;
+        const int tap = stage - chunk * 9;
+        const long long koff = (long long)tap * a.cin_pad + chunk * 32;
+#pragma unroll
+        for (int k = 0; k < B_PPT; ++k) {
+            f16x8 v = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            if (wok[k]) v = *reinterpret_cast<const f16x8*>(wsrc[k] + koff);
+            wr[k] = v;
+        }
+    };
+    auto w_store = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < B_PPT; ++k)
+            if (wact[k]) *reinterpret_cast<f16x8*>((wlo[k] ? b_lo : b_hi) + buf * BN * 32 + wdst[k]) = wr[k];
+    };
+
+    // ---- prologue: halo of chunk 0, weights of stage 0 ----
+#pragma unroll
+    for (int k = 0; k < HALO_TPT; ++k) {
+        halo_load(k, 0);
+        halo_store(k, 0);
+    }
+    w_load(0);
+    w_store(0);
+    __syncthreads();
+
+    for (int s = 0; s < nstages; ++s) {
+        const int chunk = s / 9;
+        const int tap = s - chunk * 9;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int hb = chunk & 1, wb = s & 1;
+        const bool more_w = (s + 1) < nstages;
+        const bool more_h = (tap < HALO_TPT) && (chunk + 1 < nchunks);
+        if (more_w) w_load(s + 1);
+#pragma unroll
+        for (int k = 0; k < HALO_TPT; ++k)      // static k: runtime-indexed register arrays would go to scratch
+            if (more_h && tap == k) halo_load(k, chunk + 1);
+
+        f16x8 xh[2], xl[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int p = (2 * wave + i + ky) * HW_ + kx + r;
+            const int off = hb * NPIX * 32 + p * 32 + ((g ^ swz64(p)) << 3);
+            xh[i] = *reinterpret_cast<const f16x8*>(halo_hi + off);
+            xl[i] = *reinterpret_cast<const f16x8*>(halo_lo + off);
+        }
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int row = 16 * j + r;
+            const int off = wb * BN * 32 + row * 32 + ((g ^ swz64(row)) << 3);
+            const f16x8 wh = *reinterpret_cast<const f16x8*>(b_hi + off);
+            const f16x8 wl = *reinterpret_cast<const f16x8*>(b_lo + off);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                cor[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[i], cor[i][j], 0, 0, 0);
+                cor[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[i], cor[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[i], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (more_w) w_store(wb ^ 1);
+#pragma unroll
+        for (int k = 0; k < HALO_TPT; ++k)
+            if (more_h && tap == k) halo_store(k, hb ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds channels nb..nb+3 of pixel (oy0 + 2*wave + i, ox0 + r) ----
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int oy = oy0 + 2 * wave + i, ox = ox0 + r;
+        if (oy >= a.H || ox >= a.W) continue;
+        float* orow = a.out + (((long long)img * a.H + oy) * a.W + ox) * a.out_ld;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int co = n0 + 16 * j + 4 * g;
+            if (co >= a.Cout) continue;
+            const f32x4 v = acc[i][j], c2 = cor[i][j];
+            const int nvalid = a.Cout - co;
+            float vv[4] = {v.x + c2.x * LO_UNSCALE, v.y + c2.y * LO_UNSCALE, v.z + c2.z * LO_UNSCALE, v.w + c2.w * LO_UNSCALE};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (e < nvalid) {
+                    float x = vv[e];
+                    if (a.bias) x += a.bias[co + e];
+                    if (a.prelu) x = x > 0.f ? x : a.prelu[co + e] * x;
+                    vv[e] = x;
+                }
+            }
+            if (nvalid >= 4) {
+                *reinterpret_cast<f32x4*>(orow + co) = (f32x4){vv[0], vv[1], vv[2], vv[3]};
+            } else {
+                for (int e = 0; e < nvalid; ++e) orow[co + e] = vv[e];
+            }
+        }
+    }
+}
+
+__global__ void pack_split_kernel(const float* __restrict__ src, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
+                                  int Cout, int Cin, int kh, int kw, int rows, int cin_pad) {
+    const int taps = kh * kw;
+    const long long total = (long long)rows * taps * cin_pad;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % cin_pad);
+        const int tap = (int)((idx / cin_pad) % taps);
+        const int row = (int)(idx / ((long long)cin_pad * taps));
+        float v = 0.f;
+        if (c < Cin && row < Cout) {
+            const int ky = tap / kw, kx = tap - ky * kw;
+            v = src[(((long long)row * Cin + c) * kh + ky) * kw + kx];
+        }
+        const _Float16 h = sat_half(v);
+        hi[idx] = h;
+        lo[idx] = sat_half((v - (float)h) * LO_SCALE);
+    }
+}
+
+template <int WN>
+int launch3(const Conv3Dev& d, int ntiles, hipStream_t s) {
+    constexpr int BN = 16 * WN;
+    const size_t lds = (size_t)(4 * NPIX * 32 + 4 * BN * 32) * sizeof(_Float16);
+    auto kern = conv3x3_f16x3_kernel<WN>;
+    static bool attr_set = false;      // idempotent, per instantiation
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        ATMVFI_REQUIRE(e == hipSuccess, ATMVFI_ELAUNCH, "conv3x3_f16x3: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    dim3 grid((unsigned)((long long)d.N * d.tiles_x * d.tiles_y), (unsigned)((ntiles + WN - 1) / WN));
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, d);
+    return atmvfi::check_launch("conv3x3_f16x3");
+}
+
+}  // namespace
+
+extern "C" int64_t atmvfi_split_weight_halves(int Cout, int Cin, int kh, int kw) {
+    return (int64_t)atmvfi::round_up(Cout, 16) * kh * kw * atmvfi::round_up(Cin, 32);
+}
+
+extern "C" int atmvfi_pack_weight_split(const float* src, void* dst_hi, void* dst_lo, int Cout, int Cin, int kh, int kw,
+                                         void* stream) {
+    ATMVFI_REQUIRE(src && dst_hi && dst_lo && Cout > 0 && Cin > 0 && kh > 0 && kw > 0, ATMVFI_EINVAL, "pack_weight_split: bad arguments");
+    const int64_t total = atmvfi_split_weight_halves(Cout, Cin, kh, kw);
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(pack_split_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (_Float16*)dst_hi,
+                       (_Float16*)dst_lo, Cout, Cin, kh, kw, atmvfi::round_up(Cout, 16), atmvfi::round_up(Cin, 32));
+    return atmvfi::check_launch("pack_weight_split");
+}
+
+extern "C" int atmvfi_conv3x3_f16x3(const float* in, int in_ld, int N, int H, int W, int Cin, const void* w_hi,
+                                     const void* w_lo, int Cout, float* out, int out_ld, const float* bias,
+                                     const float* prelu, void* stream) {
+    ATMVFI_REQUIRE(in && w_hi && w_lo && out, ATMVFI_EINVAL, "conv3x3_f16x3: null pointer");
+    ATMVFI_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, ATMVFI_EINVAL, "conv3x3_f16x3: bad shape");
+    ATMVFI_REQUIRE(in_ld % 4 == 0 && in_ld >= atmvfi::round_up(Cin, 4) && out_ld % 4 == 0 && out_ld >= atmvfi::round_up(Cout, 4),
+                   ATMVFI_EALIGN, "conv3x3_f16x3: leading dimensions must be multiples of 4 and cover the channels");
+    ATMVFI_REQUIRE(atmvfi::aligned16(in) && atmvfi::aligned16(out) && atmvfi::aligned16(w_hi) && atmvfi::aligned16(w_lo), ATMVFI_EALIGN,
+                   "conv3x3_f16x3: pointers must be 16-byte aligned");
+    Conv3Dev d;
+    d.in = in; d.in_ld = in_ld; d.N = N; d.H = H; d.W = W; d.Cin = Cin;
+    d.w_hi = (const _Float16*)w_hi; d.w_lo = (const _Float16*)w_lo;
+    d.wrows = atmvfi::round_up(Cout, 16);
+    d.cin_pad = atmvfi::round_up(Cin, 32);
+    d.Cout = Cout; d.out = out; d.out_ld = out_ld; d.bias = bias; d.prelu = prelu;
+    d.tiles_x = (W + TW - 1) / TW;
+    d.tiles_y = (H + TH - 1) / TH;
+    ATMVFI_REQUIRE((long long)N * d.tiles_x * d.tiles_y < (1ll << 31), ATMVFI_EINVAL, "conv3x3_f16x3: grid too large");
+    const int ntiles = (Cout + 15) / 16;
+    int best = 1;
+    float best_cost = 1e30f;
+    for (int wn = 1; wn <= 8; ++wn) {
+        const int padded = (ntiles + wn - 1) / wn * wn;
+        const float cost = (float)padded * (1.0f + 1.0f / (float)wn);
+        if (cost <= best_cost) { best_cost = cost; best = wn; }
+    }
+    hipStream_t s = (hipStream_t)stream;
+    switch (best) {
+        case 1: return launch3<1>(d, ntiles, s);
+        case 2: return launch3<2>(d, ntiles, s);
+        case 3: return launch3<3>(d, ntiles, s);
+        case 4: return launch3<4>(d, ntiles, s);
+        case 5: return launch3<5>(d, ntiles, s);
+        case 6: return launch3<6>(d, ntiles, s);
+        case 7: return launch3<7>(d, ntiles, s);
+        default: return launch3<8>(d, ntiles, s);
+    }
+}

@@ -62,6 +62,9 @@ SIGNATURES = {
     "atmvfi_deconv2x2": (c_i, [ctypes.POINTER(GemmParams), c_f]),
     "atmvfi_packed_weight_floats": (c_l, [c_i, c_i, c_i, c_i, c_i]),
     "atmvfi_pack_weight": (c_i, [c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
+    "atmvfi_split_weight_halves": (c_l, [c_i, c_i, c_i, c_i]),
+    "atmvfi_pack_weight_split": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
+    "atmvfi_conv3x3_f16x3": (c_i, [c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_i, c_f, c_f, c_f]),
     "atmvfi_layernorm": (c_i, [c_f, c_i, c_l, c_i, c_f, c_f, c_i, c_f, c_f, c_l, c_i, c_f]),
     "atmvfi_dwconv3x3_gelu": (c_i, [c_f, c_i, c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     "atmvfi_pack_dw_weight": (c_i, [c_f, c_f, c_i, c_f]),
@@ -102,6 +105,8 @@ class PackedWeight:
     kw: int
     orig: torch.Tensor                 # the parameter (OIHW / [out,in] / IOHW)
     packed: Optional[torch.Tensor]     # GEMM layout on the device (None only for test doubles)
+    hi: Optional[torch.Tensor] = None  # split-precision planes (fp16) for the f16x3 3x3 kernel
+    lo: Optional[torch.Tensor] = None
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -165,6 +170,9 @@ class HipOps:
         self.lib = load_library()
         self.device = device
         self.profile: Optional[List] = None      # when a list: (name, meta, start_evt, end_evt) per launch
+        # "f16x3": 3x3/s1 convs run split-precision on the 16-bit MFMA (hi*hi + hi*lo + lo*hi, fp32 accumulate);
+        # "f32": everything on the exact-fp32 MFMA.
+        self.precision = "f16x3"
 
     # ------------------------------------------------------------------ utils
     def _stream(self):
@@ -205,7 +213,14 @@ class HipOps:
         n = self.lib.atmvfi_packed_weight_floats(mode, cout, cin, kh, kw)
         dst = self.empty(n)
         self._check(self.lib.atmvfi_pack_weight(mode, _ptr(w), _ptr(dst), cout, cin, kh, kw, self._stream()), "pack_weight")
-        return PackedWeight(mode, cout, cin, kh, kw, w, dst)
+        pw = PackedWeight(mode, cout, cin, kh, kw, w, dst)
+        if mode == GEMM_CONV and kh == 3 and kw == 3 and cin >= 16:
+            nh = self.lib.atmvfi_split_weight_halves(cout, cin, kh, kw)
+            pw.hi = torch.empty(nh, dtype=torch.float16, device=self.device)
+            pw.lo = torch.empty(nh, dtype=torch.float16, device=self.device)
+            self._check(self.lib.atmvfi_pack_weight_split(_ptr(w), _ptr(pw.hi), _ptr(pw.lo), cout, cin, kh, kw, self._stream()),
+                        "pack_weight_split")
+        return pw
 
     def pack_dw_weight(self, w: torch.Tensor) -> torch.Tensor:
         _chk(w, "pack_dw_weight")
@@ -228,13 +243,18 @@ class HipOps:
         old, on, oh, ow, cout = nhwc_view(out, "conv.out")
         if cin != w.cin or cout != w.cout or on != n or w.mode != GEMM_CONV:
             raise ValueError(f"conv: shape mismatch in {tuple(x.shape)} w ({w.cout},{w.cin},{w.kh},{w.kw}) out {tuple(out.shape)}")
+        meta = {"flops": 2.0 * n * oh * ow * cout * cin * w.kh * w.kw,
+                "bytes": 4.0 * (n * h * wd * cin + n * oh * ow * cout + cout * cin * w.kh * w.kw),
+                "shape": f"M{n * oh * ow} N{cout} K{cin * w.kh * w.kw}"}
+        if (self.precision == "f16x3" and w.hi is not None and w.kh == 3 and stride == 1 and pad == 1 and dil == 1
+                and in_prelu is None):
+            self._run("conv3x3_f16x3", meta, self.lib.atmvfi_conv3x3_f16x3, _ptr(x), ld, n, h, wd, cin, _ptr(w.hi), _ptr(w.lo),
+                      cout, _ptr(out), old, _ptr(bias), _ptr(prelu), self._stream())
+            return
         p = GemmParams(mode=GEMM_CONV, in_=x.data_ptr(), in_ld=ld, N=n, H=h, W=wd, Cin=cin, in_gstride=0, in_rpg=0,
                        weight=w.packed.data_ptr(), Cout=cout, kh=w.kh, kw=w.kw, stride=stride, pad=pad, dil=dil,
                        Ho=oh, Wo=ow, M=n * oh * ow, out=out.data_ptr(), out_ld=old, out_gstride=0, out_rpg=0,
                        out_row_map=None, bias=_ptr(bias), prelu=_ptr(prelu), in_prelu=_ptr(in_prelu), residual=None, res_ld=0)
-        meta = {"flops": 2.0 * n * oh * ow * cout * cin * w.kh * w.kw,
-                "bytes": 4.0 * (n * h * wd * cin + n * oh * ow * cout + cout * cin * w.kh * w.kw),
-                "shape": f"M{n * oh * ow} N{cout} K{cin * w.kh * w.kw}"}
         self._run("conv2d", meta, self.lib.atmvfi_conv2d, ctypes.byref(p), self._stream())
 
     def deconv(self, x, w: PackedWeight, out, bias=None, prelu=None, in_prelu=None):

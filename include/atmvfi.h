@@ -96,6 +96,22 @@ int64_t atmvfi_packed_weight_floats(int mode, int Cout, int Cin, int kh, int kw)
 int atmvfi_pack_weight(int mode, const float* src, float* dst, int Cout, int Cin, int kh, int kw, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Split-precision ("f16x3") 3x3 / stride 1 / pad 1 convolution -- the same Conv2d(+PReLU) call
+ * sites as ATMVFI_GEMM_CONV (network_base.py:20-25), two thirds of the network's FLOPs.
+ * Every fp32 operand is split as x = hi + lo (fp16 each) and hi*hi + hi*lo + lo*hi is accumulated
+ * in fp32 on v_mfma_f32_16x16x32_f16 (3 MFMAs at 16x the fp32-MFMA rate; ~22 significand bits,
+ * finite for |x| < 1.3e5).  The input halo of a 16x16 output tile is staged in LDS once per
+ * 32-channel chunk and reused by all nine taps.  Weights are split once by
+ * atmvfi_pack_weight_split into two fp16 planes [rows16(Cout)][kh*kw][CinPad32]
+ * (atmvfi_split_weight_halves() halves each).  Epilogue: + bias[co]; PReLU(slope[co]).
+ * ---------------------------------------------------------------------------------- */
+int64_t atmvfi_split_weight_halves(int Cout, int Cin, int kh, int kw);
+int atmvfi_pack_weight_split(const float* src /*OIHW*/, void* dst_hi, void* dst_lo, int Cout, int Cin, int kh, int kw,
+                             void* stream);
+int atmvfi_conv3x3_f16x3(const float* in, int in_ld, int N, int H, int W, int Cin, const void* w_hi, const void* w_lo,
+                         int Cout, float* out, int out_ld, const float* bias, const float* prelu, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * LayerNorm over the channel axis of token rows (eps 1e-5, affine), optional gather.
  * Replaces nn.LayerNorm at attention.py:316 (norm1 on windowed tokens), :333 (norm2) and
  * network_base.py:84 (fusion norm).  With `src_row_map` (length `rows`), output row r reads

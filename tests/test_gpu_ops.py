@@ -70,18 +70,57 @@ def test_conv2d(case, hip, cpu, dev):
     slope = torch.rand(cout, generator=g) * 0.4
     Ho = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
     Wo = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
-    for use_prelu in (True, False):
+    for use_prelu, precision in ((True, "f32"), (False, "f32"), (True, "f16x3"), (False, "f16x3")):
         obuf_c = torch.full((N, Ho, Wo, old), 7.0)
         cpu.conv(buf[..., ioff:ioff + cin], cpu.pack_weight(GEMM_CONV, w), obuf_c[..., ooff:ooff + cout], stride, pad, dil,
                  bias, slope if use_prelu else None)
         dbuf = buf.to(dev)
         obuf_g = torch.full((N, Ho, Wo, old), 7.0, device=dev)
         pw = hip.pack_weight(GEMM_CONV, w.to(dev))
-        hip.conv(dbuf[..., ioff:ioff + cin], pw, obuf_g[..., ooff:ooff + cout], stride, pad, dil, bias.to(dev),
-                 slope.to(dev) if use_prelu else None)
+        hip.precision = precision
+        try:
+            hip.conv(dbuf[..., ioff:ioff + cin], pw, obuf_g[..., ooff:ooff + cout], stride, pad, dil, bias.to(dev),
+                     slope.to(dev) if use_prelu else None)
+        finally:
+            hip.precision = "f16x3"
         torch.cuda.synchronize()
-        # the whole buffer is compared: channels outside the view must stay untouched (7.0)
+        # the whole buffer is compared: channels outside the view must stay untouched (7.0).
+        # f16x3 (3x3/s1 only) keeps ~22 significand bits: same budget as the fp32-MFMA path.
         assert maxdiff(obuf_g, obuf_c) <= 1e-4
+
+
+def test_conv3x3_f16x3_large_and_ragged(hip, cpu, dev):
+    """Split-precision halo kernel: partial 16x16 tiles, image borders, several images, large
+    magnitudes, tiny magnitudes (lo' is scaled so it never goes subnormal) and operands beyond the
+    fp16 range, which SATURATE at +-65504*(1+2^-10) instead of turning into inf/NaN (documented limit)."""
+    g = torch.Generator().manual_seed(77)
+    for (cin, cout, H, W, N, scale, overflow) in ((48, 37, 23, 41, 2, 1.0, False), (773 // 4, 64, 17, 16, 1, 1.0, False),
+                                                  (32, 16, 16, 16, 1, 3.0e4, False), (32, 16, 16, 16, 1, 3.0e4, True),
+                                                  (64, 128, 33, 18, 1, 1e-3, False)):
+        r4 = lambda c: (c + 3) // 4 * 4
+        x = rnd(g, N, H, W, r4(cin), scale=scale)[..., :cin]
+        if overflow:
+            x[0, 3, 3, :4] = torch.tensor([1.0e5, -1.2e5, 65504.0, 7.0e4])
+        w = rnd(g, cout, cin, 3, 3, scale=1.0 / np.sqrt(9 * cin))
+        bias = rnd(g, cout, scale=0.2 * scale)
+        oc = torch.empty(N, H, W, r4(cout))[..., :cout]
+        cpu.conv(x, cpu.pack_weight(GEMM_CONV, w), oc, 1, 1, 1, bias, None)
+        og = torch.empty(N, H, W, r4(cout), device=dev)[..., :cout]
+        xg = torch.zeros(N, H, W, r4(cin), device=dev)
+        xg[..., :cin] = x.to(dev)
+        hip.conv(xg[..., :cin], hip.pack_weight(GEMM_CONV, w.to(dev)), og, 1, 1, 1, bias.to(dev), None)
+        torch.cuda.synchronize()
+        assert hip.precision == "f16x3"
+        assert not torch.isnan(og).any() and not torch.isinf(og).any()
+        xr = x.clamp(-65504.0 * (1 + 2.0 ** -10), 65504.0 * (1 + 2.0 ** -10)) if overflow else x
+        ref64 = torch.nn.functional.conv2d(xr.permute(0, 3, 1, 2).double(), w.double(), bias.double(), padding=1).permute(0, 2, 3, 1)
+        err_hip = (og.cpu().double() - ref64).abs().max().item()
+        err_cpu32 = (oc.double() - ref64).abs().max().item()
+        if overflow:
+            assert err_hip <= 0.5, (err_hip, err_cpu32)       # equals the convolution of the saturated input
+        else:
+            # within a small factor of what plain fp32 arithmetic itself loses against fp64
+            assert err_hip <= max(8 * err_cpu32, 2e-6 * scale), (cin, cout, err_hip, err_cpu32)
 
 
 DECONV_CASES = [(773, 389, 5, 7, 776, 392, 1), (13, 21, 6, 5, 16, 24, 2), (256, 128, 6, 10, 256, 128, 1), (128, 64, 4, 4, 328, 128, 2)]
