@@ -139,38 +139,43 @@ __global__ __launch_bounds__(512) void conv3x3_f16x3_kernel(const Conv3Dev a) {
     const int nchunks = a.cin_pad >> 5;
     const int nstages = nchunks * 9;
 
-    f32x4 hra, hrb;        // one halo task in flight
-    f16x8 wr[B_PPT];
+    // Register-staged prefetch, deep enough to cover loaded-memory latency with one block per CU:
+    // weights run TWO stages ahead (two register sets, alternating), the next chunk's halo is
+    // requested at tap 0 and converted/written at tap HALO_WRITE_TAP.
+    constexpr int HALO_WRITE_TAP = 5;
+    f32x4 hr[HALO_TPT][2];
+    f16x8 wrA[B_PPT], wrB[B_PPT];
 
-    auto halo_load = [&](int k, int chunk) {
+    auto halo_load = [&](int k, int chunk) {        // k is a compile-time constant at every call site
         const int c = chunk * 32 + hq[k] * 8;
-        hra = (f32x4){0.f, 0.f, 0.f, 0.f};
-        hrb = hra;
+        f32x4 va = (f32x4){0.f, 0.f, 0.f, 0.f}, vb = va;
         if (hok[k] && c < a.Cin) {
             const float* p = hsrc[k] + chunk * 32;
-            hra = *reinterpret_cast<const f32x4*>(p);
-            if (c + 4 < a.Cin) hrb = *reinterpret_cast<const f32x4*>(p + 4);
+            va = *reinterpret_cast<const f32x4*>(p);
+            if (c + 4 < a.Cin) vb = *reinterpret_cast<const f32x4*>(p + 4);
             const int nv = a.Cin - c;          // valid channels in this group of 8 (>= 1)
             if (nv < 8) {
-                if (nv < 2) hra.y = 0.f;
-                if (nv < 3) hra.z = 0.f;
-                if (nv < 4) hra.w = 0.f;
-                if (nv < 6) hrb.y = 0.f;
-                if (nv < 7) hrb.z = 0.f;
-                hrb.w = 0.f;
-                if (nv < 5) hrb.x = 0.f;
+                if (nv < 2) va.y = 0.f;
+                if (nv < 3) va.z = 0.f;
+                if (nv < 4) va.w = 0.f;
+                if (nv < 5) vb.x = 0.f;
+                if (nv < 6) vb.y = 0.f;
+                if (nv < 7) vb.z = 0.f;
+                vb.w = 0.f;
             }
         }
+        hr[k][0] = va;
+        hr[k][1] = vb;
     };
     auto halo_store = [&](int k, int buf) {
         if (hact[k]) {
             f16x8 hi, lo;
-            split8(hra, hrb, hi, lo);
+            split8(hr[k][0], hr[k][1], hi, lo);
             *reinterpret_cast<f16x8*>(halo_hi + buf * NPIX * 32 + hdst[k]) = hi;
             *reinterpret_cast<f16x8*>(halo_lo + buf * NPIX * 32 + hdst[k]) = lo;
         }
     };
-    auto w_load = [&](int stage) {
+    auto w_load = [&](int stage, f16x8 (&dst)[B_PPT]) {
         const int chunk = stage / 9;
         const int tap = stage - chunk * 9;
         const long long koff = (long long)tap * a.cin_pad + chunk * 32;
@@ -178,37 +183,27 @@ __global__ __launch_bounds__(512) void conv3x3_f16x3_kernel(const Conv3Dev a) {
         for (int k = 0; k < B_PPT; ++k) {
             f16x8 v = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
             if (wok[k]) v = *reinterpret_cast<const f16x8*>(wsrc[k] + koff);
-            wr[k] = v;
+            dst[k] = v;
         }
     };
-    auto w_store = [&](int buf) {
+    auto w_store = [&](int buf, const f16x8 (&src)[B_PPT]) {
 #pragma unroll
         for (int k = 0; k < B_PPT; ++k)
-            if (wact[k]) *reinterpret_cast<f16x8*>((wlo[k] ? b_lo : b_hi) + buf * BN * 32 + wdst[k]) = wr[k];
+            if (wact[k]) *reinterpret_cast<f16x8*>((wlo[k] ? b_lo : b_hi) + buf * BN * 32 + wdst[k]) = src[k];
     };
-
-    // ---- prologue: halo of chunk 0, weights of stage 0 ----
-#pragma unroll
-    for (int k = 0; k < HALO_TPT; ++k) {
-        halo_load(k, 0);
-        halo_store(k, 0);
-    }
-    w_load(0);
-    w_store(0);
-    __syncthreads();
-
-    for (int s = 0; s < nstages; ++s) {
+    // one (chunk, tap) stage: `nxt` holds the weights of stage s+1 (written to LDS after the MFMAs),
+    // `far` receives the weights of stage s+2.
+    auto stage = [&](int s, f16x8 (&nxt)[B_PPT], f16x8 (&far)[B_PPT]) {
         const int chunk = s / 9;
         const int tap = s - chunk * 9;
         const int ky = tap / 3, kx = tap - ky * 3;
         const int hb = chunk & 1, wb = s & 1;
-        const bool more_w = (s + 1) < nstages;
-        const bool more_h = (tap < HALO_TPT) && (chunk + 1 < nchunks);
-        if (more_w) w_load(s + 1);
+        const bool more_h = chunk + 1 < nchunks;
+        if (s + 2 < nstages) w_load(s + 2, far);
+        if (more_h && tap == 0) {
 #pragma unroll
-        for (int k = 0; k < HALO_TPT; ++k)      // static k: runtime-indexed register arrays would go to scratch
-            if (more_h && tap == k) halo_load(k, chunk + 1);
-
+            for (int k = 0; k < HALO_TPT; ++k) halo_load(k, chunk + 1);
+        }
         f16x8 xh[2], xl[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -230,11 +225,27 @@ __global__ __launch_bounds__(512) void conv3x3_f16x3_kernel(const Conv3Dev a) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[i], acc[i][j], 0, 0, 0);
             }
         }
-        if (more_w) w_store(wb ^ 1);
+        if (s + 1 < nstages) w_store(wb ^ 1, nxt);
+        if (more_h && tap == HALO_WRITE_TAP) {
 #pragma unroll
-        for (int k = 0; k < HALO_TPT; ++k)
-            if (more_h && tap == k) halo_store(k, hb ^ 1);
+            for (int k = 0; k < HALO_TPT; ++k) halo_store(k, hb ^ 1);
+        }
         __syncthreads();
+    };
+
+    // ---- prologue: halo of chunk 0, weights of stage 0 in LDS, weights of stage 1 in flight ----
+#pragma unroll
+    for (int k = 0; k < HALO_TPT; ++k) halo_load(k, 0);
+    w_load(0, wrA);
+    if (nstages > 1) w_load(1, wrB);
+#pragma unroll
+    for (int k = 0; k < HALO_TPT; ++k) halo_store(k, 0);
+    w_store(0, wrA);
+    __syncthreads();
+
+    for (int s = 0; s < nstages; s += 2) {
+        stage(s, wrB, wrA);                        // even stage: stage s+1 lives in wrB, s+2 goes to wrA
+        if (s + 1 < nstages) stage(s + 1, wrA, wrB);
     }
 
     // ---- epilogue: lane holds channels nb..nb+3 of pixel (oy0 + 2*wave + i, ox0 + r) ----
@@ -268,9 +279,9 @@ __global__ __launch_bounds__(512) void conv3x3_f16x3_kernel(const Conv3Dev a) {
     }
 }
 
-__global__ void pack_split_kernel(const float* __restrict__ src, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
-                                  int Cout, int Cin, int kh, int kw, int rows, int cin_pad) {
-    const int taps = kh * kw;
+__global__ void pack_split_kernel(int mode, const float* __restrict__ src, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
+                                  int Cout, int Cin, int kh, int kw, int rows, int cin_pad, int coutp) {
+    const int taps = (mode == ATMVFI_GEMM_DECONV) ? 1 : kh * kw;
     const long long total = (long long)rows * taps * cin_pad;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
@@ -278,9 +289,15 @@ __global__ void pack_split_kernel(const float* __restrict__ src, _Float16* __res
         const int tap = (int)((idx / cin_pad) % taps);
         const int row = (int)(idx / ((long long)cin_pad * taps));
         float v = 0.f;
-        if (c < Cin && row < Cout) {
-            const int ky = tap / kw, kx = tap - ky * kw;
-            v = src[(((long long)row * Cin + c) * kh + ky) * kw + kx];
+        if (c < Cin) {
+            if (mode == ATMVFI_GEMM_DECONV) {
+                const int q = row / coutp;
+                const int co = row - q * coutp;
+                if (q < 4 && co < Cout) v = src[(((long long)c * Cout + co) * 2 + (q >> 1)) * 2 + (q & 1)];   // IOHW
+            } else if (row < Cout) {
+                const int ky = tap / kw, kx = tap - ky * kw;
+                v = src[(((long long)row * Cin + c) * kh + ky) * kw + kx];                                      // OIHW
+            }
         }
         const _Float16 h = sat_half(v);
         hi[idx] = h;
@@ -306,17 +323,25 @@ int launch3(const Conv3Dev& d, int ntiles, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int64_t atmvfi_split_weight_halves(int Cout, int Cin, int kh, int kw) {
-    return (int64_t)atmvfi::round_up(Cout, 16) * kh * kw * atmvfi::round_up(Cin, 32);
+static int split_rows(int mode, int Cout) {
+    return (mode == ATMVFI_GEMM_DECONV) ? atmvfi::round_up(4 * atmvfi::round_up(Cout, 4), 16) : atmvfi::round_up(Cout, 16);
 }
 
-extern "C" int atmvfi_pack_weight_split(const float* src, void* dst_hi, void* dst_lo, int Cout, int Cin, int kh, int kw,
-                                         void* stream) {
-    ATMVFI_REQUIRE(src && dst_hi && dst_lo && Cout > 0 && Cin > 0 && kh > 0 && kw > 0, ATMVFI_EINVAL, "pack_weight_split: bad arguments");
-    const int64_t total = atmvfi_split_weight_halves(Cout, Cin, kh, kw);
+extern "C" int64_t atmvfi_split_weight_halves(int mode, int Cout, int Cin, int kh, int kw) {
+    const int taps = (mode == ATMVFI_GEMM_DECONV) ? 1 : kh * kw;
+    return (int64_t)split_rows(mode, Cout) * taps * atmvfi::round_up(Cin, 32);
+}
+
+extern "C" int atmvfi_pack_weight_split(int mode, const float* src, void* dst_hi, void* dst_lo, int Cout, int Cin, int kh,
+                                         int kw, void* stream) {
+    ATMVFI_REQUIRE(src && dst_hi && dst_lo && Cout > 0 && Cin > 0 && kh > 0 && kw > 0 && mode >= 0 && mode <= 2, ATMVFI_EINVAL,
+                   "pack_weight_split: bad arguments");
+    if (mode == ATMVFI_GEMM_DECONV) ATMVFI_REQUIRE(kh == 2 && kw == 2, ATMVFI_EINVAL, "pack_weight_split: deconv must be 2x2");
+    const int64_t total = atmvfi_split_weight_halves(mode, Cout, Cin, kh, kw);
     const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-    hipLaunchKernelGGL(pack_split_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (_Float16*)dst_hi,
-                       (_Float16*)dst_lo, Cout, Cin, kh, kw, atmvfi::round_up(Cout, 16), atmvfi::round_up(Cin, 32));
+    hipLaunchKernelGGL(pack_split_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, mode, src, (_Float16*)dst_hi,
+                       (_Float16*)dst_lo, Cout, Cin, kh, kw, split_rows(mode, Cout), atmvfi::round_up(Cin, 32),
+                       atmvfi::round_up(Cout, 4));
     return atmvfi::check_launch("pack_weight_split");
 }
 

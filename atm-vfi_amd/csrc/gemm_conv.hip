@@ -15,39 +15,13 @@
 // the two operands, lane group g = lane>>4 consumes k = 4g..4g+3 of a chunk: one
 // ds_read_b128 per fragment feeds four MFMA k-steps.
 #include "common.h"
+#include "gemm_common.h"
 
 #include <algorithm>
 
 namespace {
 
-struct GemmDev {
-    int mode;
-    const float* in;
-    int in_ld, H, W, Cin;
-    long long in_gstride;
-    int in_rpg;
-    const float* weight;
-    int wrows;        // weight rows present (multiple of 16)
-    int ktot;         // floats per weight row = taps * cin_pad
-    int cin_pad;      // Cin rounded up to 16
-    int cpt;          // chunks per tap = cin_pad / 16
-    int nchunks;      // taps * cpt
-    int Cout;         // real output channels (DECONV: per-position channels)
-    int coutp;        // DECONV: Cout rounded up to 4
-    int kw, stride, pad, dil;
-    int Ho, Wo;
-    long long M;
-    float* out;
-    int out_ld;
-    long long out_gstride;
-    int out_rpg;
-    const int* out_row_map;
-    const float* bias;
-    const float* prelu;
-    const float* in_prelu;
-    const float* residual;
-    int res_ld;
-};
+using atmvfi::GemmDev;
 
 // 16-byte slot swizzle: slot' = slot ^ f(row), f = [0,2,3,1][(row>>2)&3].  With 64-byte rows
 // this makes every ds_read_b128 lane group {16 lanes} hit 16 distinct slots of a 256-byte bank row.
@@ -200,54 +174,13 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32(const GemmDev a) {
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
         const long long m = m0 + wave * 16 * WM + 16 * i + r;
-        if (m >= a.M) continue;
         float* orow;
-        if (a.mode == ATMVFI_GEMM_DECONV) {
-            const int hw = a.H * a.W;
-            const int n = (int)(m / hw);
-            const int rem = (int)(m - (long long)n * hw);
-            const int y = rem / a.W;
-            const int x = rem - y * a.W;
-            orow = a.out + (((long long)n * a.Ho + 2 * y) * a.Wo + 2 * x) * a.out_ld;   // position (a=0,b=0)
-        } else {
-            long long ro = m;
-            if (a.out_row_map) ro = a.out_row_map[m];
-            if (ro < 0) continue;
-            const long long off = (a.out_rpg > 0) ? (ro / a.out_rpg) * a.out_gstride + (ro % a.out_rpg) * (long long)a.out_ld
-                                                  : ro * (long long)a.out_ld;
-            orow = a.out + off;
-        }
-        const float* rrow = a.residual ? a.residual + m * (long long)a.res_ld : nullptr;
+        const float* rrow;
+        if (m >= a.M || !atmvfi::gemm_out_row(a, m, orow, rrow)) continue;
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
-            const int nb = n0 + 16 * j + 4 * g;
-            int co = nb;
-            float* optr = orow;
-            if (a.mode == ATMVFI_GEMM_DECONV) {
-                const int q = (nb >= a.coutp) + (nb >= 2 * a.coutp) + (nb >= 3 * a.coutp);
-                if (nb >= 4 * a.coutp) continue;
-                co = nb - q * a.coutp;
-                optr = orow + ((long long)(q >> 1) * a.Wo + (q & 1)) * a.out_ld;
-            }
-            if (co >= a.Cout) continue;
-            f32x4 v = acc[i][j];
-            const int nvalid = a.Cout - co;   // >= 1
-            float vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (e < nvalid) {
-                    float x = vv[e];
-                    if (a.bias) x += a.bias[co + e];
-                    if (a.prelu) x = x > 0.f ? x : a.prelu[co + e] * x;
-                    if (rrow) x += rrow[co + e];
-                    vv[e] = x;
-                }
-            }
-            if (nvalid >= 4) {
-                *reinterpret_cast<f32x4*>(optr + co) = (f32x4){vv[0], vv[1], vv[2], vv[3]};
-            } else {
-                for (int e = 0; e < nvalid; ++e) optr[co + e] = vv[e];
-            }
+            const f32x4 v = acc[i][j];
+            atmvfi::gemm_store4(a, orow, rrow, n0 + 16 * j + 4 * g, v.x, v.y, v.z, v.w);
         }
     }
 }
@@ -366,6 +299,18 @@ extern "C" int atmvfi_gemm(const atmvfi_gemm_params* p, void* stream) {
     d.out_row_map = p->out_row_map;
     d.bias = p->bias; d.prelu = p->prelu; d.in_prelu = p->in_prelu; d.residual = p->residual; d.res_ld = p->res_ld;
     ATMVFI_REQUIRE(d.M < (1ll << 40), ATMVFI_EINVAL, "gemm: M too large");
+    d.w_hi = (const _Float16*)p->weight_hi;
+    d.w_lo = (const _Float16*)p->weight_lo;
+    d.cin_pad32 = atmvfi::round_up(p->Cin, 32);
+    d.cpt32 = d.cin_pad32 / 32;
+    d.nchunks32 = taps * d.cpt32;
+    d.ktot32 = taps * d.cin_pad32;
+    if (p->precision == ATMVFI_PREC_F16X3) {
+        ATMVFI_REQUIRE(p->weight_hi && p->weight_lo, ATMVFI_EINVAL, "gemm: precision f16x3 needs weight_hi/weight_lo");
+        ATMVFI_REQUIRE(atmvfi::aligned16(p->weight_hi) && atmvfi::aligned16(p->weight_lo), ATMVFI_EALIGN,
+                       "gemm: split weights must be 16-byte aligned");
+        return atmvfi::launch_gemm_f16x3(d, ngemm, (hipStream_t)stream);
+    }
 
     // choose the wave tile width WN (block = 128 x 16*WN): MFMA work scales with the padded tile
     // count, operand traffic per MFMA with (1/BM + 1/BN) -- a narrow tile re-reads the activation

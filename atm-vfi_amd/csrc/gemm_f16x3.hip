@@ -1,0 +1,264 @@
+// Split-precision ("f16x3") variant of the implicit-GEMM engine for gfx950: nn.Linear rows,
+// ConvTranspose2d(k2,s2) and the strided / dilated / 1x1 convolutions -- everything the 3x3
+// stride-1 halo kernel (conv3x3_f16x3.hip) does not cover.  Same contract as gemm_conv.hip
+// (modes, row groups, scatter map, in_prelu, epilogue), same arithmetic as conv3x3_f16x3:
+//   x = hi + lo'/1024 (fp16 pair), hi*hi and hi*lo' + lo'*hi accumulated in two fp32
+//   accumulators on v_mfma_f32_16x16x32_f16, folded with 2^-10 in the epilogue.
+//
+// Block = 512 threads = 8 wavefronts stacked along M: BM = 256 rows (two 16-row MFMA tiles per
+// wave) x BN = 16*WN columns, K in chunks of 32 = (tap, 32 input channels).  fp32 activations
+// are split while they are staged (registers -> two fp16 LDS planes); weights are pre-split.
+// LDS rows are 64 bytes with the ((row>>2)&1)<<1 slot swizzle; operands of the NEXT chunk are
+// fetched into registers before the MFMA phase and written to the other buffer after it.
+#include "common.h"
+#include "gemm_common.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+using atmvfi::GemmDev;
+
+constexpr float LO_SCALE = 1024.0f;
+constexpr float LO_UNSCALE = 1.0f / 1024.0f;
+__device__ __forceinline__ _Float16 sat_half(float v) { return (_Float16)fminf(fmaxf(v, -65504.0f), 65504.0f); }
+__device__ __forceinline__ int swz64(int row) { return ((row >> 2) & 1) << 1; }
+
+__device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, f16x8& hi, f16x8& lo) {
+    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const _Float16 h = sat_half(x[e]);
+        hi[e] = h;
+        lo[e] = sat_half((x[e] - (float)h) * LO_SCALE);
+    }
+}
+
+template <int WN>
+__global__ __launch_bounds__(512) void gemm_f16x3_kernel(const GemmDev a) {
+    constexpr int BM = 256;
+    constexpr int BN = 16 * WN;
+    constexpr int BP = BN * 8;                       // 16-byte weight pieces per chunk (hi + lo planes)
+    constexpr int B_PPT = (BP + 511) / 512;
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
+    _Float16* a_hi = smem;                           // [2][BM][32]
+    _Float16* a_lo = a_hi + 2 * BM * 32;
+    _Float16* b_hi = a_lo + 2 * BM * 32;             // [2][BN][32]
+    _Float16* b_lo = b_hi + 2 * BN * 32;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int r = lane & 15;
+    const int g = lane >> 4;
+    const long long m0 = (long long)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+
+    // ---- A tasks: T = tid + 512*i -> (row = T>>2, 8-channel group q = T&3) ----
+    const int q = tid & 3;
+    const float* rbase[2];
+    int iy0[2], ix0[2], adst[2];
+    bool rok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (tid >> 2) + 128 * i;
+        const long long m = m0 + row;
+        rok[i] = m < a.M;
+        const long long mm = rok[i] ? m : 0;
+        if (a.mode == ATMVFI_GEMM_CONV) {
+            const int hw = a.Ho * a.Wo;
+            const int n = (int)(mm / hw);
+            const int rem = (int)(mm - (long long)n * hw);
+            const int oy = rem / a.Wo;
+            const int ox = rem - oy * a.Wo;
+            iy0[i] = oy * a.stride - a.pad;
+            ix0[i] = ox * a.stride - a.pad;
+            rbase[i] = a.in + (((long long)n * a.H + iy0[i]) * a.W + ix0[i]) * a.in_ld;
+        } else {
+            iy0[i] = 0;
+            ix0[i] = 0;
+            const long long off = (a.in_rpg > 0) ? (mm / a.in_rpg) * a.in_gstride + (mm % a.in_rpg) * (long long)a.in_ld
+                                                 : mm * (long long)a.in_ld;
+            rbase[i] = a.in + off;
+        }
+        adst[i] = row * 32 + ((q ^ swz64(row)) << 3);
+    }
+    // ---- weight pieces: P = tid + 512*k -> (plane, row, slot) ----
+    const _Float16* wsrc[B_PPT];
+    int wdst[B_PPT];
+    bool wok[B_PPT], wact[B_PPT], wlo[B_PPT];
+#pragma unroll
+    for (int k = 0; k < B_PPT; ++k) {
+        const int P = tid + 512 * k;
+        wact[k] = P < BP;
+        const int plane = (P >= BN * 4) ? 1 : 0;
+        const int rem = P - plane * BN * 4;
+        const int row = wact[k] ? (rem >> 2) : 0;
+        const int slot = rem & 3;
+        wlo[k] = plane == 1;
+        wok[k] = wact[k] && (n0 + row) < a.wrows;
+        wsrc[k] = (plane ? a.w_lo : a.w_hi) + (long long)(wok[k] ? n0 + row : 0) * a.ktot32 + slot * 8;
+        wdst[k] = row * 32 + ((slot ^ swz64(row)) << 3);
+    }
+
+    f32x4 acc[2][WN], cor[2][WN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            cor[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+
+    f32x4 ra[2][2];
+    f16x8 wr[B_PPT];
+
+    auto load_chunk = [&](int kc) {
+        const int tap = kc / a.cpt32;
+        const int c0 = (kc - tap * a.cpt32) * 32;
+        const int ky = tap / a.kw;
+        const int kx = tap - ky * a.kw;
+        const int dy = ky * a.dil, dx = kx * a.dil;
+        const int c = c0 + q * 8;
+        const long long toff = ((long long)dy * a.W + dx) * a.in_ld + c;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            bool ok = rok[i] && (c < a.Cin);
+            if (a.mode == ATMVFI_GEMM_CONV)
+                ok = ok && ((unsigned)(iy0[i] + dy) < (unsigned)a.H) && ((unsigned)(ix0[i] + dx) < (unsigned)a.W);
+            f32x4 va = (f32x4){0.f, 0.f, 0.f, 0.f}, vb = va;
+            if (ok) {
+                const float* p = rbase[i] + toff;
+                va = *reinterpret_cast<const f32x4*>(p);
+                if (c + 4 < a.Cin) vb = *reinterpret_cast<const f32x4*>(p + 4);
+                const int nv = a.Cin - c;
+                if (nv < 8) {
+                    if (nv < 2) va.y = 0.f;
+                    if (nv < 3) va.z = 0.f;
+                    if (nv < 4) va.w = 0.f;
+                    if (nv < 5) vb.x = 0.f;
+                    if (nv < 6) vb.y = 0.f;
+                    if (nv < 7) vb.z = 0.f;
+                    vb.w = 0.f;
+                }
+                if (a.in_prelu) {       // host pads in_prelu to a multiple of 32
+                    const f32x4 al = *reinterpret_cast<const f32x4*>(a.in_prelu + c);
+                    const f32x4 bl = *reinterpret_cast<const f32x4*>(a.in_prelu + c + 4);
+                    va.x = va.x > 0.f ? va.x : al.x * va.x;
+                    va.y = va.y > 0.f ? va.y : al.y * va.y;
+                    va.z = va.z > 0.f ? va.z : al.z * va.z;
+                    va.w = va.w > 0.f ? va.w : al.w * va.w;
+                    vb.x = vb.x > 0.f ? vb.x : bl.x * vb.x;
+                    vb.y = vb.y > 0.f ? vb.y : bl.y * vb.y;
+                    vb.z = vb.z > 0.f ? vb.z : bl.z * vb.z;
+                    vb.w = vb.w > 0.f ? vb.w : bl.w * vb.w;
+                }
+            }
+            ra[i][0] = va;
+            ra[i][1] = vb;
+        }
+        const long long koff = (long long)kc * 32;
+#pragma unroll
+        for (int k = 0; k < B_PPT; ++k) {
+            f16x8 v = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            if (wok[k]) v = *reinterpret_cast<const f16x8*>(wsrc[k] + koff);
+            wr[k] = v;
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            f16x8 hi, lo;
+            split8(ra[i][0], ra[i][1], hi, lo);
+            *reinterpret_cast<f16x8*>(a_hi + buf * BM * 32 + adst[i]) = hi;
+            *reinterpret_cast<f16x8*>(a_lo + buf * BM * 32 + adst[i]) = lo;
+        }
+#pragma unroll
+        for (int k = 0; k < B_PPT; ++k)
+            if (wact[k]) *reinterpret_cast<f16x8*>((wlo[k] ? b_lo : b_hi) + buf * BN * 32 + wdst[k]) = wr[k];
+    };
+
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    for (int kc = 0; kc < a.nchunks32; ++kc) {
+        const int buf = kc & 1;
+        if (kc + 1 < a.nchunks32) load_chunk(kc + 1);
+        f16x8 xh[2], xl[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = 32 * wave + 16 * i + r;
+            const int off = buf * BM * 32 + row * 32 + ((g ^ swz64(row)) << 3);
+            xh[i] = *reinterpret_cast<const f16x8*>(a_hi + off);
+            xl[i] = *reinterpret_cast<const f16x8*>(a_lo + off);
+        }
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int row = 16 * j + r;
+            const int off = buf * BN * 32 + row * 32 + ((g ^ swz64(row)) << 3);
+            const f16x8 wh = *reinterpret_cast<const f16x8*>(b_hi + off);
+            const f16x8 wl = *reinterpret_cast<const f16x8*>(b_lo + off);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                cor[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[i], cor[i][j], 0, 0, 0);
+                cor[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[i], cor[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[i], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (kc + 1 < a.nchunks32) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const long long m = m0 + 32 * wave + 16 * i + r;
+        float* orow;
+        const float* rrow;
+        if (m >= a.M || !atmvfi::gemm_out_row(a, m, orow, rrow)) continue;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const f32x4 v = acc[i][j], c2 = cor[i][j];
+            atmvfi::gemm_store4(a, orow, rrow, n0 + 16 * j + 4 * g, v.x + c2.x * LO_UNSCALE, v.y + c2.y * LO_UNSCALE,
+                                v.z + c2.z * LO_UNSCALE, v.w + c2.w * LO_UNSCALE);
+        }
+    }
+}
+
+template <int WN>
+int launch(const GemmDev& d, int ntiles, hipStream_t s) {
+    constexpr int BN = 16 * WN;
+    const size_t lds = (size_t)(4 * 256 * 32 + 4 * BN * 32) * sizeof(_Float16);
+    auto kern = gemm_f16x3_kernel<WN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        ATMVFI_REQUIRE(e == hipSuccess, ATMVFI_ELAUNCH, "gemm_f16x3: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    dim3 grid((unsigned)atmvfi::ceil_div64(d.M, 256), (unsigned)((ntiles + WN - 1) / WN));
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, d);
+    return atmvfi::check_launch("gemm_f16x3");
+}
+
+}  // namespace
+
+int atmvfi::launch_gemm_f16x3(const GemmDev& d, int ngemm, hipStream_t s) {
+    const int ntiles = (ngemm + 15) / 16;
+    int best = 1;
+    float best_cost = 1e30f;
+    for (int wn = 1; wn <= 8; ++wn) {
+        const int padded = (ntiles + wn - 1) / wn * wn;
+        const float cost = (float)padded * (1.0f + 1.0f / (float)wn);
+        if (cost <= best_cost) { best_cost = cost; best = wn; }
+    }
+    switch (best) {
+        case 1: return launch<1>(d, ntiles, s);
+        case 2: return launch<2>(d, ntiles, s);
+        case 3: return launch<3>(d, ntiles, s);
+        case 4: return launch<4>(d, ntiles, s);
+        case 5: return launch<5>(d, ntiles, s);
+        case 6: return launch<6>(d, ntiles, s);
+        case 7: return launch<7>(d, ntiles, s);
+        default: return launch<8>(d, ntiles, s);
+    }
+}

@@ -49,6 +49,7 @@ class GemmParams(ctypes.Structure):
         ("out_row_map", c_f),
         ("bias", c_f), ("prelu", c_f), ("in_prelu", c_f), ("residual", c_f),
         ("res_ld", ctypes.c_int32),
+        ("precision", ctypes.c_int32), ("weight_hi", c_f), ("weight_lo", c_f),
     ]
 
 
@@ -62,8 +63,8 @@ SIGNATURES = {
     "atmvfi_deconv2x2": (c_i, [ctypes.POINTER(GemmParams), c_f]),
     "atmvfi_packed_weight_floats": (c_l, [c_i, c_i, c_i, c_i, c_i]),
     "atmvfi_pack_weight": (c_i, [c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
-    "atmvfi_split_weight_halves": (c_l, [c_i, c_i, c_i, c_i]),
-    "atmvfi_pack_weight_split": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
+    "atmvfi_split_weight_halves": (c_l, [c_i, c_i, c_i, c_i, c_i]),
+    "atmvfi_pack_weight_split": (c_i, [c_i, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     "atmvfi_conv3x3_f16x3": (c_i, [c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_i, c_f, c_f, c_f]),
     "atmvfi_layernorm": (c_i, [c_f, c_i, c_l, c_i, c_f, c_f, c_i, c_f, c_f, c_l, c_i, c_f]),
     "atmvfi_dwconv3x3_gelu": (c_i, [c_f, c_i, c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
@@ -214,11 +215,11 @@ class HipOps:
         dst = self.empty(n)
         self._check(self.lib.atmvfi_pack_weight(mode, _ptr(w), _ptr(dst), cout, cin, kh, kw, self._stream()), "pack_weight")
         pw = PackedWeight(mode, cout, cin, kh, kw, w, dst)
-        if mode == GEMM_CONV and kh == 3 and kw == 3 and cin >= 16:
-            nh = self.lib.atmvfi_split_weight_halves(cout, cin, kh, kw)
+        if cin >= 16:       # split-precision planes for the f16x3 engines (tiny-K layers stay on the fp32 MFMA)
+            nh = self.lib.atmvfi_split_weight_halves(mode, cout, cin, kh, kw)
             pw.hi = torch.empty(nh, dtype=torch.float16, device=self.device)
             pw.lo = torch.empty(nh, dtype=torch.float16, device=self.device)
-            self._check(self.lib.atmvfi_pack_weight_split(_ptr(w), _ptr(pw.hi), _ptr(pw.lo), cout, cin, kh, kw, self._stream()),
+            self._check(self.lib.atmvfi_pack_weight_split(mode, _ptr(w), _ptr(pw.hi), _ptr(pw.lo), cout, cin, kh, kw, self._stream()),
                         "pack_weight_split")
         return pw
 
@@ -230,7 +231,13 @@ class HipOps:
         self._check(self.lib.atmvfi_pack_dw_weight(_ptr(w), _ptr(dst), c, self._stream()), "pack_dw_weight")
         return dst
 
-    def pad_channels(self, v: torch.Tensor, mult: int = 16) -> torch.Tensor:
+    def _prec(self, w: PackedWeight):
+        """(precision, hi, lo) fields of GemmParams for this weight under the current precision mode."""
+        if self.precision == "f16x3" and w.hi is not None:
+            return 1, w.hi.data_ptr(), w.lo.data_ptr()
+        return 0, None, None
+
+    def pad_channels(self, v: torch.Tensor, mult: int = 32) -> torch.Tensor:
         """Per-channel vector padded with zeros to a multiple of ``mult`` (in_prelu contract)."""
         c = v.shape[0]
         out = torch.zeros((c + mult - 1) // mult * mult, dtype=torch.float32, device=self.device)
@@ -255,7 +262,8 @@ class HipOps:
                        weight=w.packed.data_ptr(), Cout=cout, kh=w.kh, kw=w.kw, stride=stride, pad=pad, dil=dil,
                        Ho=oh, Wo=ow, M=n * oh * ow, out=out.data_ptr(), out_ld=old, out_gstride=0, out_rpg=0,
                        out_row_map=None, bias=_ptr(bias), prelu=_ptr(prelu), in_prelu=_ptr(in_prelu), residual=None, res_ld=0)
-        self._run("conv2d", meta, self.lib.atmvfi_conv2d, ctypes.byref(p), self._stream())
+        p.precision, p.weight_hi, p.weight_lo = self._prec(w)
+        self._run("conv2d_f16x3" if p.precision else "conv2d", meta, self.lib.atmvfi_conv2d, ctypes.byref(p), self._stream())
 
     def deconv(self, x, w: PackedWeight, out, bias=None, prelu=None, in_prelu=None):
         ld, n, h, wd, cin = nhwc_view(x, "deconv.in")
@@ -266,9 +274,10 @@ class HipOps:
                        weight=w.packed.data_ptr(), Cout=cout, kh=2, kw=2, stride=2, pad=0, dil=1, Ho=oh, Wo=ow,
                        M=n * h * wd, out=out.data_ptr(), out_ld=old, out_gstride=0, out_rpg=0, out_row_map=None,
                        bias=_ptr(bias), prelu=_ptr(prelu), in_prelu=_ptr(in_prelu), residual=None, res_ld=0)
+        p.precision, p.weight_hi, p.weight_lo = self._prec(w)
         meta = {"flops": 2.0 * n * h * wd * 4 * cout * cin, "bytes": 4.0 * (n * h * wd * cin + n * oh * ow * cout + 4 * cout * cin),
                 "shape": f"M{n * h * wd} N{4 * cout} K{cin}"}
-        self._run("deconv2x2", meta, self.lib.atmvfi_deconv2x2, ctypes.byref(p), self._stream())
+        self._run("deconv2x2_f16x3" if p.precision else "deconv2x2", meta, self.lib.atmvfi_deconv2x2, ctypes.byref(p), self._stream())
 
     def linear(self, x, w: PackedWeight, out, bias=None, residual=None, out_row_map=None):
         ld, m, cin, gs, rpg = rows_view(x, "linear.in")
@@ -288,8 +297,9 @@ class HipOps:
                        weight=w.packed.data_ptr(), Cout=cout, kh=1, kw=1, stride=1, pad=0, dil=1, Ho=1, Wo=1, M=m,
                        out=out.data_ptr(), out_ld=old, out_gstride=ogs, out_rpg=orpg, out_row_map=_ptr(out_row_map),
                        bias=_ptr(bias), prelu=None, in_prelu=None, residual=_ptr(residual), res_ld=res_ld)
+        p.precision, p.weight_hi, p.weight_lo = self._prec(w)
         meta = {"flops": 2.0 * m * cout * cin, "bytes": 4.0 * (m * cin + m * cout + cout * cin), "shape": f"M{m} N{cout} K{cin}"}
-        self._run("linear", meta, self.lib.atmvfi_linear, ctypes.byref(p), self._stream())
+        self._run("linear_f16x3" if p.precision else "linear", meta, self.lib.atmvfi_linear, ctypes.byref(p), self._stream())
 
     # ------------------------------------------------------------- transformer
     def layernorm(self, x, out, gamma, beta, src_row_map=None):

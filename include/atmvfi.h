@@ -78,7 +78,16 @@ typedef struct atmvfi_gemm_params {
     const float* in_prelu;        /* [Cin]  or NULL */
     const float* residual;        /* optional, indexed by GEMM row m (before out_row_map) */
     int32_t res_ld;
+    /* ATMVFI_PREC_F32: exact fp32 MFMA on `weight`.  ATMVFI_PREC_F16X3: split-precision engine
+       (x = hi + lo'/1024 in fp16, three 16-bit MFMAs per product, fp32 accumulate) on the two
+       fp16 planes written by atmvfi_pack_weight_split; in_prelu must then be padded to 32. */
+    int32_t precision;
+    const void* weight_hi;
+    const void* weight_lo;
 } atmvfi_gemm_params;
+
+#define ATMVFI_PREC_F32   0
+#define ATMVFI_PREC_F16X3 1
 
 int atmvfi_gemm(const atmvfi_gemm_params* p, void* stream);
 
@@ -105,9 +114,9 @@ int atmvfi_pack_weight(int mode, const float* src, float* dst, int Cout, int Cin
  * atmvfi_pack_weight_split into two fp16 planes [rows16(Cout)][kh*kw][CinPad32]
  * (atmvfi_split_weight_halves() halves each).  Epilogue: + bias[co]; PReLU(slope[co]).
  * ---------------------------------------------------------------------------------- */
-int64_t atmvfi_split_weight_halves(int Cout, int Cin, int kh, int kw);
-int atmvfi_pack_weight_split(const float* src /*OIHW*/, void* dst_hi, void* dst_lo, int Cout, int Cin, int kh, int kw,
-                             void* stream);
+int64_t atmvfi_split_weight_halves(int mode, int Cout, int Cin, int kh, int kw);
+int atmvfi_pack_weight_split(int mode, const float* src, void* dst_hi, void* dst_lo, int Cout, int Cin, int kh, int kw,
+                             void* stream);   /* same source layouts and row order as atmvfi_pack_weight, CinPad32 */
 int atmvfi_conv3x3_f16x3(const float* in, int in_ld, int N, int H, int W, int Cin, const void* w_hi, const void* w_lo,
                          int Cout, float* out, int out_ld, const float* bias, const float* prelu, void* stream);
 

@@ -47,7 +47,7 @@ class CpuOps:
     def pack_dw_weight(self, w):
         return w.detach()
 
-    def pad_channels(self, v, mult=16):
+    def pad_channels(self, v, mult=32):
         c = v.shape[0]
         out = torch.zeros((c + mult - 1) // mult * mult)
         out[:c] = v.detach()

@@ -399,3 +399,30 @@ def test_atm_block_reference_fixture(shift, hip, dev):
     assert np.abs(y - gold["y"]).max() <= 2e-4
     mo = mdst.reshape(4, 1024, 2).cpu().numpy()
     assert np.abs(mo - gold["motion"]).max() <= 2e-4
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_gemm_modes_both_precisions(precision, hip, cpu, dev):
+    """LINEAR (groups + scatter + residual), DECONV (in_prelu) and strided/dilated CONV on both engines."""
+    hip.precision = precision
+    try:
+        test_linear_groups_scatter_residual(hip, cpu, dev)
+        for case in DECONV_CASES:
+            test_deconv2x2(case, hip, cpu, dev)
+        g = torch.Generator().manual_seed(99)
+        for (cin, cout, k, stride, pad, dil, H, W) in ((96, 192, 3, 2, 1, 1, 18, 26), (48, 48, 3, 4, 2, 2, 24, 40),
+                                                      (768, 5, 1, 1, 0, 1, 9, 7), (37 * 4, 21, 3, 2, 1, 1, 11, 13)):
+            x = rnd(g, 2, H, W, cin)
+            w = rnd(g, cout, cin, k, k, scale=1.0 / np.sqrt(cin * k * k))
+            b = rnd(g, cout, scale=0.2)
+            Ho = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
+            Wo = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+            r4 = (cout + 3) // 4 * 4
+            oc = torch.full((2, Ho, Wo, r4), 7.0)
+            og = torch.full((2, Ho, Wo, r4), 7.0, device=dev)
+            cpu.conv(x, cpu.pack_weight(GEMM_CONV, w), oc[..., :cout], stride, pad, dil, b, None)
+            hip.conv(x.to(dev), hip.pack_weight(GEMM_CONV, w.to(dev)), og[..., :cout], stride, pad, dil, b.to(dev), None)
+            torch.cuda.synchronize()
+            assert maxdiff(og, oc) <= 1e-4
+    finally:
+        hip.precision = "f16x3"
