@@ -40,6 +40,7 @@ FLOPS_PER_PAIR = {  # SURVEY.md section 8d, algorithmic FLOPs per frame pair (2 
     ("lite", 256, 256, True): 56.2e9,
 }
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, dense fp32 matrix peak
+PEAK_F16_MFMA_TFLOPS = 2500.0  # dense fp16/bf16 matrix peak (no sparsity)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -54,6 +55,7 @@ def parse():
     ap.add_argument("--global-off", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f32"])
     return ap.parse_args()
 
 
@@ -103,6 +105,8 @@ def main():
             dist.all_gather(gathered, out)      # per-rank output frames only
         return out
 
+    net(*frames[0])                      # builds the op backend
+    net._ops_obj.precision = args.precision
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
@@ -132,7 +136,8 @@ def main():
             else f"interpolated frames/s ({variant} {args.height}x{args.width})",
             "value": round(fps, 4), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32 (contractions as fp16 hi/lo split x3 MFMA, fp32 accumulate; ~22 significand bits)" if getattr(net._ops_obj, "precision", "") == "f16x3" else "f32",
+            "data": "synthetic",
             "config": {"workload": f"network_{variant} {args.height}x{args.width} (padded {H}x{W}) bs=1 per GPU, "
                                    f"global {'on' if net.global_motion else 'off'}, fp32, random frame pairs, stress weights seed 1",
                        "pairs_per_step": world, "parallelism": f"frame-batch dp{world} + all-gather" if world > 1 else "single GPU"},
@@ -140,6 +145,7 @@ def main():
         if flops:
             result["forward_tflops"] = round(flops * fps / world / 1e12, 2)     # per-GPU algorithmic rate of the whole forward
             result["forward_frac_of_f32_mfma_peak"] = round(flops * fps / world / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
+            result["forward_frac_of_f16x3_peak"] = round(flops * fps / world / 1e12 / (PEAK_F16_MFMA_TFLOPS / 3.0), 4)
         # ---- instrumented pass: per-launch HIP events on the launch stream ----
         if not args.no_profile:
             ops = net._ops_obj
@@ -156,20 +162,30 @@ def main():
                 d["launches"] += 1
                 d["flops"] += meta.get("flops", 0.0)
                 d["bytes"] += meta.get("bytes", 0.0)
-            gemm = {"ms": 0.0, "launches": 0, "flops": 0.0}
-            for k in ("conv2d", "linear", "deconv2x2"):
-                if k in agg:
-                    for f in gemm:
-                        gemm[f] += agg[k][f]
             total_ms = sum(d["ms"] for d in agg.values())
-            if gemm["ms"] > 0:
-                ach = gemm["flops"] / (gemm["ms"] * 1e-3) / 1e12
-                result["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                      "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                                      "kernel": "gemm_mfma_f32 (conv2d + linear + deconv2x2)",
-                                      "launches": gemm["launches"], "avg_launch_ms": round(gemm["ms"] / gemm["launches"], 4),
-                                      "algorithmic_gflop_per_forward": round(gemm["flops"] / 1e9, 1),
-                                      "share_of_forward_time": round(gemm["ms"] / total_ms, 4)}
+            # kernel families and the MFMA peak that bounds them: the f16x3 engines issue three
+            # 16-bit MFMAs per algorithmic multiply-add, so their algorithmic peak is 2500/3 TFLOP/s.
+            families = {
+                "conv3x3_f16x3_kernel": (["conv3x3_f16x3"], PEAK_F16_MFMA_TFLOPS / 3.0),
+                "gemm_f16x3_kernel (linear + deconv2x2 + strided conv2d)": (["linear_f16x3", "deconv2x2_f16x3", "conv2d_f16x3"], PEAK_F16_MFMA_TFLOPS / 3.0),
+                "gemm_mfma_f32 (exact-fp32 engine)": (["conv2d", "linear", "deconv2x2"], PEAK_F32_MFMA_TFLOPS),
+            }
+            fam_out = {}
+            for fam, (names, peak) in families.items():
+                ms = sum(agg[n]["ms"] for n in names if n in agg)
+                if ms <= 0:
+                    continue
+                fl = sum(agg[n]["flops"] for n in names if n in agg)
+                nl = sum(agg[n]["launches"] for n in names if n in agg)
+                ach = fl / (ms * 1e-3) / 1e12
+                fam_out[fam] = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                                "frac": round(ach / peak, 4), "traffic": None, "kernel": fam, "launches": nl,
+                                "avg_launch_ms": round(ms / nl, 4), "algorithmic_gflop_per_forward": round(fl / 1e9, 1),
+                                "share_of_forward_time": round(ms / total_ms, 4)}
+            if fam_out:
+                dom = max(fam_out.values(), key=lambda d: d["share_of_forward_time"])
+                result["roofline"] = dom
+                result["roofline_all_families"] = fam_out
             result["kernels"] = {k: {"ms": round(d["ms"], 3), "launches": d["launches"],
                                      **({"tflops": round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 2)} if d["flops"] and d["ms"] > 0 else {}),
                                      **({"gbs": round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1)} if d["bytes"] and d["ms"] > 0 else {})}
