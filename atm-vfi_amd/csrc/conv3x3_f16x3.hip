@@ -22,48 +22,11 @@
 // registers before the MFMA phase and written to the other LDS buffer after it.
 #include "common.h"
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+#include "conv3_common.h"
+
+#include <stdlib.h>
 
 namespace {
-
-struct Conv3Dev {
-    const float* in;
-    int in_ld, N, H, W, Cin;
-    const _Float16* w_hi;
-    const _Float16* w_lo;
-    int wrows;      // packed weight rows (multiple of 16)
-    int cin_pad;    // Cin rounded up to 32
-    int Cout;
-    float* out;
-    int out_ld;
-    const float* bias;
-    const float* prelu;
-    int tiles_x, tiles_y;
-};
-
-constexpr int TW = 16, TH = 16, HW_ = TW + 2, HH_ = TH + 2, NPIX = HW_ * HH_;   // 18 x 18 = 324 halo pixels
-constexpr int HALO_TASKS = NPIX * 4;                                            // (pixel, 8-channel group)
-constexpr int HALO_TPT = (HALO_TASKS + 511) / 512;                              // 3 tasks per thread
-
-__device__ __forceinline__ int swz64(int row) { return ((row >> 2) & 1) << 1; }
-
-// x = hi + lo'/1024 with hi = fp16(x) and lo' = fp16((x - hi) * 1024): scaling keeps lo' a NORMAL fp16
-// whenever hi is (|lo'| <= |x|), so the pair carries ~22 significand bits at any magnitude down to
-// fp16's normal range.  Both conversions clamp to +-65504 first, so finite fp32 never becomes inf.
-constexpr float LO_SCALE = 1024.0f;
-constexpr float LO_UNSCALE = 1.0f / 1024.0f;
-__device__ __forceinline__ _Float16 sat_half(float v) { return (_Float16)fminf(fmaxf(v, -65504.0f), 65504.0f); }
-
-__device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, f16x8& hi, f16x8& lo) {
-    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const _Float16 h = sat_half(x[e]);
-        hi[e] = h;
-        lo[e] = sat_half((x[e] - (float)h) * LO_SCALE);
-    }
-}
 
 template <int WN>
 __global__ __launch_bounds__(512) void conv3x3_f16x3_kernel(const Conv3Dev a) {
@@ -144,33 +107,37 @@ __global__ __launch_bounds__(512) void conv3x3_f16x3_kernel(const Conv3Dev a) {
     // requested at tap 0 and converted/written at tap HALO_WRITE_TAP.
     constexpr int HALO_WRITE_TAP = 5;
     f32x4 hr[HALO_TPT][2];
+    int hnv[HALO_TPT];
     f16x8 wrA[B_PPT], wrB[B_PPT];
 
     auto halo_load = [&](int k, int chunk) {        // k is a compile-time constant at every call site
+        // Unconditional loads from a clamped, always-valid address, zeroed afterwards by selects: a
+        // predicated load makes hipcc branch around it and wait vmcnt(0) on the spot, which serialises
+        // the whole prefetch (seen in the ISA; cdna_hip_programming.md "Three .s-level traps" (c)).
         const int c = chunk * 32 + hq[k] * 8;
-        f32x4 va = (f32x4){0.f, 0.f, 0.f, 0.f}, vb = va;
-        if (hok[k] && c < a.Cin) {
-            const float* p = hsrc[k] + chunk * 32;
-            va = *reinterpret_cast<const f32x4*>(p);
-            if (c + 4 < a.Cin) vb = *reinterpret_cast<const f32x4*>(p + 4);
-            const int nv = a.Cin - c;          // valid channels in this group of 8 (>= 1)
-            if (nv < 8) {
-                if (nv < 2) va.y = 0.f;
-                if (nv < 3) va.z = 0.f;
-                if (nv < 4) va.w = 0.f;
-                if (nv < 5) vb.x = 0.f;
-                if (nv < 6) vb.y = 0.f;
-                if (nv < 7) vb.z = 0.f;
-                vb.w = 0.f;
-            }
-        }
+        const bool ok = hok[k] && c < a.Cin;
+        const int nv = ok ? a.Cin - c : 0;                       // valid channels in this group of 8
+        const float* p = ok ? hsrc[k] + chunk * 32 : a.in;       // masked lanes read the tensor base: hsrc[k] + q*8 may lie past a narrow last pixel
+        const f32x4 va = *reinterpret_cast<const f32x4*>(p);
+        const f32x4 vb = *reinterpret_cast<const f32x4*>(p + (nv > 4 ? 4 : 0));
+        hnv[k] = nv;                                             // masking happens at store time: no early consumer
         hr[k][0] = va;
         hr[k][1] = vb;
     };
     auto halo_store = [&](int k, int buf) {
         if (hact[k]) {
             f16x8 hi, lo;
-            split8(hr[k][0], hr[k][1], hi, lo);
+            f32x4 va = hr[k][0], vb = hr[k][1];
+            const int nv = hnv[k];
+            va.x = nv > 0 ? va.x : 0.f;
+            va.y = nv > 1 ? va.y : 0.f;
+            va.z = nv > 2 ? va.z : 0.f;
+            va.w = nv > 3 ? va.w : 0.f;
+            vb.x = nv > 4 ? vb.x : 0.f;
+            vb.y = nv > 5 ? vb.y : 0.f;
+            vb.z = nv > 6 ? vb.z : 0.f;
+            vb.w = nv > 7 ? vb.w : 0.f;
+            split8(va, vb, hi, lo);
             *reinterpret_cast<f16x8*>(halo_hi + buf * NPIX * 32 + hdst[k]) = hi;
             *reinterpret_cast<f16x8*>(halo_lo + buf * NPIX * 32 + hdst[k]) = lo;
         }
@@ -181,15 +148,15 @@ __global__ __launch_bounds__(512) void conv3x3_f16x3_kernel(const Conv3Dev a) {
         const long long koff = (long long)tap * a.cin_pad + chunk * 32;
 #pragma unroll
         for (int k = 0; k < B_PPT; ++k) {
-            f16x8 v = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
-            if (wok[k]) v = *reinterpret_cast<const f16x8*>(wsrc[k] + koff);
-            dst[k] = v;
+            dst[k] = *reinterpret_cast<const f16x8*>(wsrc[k] + koff);        // row-clamped address: always valid; masked at store
         }
     };
     auto w_store = [&](int buf, const f16x8 (&src)[B_PPT]) {
 #pragma unroll
         for (int k = 0; k < B_PPT; ++k)
-            if (wact[k]) *reinterpret_cast<f16x8*>((wlo[k] ? b_lo : b_hi) + buf * BN * 32 + wdst[k]) = src[k];
+            if (wact[k])
+                *reinterpret_cast<f16x8*>((wlo[k] ? b_lo : b_hi) + buf * BN * 32 + wdst[k]) =
+                    wok[k] ? src[k] : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
     };
     // one (chunk, tap) stage: `nxt` holds the weights of stage s+1 (written to LDS after the MFMAs),
     // `far` receives the weights of stage s+2.
@@ -218,12 +185,13 @@ __global__ __launch_bounds__(512) void conv3x3_f16x3_kernel(const Conv3Dev a) {
             const int off = wb * BN * 32 + row * 32 + ((g ^ swz64(row)) << 3);
             const f16x8 wh = *reinterpret_cast<const f16x8*>(b_hi + off);
             const f16x8 wl = *reinterpret_cast<const f16x8*>(b_lo + off);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                cor[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[i], cor[i][j], 0, 0, 0);
-                cor[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[i], cor[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[i], acc[i][j], 0, 0, 0);
-            }
+                // dependent MFMAs (same accumulator) are kept 4 issues apart: back-to-back they stall the pipe
+                cor[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[0], cor[0][j], 0, 0, 0);
+                cor[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[1], cor[1][j], 0, 0, 0);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[0], acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[1], acc[1][j], 0, 0, 0);
+                cor[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[0], cor[0][j], 0, 0, 0);
+                cor[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[1], cor[1][j], 0, 0, 0);
         }
         if (s + 1 < nstages) w_store(wb ^ 1, nxt);
         if (more_h && tap == HALO_WRITE_TAP) {
@@ -364,6 +332,10 @@ extern "C" int atmvfi_conv3x3_f16x3(const float* in, int in_ld, int N, int H, in
     d.tiles_y = (H + TH - 1) / TH;
     ATMVFI_REQUIRE((long long)N * d.tiles_x * d.tiles_y < (1ll << 31), ATMVFI_EINVAL, "conv3x3_f16x3: grid too large");
     const int ntiles = (Cout + 15) / 16;
+    hipStream_t s = (hipStream_t)stream;
+    // default schedule: one kernel row (3 taps) per stage; ATMVFI_CONV3_ONE_TAP=1 selects the one-tap schedule (A/B runs)
+    static const bool one_tap = getenv("ATMVFI_CONV3_ONE_TAP") != nullptr;
+    if (!one_tap) return atmvfi::launch_conv3x3_row(d, ntiles, s);
     int best = 1;
     float best_cost = 1e30f;
     for (int wn = 1; wn <= 8; ++wn) {
@@ -371,7 +343,6 @@ extern "C" int atmvfi_conv3x3_f16x3(const float* in, int in_ld, int N, int H, in
         const float cost = (float)padded * (1.0f + 1.0f / (float)wn);
         if (cost <= best_cost) { best_cost = cost; best = wn; }
     }
-    hipStream_t s = (hipStream_t)stream;
     switch (best) {
         case 1: return launch3<1>(d, ntiles, s);
         case 2: return launch3<2>(d, ntiles, s);

@@ -1,0 +1,274 @@
+// 3x3 / stride 1 / pad 1 split-precision convolution, "row-stage" schedule (gfx950).
+//
+// Same tile, arithmetic and LDS images as conv3x3_f16x3.hip (16x16 output pixels x 16*WN channels,
+// 512 threads, x = hi + lo'/1024 in fp16, three v_mfma_f32_16x16x32_f16 per product into two fp32
+// accumulators), but ONE STAGE = ONE KERNEL ROW: the weights of the three taps (ky, 0..2) of a
+// 32-channel chunk sit in one LDS buffer and are consumed between two barriers, so a chunk costs
+// 3 stage barriers + 1 halo barrier instead of 9, and every barrier interval carries 3x the MFMA
+// work (measured on the one-tap schedule: ~3 000 cycles per stage against 1 344 of MFMA issue; the
+// LDS-read, MFMA and LDS-write phases of the 8 lock-stepped waves do not overlap, so the fixed
+// part is what has to be amortised).  The halo is single-buffered to make room for the 3-tap
+// weight buffers: the next chunk's halo is requested at the start of the chunk's last stage,
+// converted and written after that stage's barrier, and published by one extra barrier.
+// Weight fragments are read one n-tile ahead of the MFMAs that consume them.
+#include "conv3_common.h"
+
+namespace {
+
+template <int WN>
+__global__ __launch_bounds__(512) void conv3x3_f16x3_row_kernel(const Conv3Dev a) {
+    constexpr int BN = 16 * WN;
+    constexpr int BP = 3 * BN * 8;                  // 16-byte weight pieces per stage: 3 taps x (hi + lo) planes
+    constexpr int B_PPT = (BP + 511) / 512;
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
+    _Float16* halo_hi = smem;                           // [NPIX][32]
+    _Float16* halo_lo = halo_hi + NPIX * 32;
+    _Float16* b_hi = halo_lo + NPIX * 32;               // [2][3][BN][32]
+    _Float16* b_lo = b_hi + 2 * 3 * BN * 32;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int r = lane & 15;
+    const int g = lane >> 4;
+
+    int bid = blockIdx.x;
+    const int txb = bid % a.tiles_x;
+    bid /= a.tiles_x;
+    const int tyb = bid % a.tiles_y;
+    const int img = bid / a.tiles_y;
+    const int ox0 = txb * TW, oy0 = tyb * TH;
+    const int n0 = blockIdx.y * BN;
+
+    // ---- halo tasks: T = tid + 512*k -> (halo pixel, 8-channel group) ----
+    const float* hsrc[HALO_TPT];
+    int hdst[HALO_TPT], hq[HALO_TPT];
+    bool hok[HALO_TPT], hact[HALO_TPT];
+#pragma unroll
+    for (int k = 0; k < HALO_TPT; ++k) {
+        const int T = tid + 512 * k;
+        hact[k] = T < HALO_TASKS;
+        const int hp = hact[k] ? (T >> 2) : 0;
+        const int q = T & 3;
+        const int hy = hp / HW_, hx = hp - hy * HW_;
+        const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+        hok[k] = hact[k] && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        hsrc[k] = a.in + (((long long)img * a.H + (hok[k] ? iy : 0)) * a.W + (hok[k] ? ix : 0)) * a.in_ld + q * 8;
+        hdst[k] = hp * 32 + ((q ^ swz64(hp)) << 3);
+        hq[k] = q;
+    }
+    // ---- weight pieces: P = tid + 512*k -> (plane, tap-in-row t, row, slot) ----
+    const _Float16* wsrc[B_PPT];
+    int wdst[B_PPT];
+    bool wok[B_PPT], wact[B_PPT], wlo[B_PPT];
+    const long long ktot = 9ll * a.cin_pad;
+#pragma unroll
+    for (int k = 0; k < B_PPT; ++k) {
+        const int P = tid + 512 * k;
+        wact[k] = P < BP;
+        const int plane = (P >= 3 * BN * 4) ? 1 : 0;
+        int rem = P - plane * 3 * BN * 4;
+        const int t = wact[k] ? rem / (BN * 4) : 0;
+        rem -= t * BN * 4;
+        const int row = wact[k] ? (rem >> 2) : 0;
+        const int slot = rem & 3;
+        wlo[k] = plane == 1;
+        wok[k] = wact[k] && (n0 + row) < a.wrows;
+        wsrc[k] = (plane ? a.w_lo : a.w_hi) + (long long)(wok[k] ? n0 + row : 0) * ktot + (long long)t * a.cin_pad + slot * 8;
+        wdst[k] = (t * BN + row) * 32 + ((slot ^ swz64(row)) << 3);
+    }
+
+    f32x4 acc[2][WN], cor[2][WN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            cor[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+
+    const int nchunks = a.cin_pad >> 5;
+    const int nstages = nchunks * 3;
+
+    f32x4 hr[HALO_TPT][2];
+    int hnv[HALO_TPT];
+    f16x8 wr[B_PPT];
+
+    auto halo_load = [&](int k, int chunk) {
+        // Unconditional loads from a clamped, always-valid address, zeroed afterwards by selects: a
+        // predicated load makes hipcc branch around it and wait vmcnt(0) on the spot, which serialises
+        // the whole prefetch (seen in the ISA; cdna_hip_programming.md "Three .s-level traps" (c)).
+        const int c = chunk * 32 + hq[k] * 8;
+        const bool ok = hok[k] && c < a.Cin;
+        const int nv = ok ? a.Cin - c : 0;                       // valid channels in this group of 8
+        const float* p = ok ? hsrc[k] + chunk * 32 : a.in;       // masked lanes read the tensor base: hsrc[k] + q*8 may lie past a narrow last pixel
+        const f32x4 va = *reinterpret_cast<const f32x4*>(p);
+        const f32x4 vb = *reinterpret_cast<const f32x4*>(p + (nv > 4 ? 4 : 0));
+        hnv[k] = nv;                                             // masking happens at store time: no early consumer
+        hr[k][0] = va;
+        hr[k][1] = vb;
+    };
+    auto halo_store = [&](int k) {
+        if (hact[k]) {
+            f16x8 hi, lo;
+            f32x4 va = hr[k][0], vb = hr[k][1];
+            const int nv = hnv[k];
+            va.x = nv > 0 ? va.x : 0.f;
+            va.y = nv > 1 ? va.y : 0.f;
+            va.z = nv > 2 ? va.z : 0.f;
+            va.w = nv > 3 ? va.w : 0.f;
+            vb.x = nv > 4 ? vb.x : 0.f;
+            vb.y = nv > 5 ? vb.y : 0.f;
+            vb.z = nv > 6 ? vb.z : 0.f;
+            vb.w = nv > 7 ? vb.w : 0.f;
+            split8(va, vb, hi, lo);
+            *reinterpret_cast<f16x8*>(halo_hi + hdst[k]) = hi;
+            *reinterpret_cast<f16x8*>(halo_lo + hdst[k]) = lo;
+        }
+    };
+    auto w_load = [&](int stage) {
+        const int chunk = stage / 3;
+        const int ky = stage - chunk * 3;
+        const long long koff = (long long)(ky * 3) * a.cin_pad + chunk * 32;
+#pragma unroll
+        for (int k = 0; k < B_PPT; ++k) {
+            wr[k] = *reinterpret_cast<const f16x8*>(wsrc[k] + koff);         // row-clamped address: always valid; masked at store
+        }
+    };
+    auto w_store = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < B_PPT; ++k)
+            if (wact[k])
+                *reinterpret_cast<f16x8*>((wlo[k] ? b_lo : b_hi) + buf * 3 * BN * 32 + wdst[k]) =
+                    wok[k] ? wr[k] : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    };
+
+    // ---- prologue ----
+#pragma unroll
+    for (int k = 0; k < HALO_TPT; ++k) halo_load(k, 0);
+    w_load(0);
+#pragma unroll
+    for (int k = 0; k < HALO_TPT; ++k) halo_store(k);
+    w_store(0);
+    __syncthreads();
+
+    for (int s = 0; s < nstages; ++s) {
+        const int chunk = s / 3;
+        const int ky = s - chunk * 3;
+        const int wb = s & 1;
+        const bool more_w = (s + 1) < nstages;
+        const bool next_halo = (ky == 2) && (chunk + 1 < nchunks);
+        if (more_w) w_load(s + 1);
+        if (next_halo) {
+#pragma unroll
+            for (int k = 0; k < HALO_TPT; ++k) halo_load(k, chunk + 1);
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            f16x8 xh[2], xl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int p = (2 * wave + i + ky) * HW_ + t + r;
+                const int off = p * 32 + ((g ^ swz64(p)) << 3);
+                xh[i] = *reinterpret_cast<const f16x8*>(halo_hi + off);
+                xl[i] = *reinterpret_cast<const f16x8*>(halo_lo + off);
+            }
+            const int wbase = (wb * 3 + t) * BN * 32 + r * 32 + ((g ^ swz64(r)) << 3);     // swz64(16j + r) == swz64(r)
+            // weight fragments ping-pong between two statically indexed register sets (j is a compile-time
+            // constant after unrolling): the next n-tile is fetched before this tile's MFMAs, without copies
+            f16x8 wh[2], wl[2];
+            wh[0] = *reinterpret_cast<const f16x8*>(b_hi + wbase);
+            wl[0] = *reinterpret_cast<const f16x8*>(b_lo + wbase);
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                if (j + 1 < WN) {
+                    wh[(j + 1) & 1] = *reinterpret_cast<const f16x8*>(b_hi + wbase + (j + 1) * 16 * 32);
+                    wl[(j + 1) & 1] = *reinterpret_cast<const f16x8*>(b_lo + wbase + (j + 1) * 16 * 32);
+                }
+                const f16x8 ch = wh[j & 1], cl = wl[j & 1];
+                // dependent MFMAs (same accumulator) are kept 4 issues apart
+                cor[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cl, xh[0], cor[0][j], 0, 0, 0);
+                cor[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cl, xh[1], cor[1][j], 0, 0, 0);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, xh[0], acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, xh[1], acc[1][j], 0, 0, 0);
+                cor[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, xl[0], cor[0][j], 0, 0, 0);
+                cor[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, xl[1], cor[1][j], 0, 0, 0);
+            }
+        }
+        if (more_w) w_store(wb ^ 1);
+        __syncthreads();
+        if (next_halo) {        // every wave has finished reading the old halo
+#pragma unroll
+            for (int k = 0; k < HALO_TPT; ++k) halo_store(k);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue ----
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int oy = oy0 + 2 * wave + i, ox = ox0 + r;
+        if (oy >= a.H || ox >= a.W) continue;
+        float* orow = a.out + (((long long)img * a.H + oy) * a.W + ox) * a.out_ld;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int co = n0 + 16 * j + 4 * g;
+            if (co >= a.Cout) continue;
+            const f32x4 v = acc[i][j], c2 = cor[i][j];
+            const int nvalid = a.Cout - co;
+            float vv[4] = {v.x + c2.x * LO_UNSCALE, v.y + c2.y * LO_UNSCALE, v.z + c2.z * LO_UNSCALE, v.w + c2.w * LO_UNSCALE};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (e < nvalid) {
+                    float x = vv[e];
+                    if (a.bias) x += a.bias[co + e];
+                    if (a.prelu) x = x > 0.f ? x : a.prelu[co + e] * x;
+                    vv[e] = x;
+                }
+            }
+            if (nvalid >= 4) {
+                *reinterpret_cast<f32x4*>(orow + co) = (f32x4){vv[0], vv[1], vv[2], vv[3]};
+            } else {
+                for (int e = 0; e < nvalid; ++e) orow[co + e] = vv[e];
+            }
+        }
+    }
+}
+
+template <int WN>
+int launch_row(const Conv3Dev& d, int ntiles, hipStream_t s) {
+    constexpr int BN = 16 * WN;
+    const size_t lds = (size_t)(2 * NPIX * 32 + 2 * 2 * 3 * BN * 32) * sizeof(_Float16);
+    auto kern = conv3x3_f16x3_row_kernel<WN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        ATMVFI_REQUIRE(e == hipSuccess, ATMVFI_ELAUNCH, "conv3x3_f16x3_row: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    dim3 grid((unsigned)((long long)d.N * d.tiles_x * d.tiles_y), (unsigned)((ntiles + WN - 1) / WN));
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, d);
+    return atmvfi::check_launch("conv3x3_f16x3_row");
+}
+
+}  // namespace
+
+int atmvfi::launch_conv3x3_row(const Conv3Dev& d, int ntiles, hipStream_t s) {
+    int best = 1;
+    float best_cost = 1e30f;
+    for (int wn = 1; wn <= 8; ++wn) {
+        const int padded = (ntiles + wn - 1) / wn * wn;
+        const float cost = (float)padded * (1.0f + 1.0f / (float)wn);
+        if (cost <= best_cost) { best_cost = cost; best = wn; }
+    }
+    switch (best) {
+        case 1: return launch_row<1>(d, ntiles, s);
+        case 2: return launch_row<2>(d, ntiles, s);
+        case 3: return launch_row<3>(d, ntiles, s);
+        case 4: return launch_row<4>(d, ntiles, s);
+        case 5: return launch_row<5>(d, ntiles, s);
+        case 6: return launch_row<6>(d, ntiles, s);
+        case 7: return launch_row<7>(d, ntiles, s);
+        default: return launch_row<8>(d, ntiles, s);
+    }
+}

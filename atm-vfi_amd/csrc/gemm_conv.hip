@@ -87,6 +87,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32(const GemmDev a) {
         for (int j = 0; j < WN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     f32x4 ra[WM], rb[NB];
+    int anv[WM], ac[WM];
 
     auto load_chunk = [&](int kc) {
         const int tap = kc / a.cpt;
@@ -101,43 +102,43 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32(const GemmDev a) {
             bool ok = rok[i] && (c < a.Cin);
             if (a.mode == ATMVFI_GEMM_CONV)
                 ok = ok && ((unsigned)(iy0[i] + dy) < (unsigned)a.H) && ((unsigned)(ix0[i] + dx) < (unsigned)a.W);
-            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (ok) {
-                v = *reinterpret_cast<const f32x4*>(rbase[i] + toff);
-                if (c + 3 >= a.Cin) {   // ragged channel tail inside this float4
-                    if (c + 1 >= a.Cin) v.y = 0.f;
-                    if (c + 2 >= a.Cin) v.z = 0.f;
-                    v.w = 0.f;
-                }
-                if (a.in_prelu) {       // host pads in_prelu to cin_pad
-                    const f32x4 al = *reinterpret_cast<const f32x4*>(a.in_prelu + c);
-                    v.x = v.x > 0.f ? v.x : al.x * v.x;
-                    v.y = v.y > 0.f ? v.y : al.y * v.y;
-                    v.z = v.z > 0.f ? v.z : al.z * v.z;
-                    v.w = v.w > 0.f ? v.w : al.w * v.w;
-                }
-            }
+            // unconditional load from a clamped address + selects (a predicated load costs a branch and a vmcnt(0))
+            const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? rbase[i] + toff : a.in);
+            anv[i] = ok ? a.Cin - c : 0;       // masking / in_prelu happen at store time: no early consumer of the loads
+            ac[i] = ok ? c : 0;
             ra[i] = v;
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (wok[i]) v = *reinterpret_cast<const f32x4*>(wbase[i] + (long long)kc * 16);
-            rb[i] = v;
+            rb[i] = *reinterpret_cast<const f32x4*>(wbase[i] + (long long)kc * 16);      // row-clamped: always valid; masked at store
         }
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
             const int row = (t >> 2) + 64 * i;
-            *reinterpret_cast<f32x4*>(As + ((buf * BM + row) * 16 + ((kq ^ swz(row)) << 2))) = ra[i];
+            f32x4 v = ra[i];
+            const int nv = anv[i];
+            v.x = nv > 0 ? v.x : 0.f;
+            v.y = nv > 1 ? v.y : 0.f;
+            v.z = nv > 2 ? v.z : 0.f;
+            v.w = nv > 3 ? v.w : 0.f;
+            if (a.in_prelu) {       // host pads in_prelu (uniform branch)
+                const f32x4 al = *reinterpret_cast<const f32x4*>(a.in_prelu + ac[i]);
+                v.x = v.x > 0.f ? v.x : al.x * v.x;
+                v.y = v.y > 0.f ? v.y : al.y * v.y;
+                v.z = v.z > 0.f ? v.z : al.z * v.z;
+                v.w = v.w > 0.f ? v.w : al.w * v.w;
+            }
+            *reinterpret_cast<f32x4*>(As + ((buf * BM + row) * 16 + ((kq ^ swz(row)) << 2))) = v;
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int f = t + 256 * i;
             if (f < BN * 4) {
                 const int row = f >> 2;
-                *reinterpret_cast<f32x4*>(Bs + ((buf * BN + row) * 16 + (((f & 3) ^ swz(row)) << 2))) = rb[i];
+                *reinterpret_cast<f32x4*>(Bs + ((buf * BN + row) * 16 + (((f & 3) ^ swz(row)) << 2))) =
+                    wok[i] ? rb[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
     };

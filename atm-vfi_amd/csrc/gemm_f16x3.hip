@@ -111,6 +111,7 @@ __global__ __launch_bounds__(512) void gemm_f16x3_kernel(const GemmDev a) {
         }
 
     f32x4 ra[2][2];
+    int anv[2], ac[2];
     f16x8 wr[B_PPT];
 
     auto load_chunk = [&](int kc) {
@@ -126,56 +127,57 @@ __global__ __launch_bounds__(512) void gemm_f16x3_kernel(const GemmDev a) {
             bool ok = rok[i] && (c < a.Cin);
             if (a.mode == ATMVFI_GEMM_CONV)
                 ok = ok && ((unsigned)(iy0[i] + dy) < (unsigned)a.H) && ((unsigned)(ix0[i] + dx) < (unsigned)a.W);
-            f32x4 va = (f32x4){0.f, 0.f, 0.f, 0.f}, vb = va;
-            if (ok) {
-                const float* p = rbase[i] + toff;
-                va = *reinterpret_cast<const f32x4*>(p);
-                if (c + 4 < a.Cin) vb = *reinterpret_cast<const f32x4*>(p + 4);
-                const int nv = a.Cin - c;
-                if (nv < 8) {
-                    if (nv < 2) va.y = 0.f;
-                    if (nv < 3) va.z = 0.f;
-                    if (nv < 4) va.w = 0.f;
-                    if (nv < 5) vb.x = 0.f;
-                    if (nv < 6) vb.y = 0.f;
-                    if (nv < 7) vb.z = 0.f;
-                    vb.w = 0.f;
-                }
-                if (a.in_prelu) {       // host pads in_prelu to a multiple of 32
-                    const f32x4 al = *reinterpret_cast<const f32x4*>(a.in_prelu + c);
-                    const f32x4 bl = *reinterpret_cast<const f32x4*>(a.in_prelu + c + 4);
-                    va.x = va.x > 0.f ? va.x : al.x * va.x;
-                    va.y = va.y > 0.f ? va.y : al.y * va.y;
-                    va.z = va.z > 0.f ? va.z : al.z * va.z;
-                    va.w = va.w > 0.f ? va.w : al.w * va.w;
-                    vb.x = vb.x > 0.f ? vb.x : bl.x * vb.x;
-                    vb.y = vb.y > 0.f ? vb.y : bl.y * vb.y;
-                    vb.z = vb.z > 0.f ? vb.z : bl.z * vb.z;
-                    vb.w = vb.w > 0.f ? vb.w : bl.w * vb.w;
-                }
-            }
+            // unconditional loads from a clamped address + selects (a predicated load costs a branch and a vmcnt(0))
+            const int nv = ok ? a.Cin - c : 0;
+            const float* p = ok ? rbase[i] + toff : a.in;
+            const f32x4 va = *reinterpret_cast<const f32x4*>(p);
+            const f32x4 vb = *reinterpret_cast<const f32x4*>(p + (nv > 4 ? 4 : 0));
+            anv[i] = nv;                       // masking / in_prelu happen at store time: no early consumer of the loads
+            ac[i] = ok ? c : 0;
             ra[i][0] = va;
             ra[i][1] = vb;
         }
         const long long koff = (long long)kc * 32;
 #pragma unroll
         for (int k = 0; k < B_PPT; ++k) {
-            f16x8 v = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
-            if (wok[k]) v = *reinterpret_cast<const f16x8*>(wsrc[k] + koff);
-            wr[k] = v;
+            wr[k] = *reinterpret_cast<const f16x8*>(wsrc[k] + koff);         // row-clamped address: always valid; masked at store
         }
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             f16x8 hi, lo;
-            split8(ra[i][0], ra[i][1], hi, lo);
+            f32x4 va = ra[i][0], vb = ra[i][1];
+            const int nv = anv[i];
+            va.x = nv > 0 ? va.x : 0.f;
+            va.y = nv > 1 ? va.y : 0.f;
+            va.z = nv > 2 ? va.z : 0.f;
+            va.w = nv > 3 ? va.w : 0.f;
+            vb.x = nv > 4 ? vb.x : 0.f;
+            vb.y = nv > 5 ? vb.y : 0.f;
+            vb.z = nv > 6 ? vb.z : 0.f;
+            vb.w = nv > 7 ? vb.w : 0.f;
+            if (a.in_prelu) {       // host pads in_prelu to a multiple of 32 (uniform branch)
+                const f32x4 al = *reinterpret_cast<const f32x4*>(a.in_prelu + ac[i]);
+                const f32x4 bl = *reinterpret_cast<const f32x4*>(a.in_prelu + ac[i] + 4);
+                va.x = va.x > 0.f ? va.x : al.x * va.x;
+                va.y = va.y > 0.f ? va.y : al.y * va.y;
+                va.z = va.z > 0.f ? va.z : al.z * va.z;
+                va.w = va.w > 0.f ? va.w : al.w * va.w;
+                vb.x = vb.x > 0.f ? vb.x : bl.x * vb.x;
+                vb.y = vb.y > 0.f ? vb.y : bl.y * vb.y;
+                vb.z = vb.z > 0.f ? vb.z : bl.z * vb.z;
+                vb.w = vb.w > 0.f ? vb.w : bl.w * vb.w;
+            }
+            split8(va, vb, hi, lo);
             *reinterpret_cast<f16x8*>(a_hi + buf * BM * 32 + adst[i]) = hi;
             *reinterpret_cast<f16x8*>(a_lo + buf * BM * 32 + adst[i]) = lo;
         }
 #pragma unroll
         for (int k = 0; k < B_PPT; ++k)
-            if (wact[k]) *reinterpret_cast<f16x8*>((wlo[k] ? b_lo : b_hi) + buf * BN * 32 + wdst[k]) = wr[k];
+            if (wact[k])
+                *reinterpret_cast<f16x8*>((wlo[k] ? b_lo : b_hi) + buf * BN * 32 + wdst[k]) =
+                    wok[k] ? wr[k] : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
     };
 
     load_chunk(0);
@@ -198,12 +200,13 @@ __global__ __launch_bounds__(512) void gemm_f16x3_kernel(const GemmDev a) {
             const int off = buf * BN * 32 + row * 32 + ((g ^ swz64(row)) << 3);
             const f16x8 wh = *reinterpret_cast<const f16x8*>(b_hi + off);
             const f16x8 wl = *reinterpret_cast<const f16x8*>(b_lo + off);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                cor[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[i], cor[i][j], 0, 0, 0);
-                cor[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[i], cor[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[i], acc[i][j], 0, 0, 0);
-            }
+                // dependent MFMAs (same accumulator) are kept 4 issues apart: back-to-back they stall the pipe
+                cor[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[0], cor[0][j], 0, 0, 0);
+                cor[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[1], cor[1][j], 0, 0, 0);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[0], acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[1], acc[1][j], 0, 0, 0);
+                cor[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[0], cor[0][j], 0, 0, 0);
+                cor[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[1], cor[1][j], 0, 0, 0);
         }
         if (kc + 1 < a.nchunks32) store_chunk(buf ^ 1);
         __syncthreads();

@@ -213,12 +213,16 @@ def test_layernorm_gather_groups(hip, cpu, dev):
     assert maxdiff(og, oc) <= 2e-5
 
 
-def test_dwconv_gelu(hip, cpu, dev):
-    g = torch.Generator().manual_seed(6)
-    x = rnd(g, 2, 7, 9, 448, scale=2.0)
-    w = rnd(g, 448, 1, 3, 3, scale=0.5)
-    b = rnd(g, 448, scale=0.3)
-    oc, og = torch.empty(2, 7, 9, 448), torch.empty(2, 7, 9, 448, device=dev)
+@pytest.mark.parametrize("shape", [(2, 7, 9, 448), (1, 19, 37, 704), (2, 5, 6, 100), (1, 16, 16, 64)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_dwconv_gelu(shape, hip, cpu, dev):
+    """C % 64 == 0 -> sliding-window kernel (partial strips / x-blocks / image borders); otherwise per-pixel kernel."""
+    n, h, w_, c = shape
+    g = torch.Generator().manual_seed(6 + c)
+    x = rnd(g, n, h, w_, c, scale=2.0)
+    w = rnd(g, c, 1, 3, 3, scale=0.5)
+    b = rnd(g, c, scale=0.3)
+    oc, og = torch.empty(n, h, w_, c), torch.full((n, h, w_, c), 9.0, device=dev)
     cpu.dwconv_gelu(x, oc, w, b)
     hip.dwconv_gelu(x.to(dev), og, hip.pack_dw_weight(w.to(dev)), b.to(dev))
     assert maxdiff(og, oc) <= 2e-5
