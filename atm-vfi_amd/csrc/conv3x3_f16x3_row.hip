@@ -205,31 +205,46 @@ __global__ __launch_bounds__(512) void conv3x3_f16x3_row_kernel(const Conv3Dev a
     }
 
     // ---- epilogue ----
+    float* orow[2];
+    bool live[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int oy = oy0 + 2 * wave + i, ox = ox0 + r;
-        if (oy >= a.H || ox >= a.W) continue;
-        float* orow = a.out + (((long long)img * a.H + oy) * a.W + ox) * a.out_ld;
+        live[i] = oy < a.H && ox < a.W;
+        orow[i] = a.out + (((long long)img * a.H + (live[i] ? oy : 0)) * a.W + (live[i] ? ox : 0)) * a.out_ld;
+    }
 #pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const int co = n0 + 16 * j + 4 * g;
-            if (co >= a.Cout) continue;
-            const f32x4 v = acc[i][j], c2 = cor[i][j];
-            const int nvalid = a.Cout - co;
-            float vv[4] = {v.x + c2.x * LO_UNSCALE, v.y + c2.y * LO_UNSCALE, v.z + c2.z * LO_UNSCALE, v.w + c2.w * LO_UNSCALE};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (e < nvalid) {
-                    float x = vv[e];
-                    if (a.bias) x += a.bias[co + e];
-                    if (a.prelu) x = x > 0.f ? x : a.prelu[co + e] * x;
-                    vv[e] = x;
-                }
+    for (int j = 0; j < WN; ++j) {
+        const int co = n0 + 16 * j + 4 * g;
+        const int nvalid = a.Cout - co;
+        if (nvalid <= 0) continue;
+        // bias / PReLU slopes of the tile, one 16-byte load each (host guarantees alignment)
+        f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f}, pv = (f32x4){1.f, 1.f, 1.f, 1.f};
+        if (nvalid >= 4) {
+            if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + co);
+            if (a.prelu) pv = *reinterpret_cast<const f32x4*>(a.prelu + co);
+        } else {
+            float bb[4] = {0.f, 0.f, 0.f, 0.f}, pp[4] = {1.f, 1.f, 1.f, 1.f};
+            for (int e = 0; e < nvalid; ++e) {
+                if (a.bias) bb[e] = a.bias[co + e];
+                if (a.prelu) pp[e] = a.prelu[co + e];
             }
+            bv = (f32x4){bb[0], bb[1], bb[2], bb[3]};
+            pv = (f32x4){pp[0], pp[1], pp[2], pp[3]};
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (!live[i]) continue;
+            f32x4 v = acc[i][j] + cor[i][j] * LO_UNSCALE + bv;
+            v.x = v.x > 0.f ? v.x : pv.x * v.x;
+            v.y = v.y > 0.f ? v.y : pv.y * v.y;
+            v.z = v.z > 0.f ? v.z : pv.z * v.z;
+            v.w = v.w > 0.f ? v.w : pv.w * v.w;
             if (nvalid >= 4) {
-                *reinterpret_cast<f32x4*>(orow + co) = (f32x4){vv[0], vv[1], vv[2], vv[3]};
+                *reinterpret_cast<f32x4*>(orow[i] + co) = v;
             } else {
-                for (int e = 0; e < nvalid; ++e) orow[co + e] = vv[e];
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+                for (int e = 0; e < nvalid; ++e) orow[i][co + e] = vv[e];
             }
         }
     }

@@ -64,34 +64,61 @@ __device__ __forceinline__ bool gemm_out_row(const GemmDev& a, long long m, floa
     return true;
 }
 
-// Store four consecutive GEMM columns nb..nb+3 of one row: + bias, PReLU, + residual, 16-byte store.
-__device__ __forceinline__ void gemm_store4(const GemmDev& a, float* orow, const float* rrow, int nb, float v0, float v1,
-                                            float v2, float v3) {
-    int co = nb;
-    float* optr = orow;
+// Per-n-tile channel constants (bias, PReLU slope) of GEMM columns nb..nb+3, loaded ONCE per tile as
+// 16-byte vectors (the host guarantees 16-byte aligned bias/prelu/residual; co is a multiple of 4).
+// Scalar per-element loads here cost 100+ dependent dword loads per lane per tile and dominated
+// the short-K layers.  Missing bias -> 0, missing PReLU -> slope 1 (identity), so the math is branch-free.
+struct ChanVec {
+    f32x4 b, p;
+    int co;        // first output channel (DECONV: within the 2x2 position), -1 = nothing to store
+    int q;         // DECONV: position index a*2+b
+    int nvalid;
+};
+
+__device__ __forceinline__ ChanVec gemm_chan_vec(const GemmDev& a, int nb) {
+    ChanVec c;
+    c.q = 0;
+    c.co = nb;
     if (a.mode == ATMVFI_GEMM_DECONV) {
-        if (nb >= 4 * a.coutp) return;
-        const int q = (nb >= a.coutp) + (nb >= 2 * a.coutp) + (nb >= 3 * a.coutp);
-        co = nb - q * a.coutp;
-        optr = orow + ((long long)(q >> 1) * a.Wo + (q & 1)) * a.out_ld;
+        c.q = (nb >= a.coutp) + (nb >= 2 * a.coutp) + (nb >= 3 * a.coutp);
+        c.co = nb - c.q * a.coutp;
+        if (nb >= 4 * a.coutp) c.co = -1;
     }
-    if (co >= a.Cout) return;
-    const int nvalid = a.Cout - co;   // >= 1
-    float vv[4] = {v0, v1, v2, v3};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        if (e < nvalid) {
-            float x = vv[e];
-            if (a.bias) x += a.bias[co + e];
-            if (a.prelu) x = x > 0.f ? x : a.prelu[co + e] * x;
-            if (rrow) x += rrow[co + e];
-            vv[e] = x;
+    if (c.co >= a.Cout) c.co = -1;
+    c.nvalid = c.co < 0 ? 0 : a.Cout - c.co;
+    c.b = (f32x4){0.f, 0.f, 0.f, 0.f};
+    c.p = (f32x4){1.f, 1.f, 1.f, 1.f};
+    if (c.nvalid >= 4) {
+        if (a.bias) c.b = *reinterpret_cast<const f32x4*>(a.bias + c.co);
+        if (a.prelu) c.p = *reinterpret_cast<const f32x4*>(a.prelu + c.co);
+    } else if (c.nvalid > 0) {
+        float bb[4] = {0.f, 0.f, 0.f, 0.f}, pp[4] = {1.f, 1.f, 1.f, 1.f};
+        for (int e = 0; e < c.nvalid; ++e) {
+            if (a.bias) bb[e] = a.bias[c.co + e];
+            if (a.prelu) pp[e] = a.prelu[c.co + e];
         }
+        c.b = (f32x4){bb[0], bb[1], bb[2], bb[3]};
+        c.p = (f32x4){pp[0], pp[1], pp[2], pp[3]};
     }
-    if (nvalid >= 4) {
-        *reinterpret_cast<f32x4*>(optr + co) = (f32x4){vv[0], vv[1], vv[2], vv[3]};
+    return c;
+}
+
+// Store four consecutive GEMM columns of one row: + bias, PReLU, + residual, one 16-byte store.
+__device__ __forceinline__ void gemm_store4(const GemmDev& a, float* orow, const float* rrow, const ChanVec& c, f32x4 v) {
+    if (c.co < 0) return;
+    float* optr = orow;
+    if (a.mode == ATMVFI_GEMM_DECONV) optr = orow + ((long long)(c.q >> 1) * a.Wo + (c.q & 1)) * a.out_ld;
+    v += c.b;
+    v.x = v.x > 0.f ? v.x : c.p.x * v.x;
+    v.y = v.y > 0.f ? v.y : c.p.y * v.y;
+    v.z = v.z > 0.f ? v.z : c.p.z * v.z;
+    v.w = v.w > 0.f ? v.w : c.p.w * v.w;
+    if (c.nvalid >= 4) {
+        if (rrow) v += *reinterpret_cast<const f32x4*>(rrow + c.co);
+        *reinterpret_cast<f32x4*>(optr + c.co) = v;
     } else {
-        for (int e = 0; e < nvalid; ++e) optr[co + e] = vv[e];
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+        for (int e = 0; e < c.nvalid; ++e) optr[c.co + e] = vv[e] + (rrow ? rrow[c.co + e] : 0.f);
     }
 }
 

@@ -172,17 +172,20 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32(const GemmDev a) {
     }
 
     // ---- epilogue: lane holds channels nb..nb+3 of pixel m for every (i, j) ----
+    float* orow[WM];
+    const float* rrow[WM];
+    bool live[WM];
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
         const long long m = m0 + wave * 16 * WM + 16 * i + r;
-        float* orow;
-        const float* rrow;
-        if (m >= a.M || !atmvfi::gemm_out_row(a, m, orow, rrow)) continue;
+        live[i] = m < a.M && atmvfi::gemm_out_row(a, m, orow[i], rrow[i]);
+    }
 #pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const f32x4 v = acc[i][j];
-            atmvfi::gemm_store4(a, orow, rrow, n0 + 16 * j + 4 * g, v.x, v.y, v.z, v.w);
-        }
+    for (int j = 0; j < WN; ++j) {
+        const atmvfi::ChanVec cv = atmvfi::gemm_chan_vec(a, n0 + 16 * j + 4 * g);
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+            if (live[i]) atmvfi::gemm_store4(a, orow[i], rrow[i], cv, acc[i][j]);
     }
 }
 
@@ -258,6 +261,9 @@ extern "C" int atmvfi_gemm(const atmvfi_gemm_params* p, void* stream) {
     if (p->residual)
         ATMVFI_REQUIRE(p->res_ld >= p->Cout, ATMVFI_EINVAL, "gemm: res_ld %d < Cout %d", p->res_ld, p->Cout);
     if (p->in_prelu) ATMVFI_REQUIRE(atmvfi::aligned16(p->in_prelu), ATMVFI_EALIGN, "gemm: in_prelu must be 16-byte aligned");
+    ATMVFI_REQUIRE((!p->bias || atmvfi::aligned16(p->bias)) && (!p->prelu || atmvfi::aligned16(p->prelu)) &&
+                       (!p->residual || (atmvfi::aligned16(p->residual) && p->res_ld % 4 == 0)),
+                   ATMVFI_EALIGN, "gemm: bias/prelu/residual must be 16-byte aligned (res_ld a multiple of 4)");
 
     GemmDev d;
     d.mode = p->mode;

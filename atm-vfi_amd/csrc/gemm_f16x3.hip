@@ -212,18 +212,20 @@ __global__ __launch_bounds__(512) void gemm_f16x3_kernel(const GemmDev a) {
         __syncthreads();
     }
 
+    float* orow[2];
+    const float* rrow[2];
+    bool live[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const long long m = m0 + 32 * wave + 16 * i + r;
-        float* orow;
-        const float* rrow;
-        if (m >= a.M || !atmvfi::gemm_out_row(a, m, orow, rrow)) continue;
+        live[i] = m < a.M && atmvfi::gemm_out_row(a, m, orow[i], rrow[i]);
+    }
 #pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const f32x4 v = acc[i][j], c2 = cor[i][j];
-            atmvfi::gemm_store4(a, orow, rrow, n0 + 16 * j + 4 * g, v.x + c2.x * LO_UNSCALE, v.y + c2.y * LO_UNSCALE,
-                                v.z + c2.z * LO_UNSCALE, v.w + c2.w * LO_UNSCALE);
-        }
+    for (int j = 0; j < WN; ++j) {
+        const atmvfi::ChanVec cv = atmvfi::gemm_chan_vec(a, n0 + 16 * j + 4 * g);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (live[i]) atmvfi::gemm_store4(a, orow[i], rrow[i], cv, acc[i][j] + cor[i][j] * LO_UNSCALE);
     }
 }
 
