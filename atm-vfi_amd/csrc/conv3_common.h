@@ -19,9 +19,12 @@ struct Conv3Dev {
     const float* bias;
     const float* prelu;
     int tiles_x, tiles_y;
+    unsigned long long* stamp;   // diagnostic builds only (ATMVFI_STAMP)
 };
 // conv3x3_f16x3_row.hip: three taps (one kernel row) per stage, single-buffered halo
 int launch_conv3x3_row(const Conv3Dev& d, int ntiles, hipStream_t stream);
+// conv3x3_f16x3_half.hip: 256-thread workgroups on 16x8 tiles, two per CU, single-buffered LDS
+int launch_conv3x3_half(const Conv3Dev& d, int ntiles, hipStream_t stream);
 }  // namespace atmvfi
 using atmvfi::Conv3Dev;
 

@@ -344,14 +344,19 @@ extern "C" int atmvfi_conv3x3_f16x3(const float* in, int in_ld, int N, int H, in
     d.wrows = atmvfi::round_up(Cout, 16);
     d.cin_pad = atmvfi::round_up(Cin, 32);
     d.Cout = Cout; d.out = out; d.out_ld = out_ld; d.bias = bias; d.prelu = prelu;
+    d.stamp = nullptr;
     d.tiles_x = (W + TW - 1) / TW;
     d.tiles_y = (H + TH - 1) / TH;
     ATMVFI_REQUIRE((long long)N * d.tiles_x * d.tiles_y < (1ll << 31), ATMVFI_EINVAL, "conv3x3_f16x3: grid too large");
     const int ntiles = (Cout + 15) / 16;
     hipStream_t s = (hipStream_t)stream;
-    // default schedule: one kernel row (3 taps) per stage; ATMVFI_CONV3_ONE_TAP=1 selects the one-tap schedule (A/B runs)
-    static const bool one_tap = getenv("ATMVFI_CONV3_ONE_TAP") != nullptr;
-    if (!one_tap) return atmvfi::launch_conv3x3_row(d, ntiles, s);
+    // schedules (A/B via ATMVFI_CONV3_SCHED): "row" (default) = one 512-thread workgroup per CU, 3 taps per stage;
+    // "half" = two 256-thread workgroups per CU on 16x8 tiles, single-buffered (wins only around WN = 6, spills at
+    // WN >= 7); "onetap" = the first schedule, one tap per stage
+    static const char* sched_env = getenv("ATMVFI_CONV3_SCHED");
+    static const int sched = !sched_env ? 1 : (sched_env[0] == 'h' ? 0 : (sched_env[0] == 'o' ? 2 : 1));
+    if (sched == 0) return atmvfi::launch_conv3x3_half(d, ntiles, s);
+    if (sched == 1) return atmvfi::launch_conv3x3_row(d, ntiles, s);
     int best = 1;
     float best_cost = 1e30f;
     for (int wn = 1; wn <= 8; ++wn) {

@@ -13,6 +13,17 @@
 // Weight fragments are read one n-tile ahead of the MFMAs that consume them.
 #include "conv3_common.h"
 
+#ifdef ATMVFI_STAMP
+// Diagnostic build only (`make stamp`, tools/stamp_conv.py): per-wave cycle sums of the phases of a stage.
+static unsigned long long* g_stamp_buf = nullptr;
+extern "C" void atmvfi_debug_set_stamp_buffer(void* p) { g_stamp_buf = (unsigned long long*)p; }
+#define STAMP_DECL unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
+#define STAMP(k) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); st_[k] += t1_ - st_t0; st_t0 = t1_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define STAMP_DECL
+#define STAMP(k)
+#endif
+
 namespace {
 
 template <int WN>
@@ -143,6 +154,7 @@ __global__ __launch_bounds__(512) void conv3x3_f16x3_row_kernel(const Conv3Dev a
                     wok[k] ? wr[k] : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
     };
 
+    STAMP_DECL
     // ---- prologue ----
 #pragma unroll
     for (int k = 0; k < HALO_TPT; ++k) halo_load(k, 0);
@@ -151,6 +163,7 @@ __global__ __launch_bounds__(512) void conv3x3_f16x3_row_kernel(const Conv3Dev a
     for (int k = 0; k < HALO_TPT; ++k) halo_store(k);
     w_store(0);
     __syncthreads();
+    STAMP(0)
 
     for (int s = 0; s < nstages; ++s) {
         const int chunk = s / 3;
@@ -163,6 +176,7 @@ __global__ __launch_bounds__(512) void conv3x3_f16x3_row_kernel(const Conv3Dev a
 #pragma unroll
             for (int k = 0; k < HALO_TPT; ++k) halo_load(k, chunk + 1);
         }
+        STAMP(1)
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             f16x8 xh[2], xl[2];
@@ -176,16 +190,23 @@ __global__ __launch_bounds__(512) void conv3x3_f16x3_row_kernel(const Conv3Dev a
             const int wbase = (wb * 3 + t) * BN * 32 + r * 32 + ((g ^ swz64(r)) << 3);     // swz64(16j + r) == swz64(r)
             // weight fragments ping-pong between two statically indexed register sets (j is a compile-time
             // constant after unrolling): the next n-tile is fetched before this tile's MFMAs, without copies
-            f16x8 wh[2], wl[2];
+            // weight fragments run two n-tiles ahead of the MFMAs (3-slot ring, static indices) and the order is
+            // pinned per tile: left alone, the scheduler folds the ring into one register, hoists the next tile's
+            // MFMAs behind its just-issued ds_read and stalls on it (lgkmcnt(1)) every 6 MFMAs
+            f16x8 wh[3], wl[3];
             wh[0] = *reinterpret_cast<const f16x8*>(b_hi + wbase);
             wl[0] = *reinterpret_cast<const f16x8*>(b_lo + wbase);
+            if (WN > 1) {
+                wh[1] = *reinterpret_cast<const f16x8*>(b_hi + wbase + 16 * 32);
+                wl[1] = *reinterpret_cast<const f16x8*>(b_lo + wbase + 16 * 32);
+            }
 #pragma unroll
             for (int j = 0; j < WN; ++j) {
-                if (j + 1 < WN) {
-                    wh[(j + 1) & 1] = *reinterpret_cast<const f16x8*>(b_hi + wbase + (j + 1) * 16 * 32);
-                    wl[(j + 1) & 1] = *reinterpret_cast<const f16x8*>(b_lo + wbase + (j + 1) * 16 * 32);
+                if (j + 2 < WN) {
+                    wh[(j + 2) % 3] = *reinterpret_cast<const f16x8*>(b_hi + wbase + (j + 2) * 16 * 32);
+                    wl[(j + 2) % 3] = *reinterpret_cast<const f16x8*>(b_lo + wbase + (j + 2) * 16 * 32);
                 }
-                const f16x8 ch = wh[j & 1], cl = wl[j & 1];
+                const f16x8 ch = wh[j % 3], cl = wl[j % 3];
                 // dependent MFMAs (same accumulator) are kept 4 issues apart
                 cor[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cl, xh[0], cor[0][j], 0, 0, 0);
                 cor[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cl, xh[1], cor[1][j], 0, 0, 0);
@@ -193,14 +214,19 @@ __global__ __launch_bounds__(512) void conv3x3_f16x3_row_kernel(const Conv3Dev a
                 acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, xh[1], acc[1][j], 0, 0, 0);
                 cor[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, xl[0], cor[0][j], 0, 0, 0);
                 cor[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, xl[1], cor[1][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+        STAMP(2)
         if (more_w) w_store(wb ^ 1);
+        STAMP(3)
         __syncthreads();
+        STAMP(4)
         if (next_halo) {        // every wave has finished reading the old halo
 #pragma unroll
             for (int k = 0; k < HALO_TPT; ++k) halo_store(k);
             __syncthreads();
+            STAMP(5)
         }
     }
 
@@ -248,6 +274,13 @@ __global__ __launch_bounds__(512) void conv3x3_f16x3_row_kernel(const Conv3Dev a
             }
         }
     }
+    STAMP(6)
+#ifdef ATMVFI_STAMP
+    if (a.stamp && lane == 0) {
+        unsigned long long* o = a.stamp + (((long long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 8;
+        for (int k = 0; k < 8; ++k) o[k] = st_[k];
+    }
+#endif
 }
 
 template <int WN>
@@ -262,7 +295,13 @@ int launch_row(const Conv3Dev& d, int ntiles, hipStream_t s) {
         attr_set = true;
     }
     dim3 grid((unsigned)((long long)d.N * d.tiles_x * d.tiles_y), (unsigned)((ntiles + WN - 1) / WN));
+#ifdef ATMVFI_STAMP
+    Conv3Dev ds = d;
+    ds.stamp = g_stamp_buf;
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, ds);
+#else
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, d);
+#endif
     return atmvfi::check_launch("conv3x3_f16x3_row");
 }
 
