@@ -10,9 +10,10 @@ and the N output frames are all-gathered over RCCL/xGMI -- the only collective o
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
 Rank 0 prints ONE JSON line.  Besides the contract's fields it carries
-  roofline     : the dominant kernel family (implicit-GEMM fp32-MFMA engine: conv2d + linear + deconv2x2),
+  roofline     : the kernel family with the largest share of the forward (today conv3x3_f16x3_kernel),
                  achieved = sum of algorithmic FLOPs / sum of launch durations, measured live with HIP
                  events on the launch stream in a separate instrumented pass after the timed region;
+                 `traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/);
   cpu_baseline : the CPU oracle (oracle/atmvfi_oracle.py, a port of the reference's algorithm) timed on this
                  node's host cores on a bounded sample (rank 0, N=1 only);
   kernels      : per-kernel-family time split of one forward (ms), for DESIGN.md / profiles/.
@@ -151,7 +152,7 @@ def main():
             ops = net._ops_obj
             for rep in range(2):          # second pass is the one reported (first warms the event pool)
                 ops.profile = []
-                step(0)
+                net(*frames[0])           # forward only: the other ranks are not in this pass, so no collective here
                 torch.cuda.synchronize()
                 prof = ops.profile
                 ops.profile = None
@@ -182,6 +183,18 @@ def main():
                                 "frac": round(ach / peak, 4), "traffic": None, "kernel": fam, "launches": nl,
                                 "avg_launch_ms": round(ms / nl, 4), "algorithmic_gflop_per_forward": round(fl / 1e9, 1),
                                 "share_of_forward_time": round(ms / total_ms, 4)}
+            # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled
+            # per the gfx950 correction); only meaningful for the workload they were taken on (base 1088x1920)
+            try:
+                if key == ("base", 1088, 1920, True):
+                    pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))["per_forward"]
+                    for fam, kn in (("conv3x3_f16x3_kernel", "conv3x3_f16x3_kernel"),
+                                    ("gemm_f16x3_kernel (linear + deconv2x2 + strided conv2d)", "gemm_f16x3_kernel")):
+                        if fam in fam_out and kn in pmc:
+                            fam_out[fam]["traffic"] = round(pmc[kn]["traffic_GB_per_launch"] * 1e9)
+                            fam_out[fam]["traffic_unit"] = "bytes/launch (PMC, profiles/r01_pmc_hbm_traffic.json)"
+            except Exception:
+                pass
             if fam_out:
                 dom = max(fam_out.values(), key=lambda d: d["share_of_forward_time"])
                 result["roofline"] = dom
