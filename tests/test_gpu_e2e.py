@@ -162,3 +162,30 @@ def test_rejects_cpu_inputs_and_bad_shapes(nets, dev):
     net.global_motion = True
     with pytest.raises(ValueError):
         net(torch.rand(1, 3, 72, 64, device=dev), torch.rand(1, 3, 72, 64, device=dev))
+
+
+def test_c5_4k_untiled_properties(nets, dev):
+    """BASELINE config C5 (network_base 2160x4096 -> padded 2176x4096, global on) on one GPU, untiled (the
+    reference has no tiling).  Too large for the CPU oracle inside a test budget, so the
+    size-independent properties are checked: finite, range, bitwise determinism and the structural identities of
+    the returned dict."""
+    net = nets["base"]
+    pad = host_io.InputPadder((1, 3, 2160, 4096), divisor=64)
+    a0, a1 = pairs.smooth_pair(1, 2160, 4096, seed=71)
+    a0, a1 = pad.pad(a0, a1)
+    assert tuple(a0.shape[-2:]) == (2176, 4096)
+    o1 = run(net, True, False, a0, a1, dev)
+    it = o1["I_t"].clone()
+    assert torch.isfinite(it).all() and it.min().item() >= 0.0 and it.max().item() <= 1.0
+    assert len(o1["im_t_list"]) == 5 and tuple(o1["opt_flow_0"].shape) == (1, 2, 2176, 4096)
+    o2 = run(net, True, False, a0, a1, dev)
+    assert torch.equal(o2["I_t"], it)
+    # structure of the outputs (network_base.py:525-533): masks are complementary, the returned frame is the clamped
+    # refined frame, and the refinement residual 2*sigmoid(r)-1 stays inside (-1, 1) around the blend
+    m1 = o2["occ_mask1"]
+    assert torch.equal(o2["occ_mask2"], 1 - m1)
+    assert torch.equal(o2["I_t"], o2["im_t_list"][0].clamp(0, 1))
+    blend = m1 * o2["I_t_0"] + (1 - m1) * o2["I_t_1"]
+    assert (o2["im_t_list"][0] - blend).abs().max().item() < 1.0 + 1e-5
+    net.release_workspace()
+    torch.cuda.empty_cache()
