@@ -80,6 +80,7 @@ class Network(nn.Module):
                 node.register_parameter(parts[-1], nn.Parameter(t))
         # ---- runtime state (not part of the state dict) ----
         self._ops_obj = None
+        self._precision = "f16x3"
         self._prepared: Dict[str, object] = {}
         self._prepared_sig = None
         self._bufs: Dict[Tuple, torch.Tensor] = {}
@@ -136,12 +137,23 @@ class Network(nn.Module):
         self._bufs.clear()
         self._geo.clear()
 
+    def set_precision(self, precision: str):
+        """"f16x3" (default): contractions as fp16 hi/lo split, three 16-bit MFMAs per product, fp32 accumulate
+        (~22 significand bits, operands must stay within the fp16 range).  "f32": every contraction on the exact-fp32
+        MFMA (about 2.5x slower).  Not part of the reference's API."""
+        if precision not in ("f16x3", "f32"):
+            raise ValueError("precision must be 'f16x3' or 'f32'")
+        self._precision = precision
+        if self._ops_obj is not None and hasattr(self._ops_obj, "precision"):
+            self._ops_obj.precision = precision
+
     def _ops(self, device: torch.device):
         if self._ops_obj is None:
             if device.type != "cuda":
                 raise RuntimeError("atm-vfi_amd.Network.forward runs on MI355X only: move the model and its inputs to "
                                    "'cuda' (HIP). There is no CPU implementation in the product; the CPU oracle lives in oracle/.")
             self._ops_obj = HipOps(device)
+            self._ops_obj.precision = self._precision
         return self._ops_obj
 
     def buf(self, name: str, *shape) -> torch.Tensor:

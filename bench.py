@@ -106,8 +106,7 @@ def main():
             dist.all_gather(gathered, out)      # per-rank output frames only
         return out
 
-    net(*frames[0])                      # builds the op backend
-    net._ops_obj.precision = args.precision
+    net.set_precision(args.precision)
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()

@@ -189,3 +189,22 @@ def test_c5_4k_untiled_properties(nets, dev):
     assert (o2["im_t_list"][0] - blend).abs().max().item() < 1.0 + 1e-5
     net.release_workspace()
     torch.cuda.empty_cache()
+
+
+def test_exact_fp32_engine_end_to_end(dev, weights):
+    """Network.set_precision("f32"): every contraction on the exact-fp32 MFMA engine (gemm_mfma_f32)."""
+    net = pkg.NetworkLite()
+    net.load_state_dict(weights("lite"), strict=True)
+    net.to(dev).eval()
+    net.set_precision("f32")
+    case = [c for c in G.e2e_cases() if c["name"] == "lite_128x192_g_b2"][0]
+    im0, im1 = G.case_inputs(case)
+    out = net(im0.to(dev), im1.to(dev))
+    assert net._ops_obj.precision == "f32"
+    errs = G.compare_e2e(out, G.load_npz(case["name"]), case["step"], TOL, TOL_FLOW)
+    net.set_precision("f16x3")
+    out2 = net(im0.to(dev), im1.to(dev))
+    errs2 = G.compare_e2e(out2, G.load_npz(case["name"]), case["step"], TOL, TOL_FLOW)
+    print("f32", {k: f"{v:.1e}" for k, v in errs.items()}, "f16x3", {k: f"{v:.1e}" for k, v in errs2.items()})
+    # the two engines agree far inside the parity budget
+    assert (out["I_t"] - out2["I_t"]).abs().max().item() <= 2e-4
