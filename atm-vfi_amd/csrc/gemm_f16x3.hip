@@ -194,19 +194,31 @@ __global__ __launch_bounds__(512) void gemm_f16x3_kernel(const GemmDev a) {
             xh[i] = *reinterpret_cast<const f16x8*>(a_hi + off);
             xl[i] = *reinterpret_cast<const f16x8*>(a_lo + off);
         }
+        // weight fragments run two n-tiles ahead of their MFMAs (3-slot ring, static indices, order pinned): left
+        // alone, hipcc folds the ring into one register and stalls on a just-issued ds_read every 6 MFMAs
+        const int wbase = buf * BN * 32 + r * 32 + ((g ^ swz64(r)) << 3);      // swz64(16j + r) == swz64(r)
+        f16x8 wh[3], wl[3];
+        wh[0] = *reinterpret_cast<const f16x8*>(b_hi + wbase);
+        wl[0] = *reinterpret_cast<const f16x8*>(b_lo + wbase);
+        if (WN > 1) {
+            wh[1] = *reinterpret_cast<const f16x8*>(b_hi + wbase + 16 * 32);
+            wl[1] = *reinterpret_cast<const f16x8*>(b_lo + wbase + 16 * 32);
+        }
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
-            const int row = 16 * j + r;
-            const int off = buf * BN * 32 + row * 32 + ((g ^ swz64(row)) << 3);
-            const f16x8 wh = *reinterpret_cast<const f16x8*>(b_hi + off);
-            const f16x8 wl = *reinterpret_cast<const f16x8*>(b_lo + off);
-                // dependent MFMAs (same accumulator) are kept 4 issues apart: back-to-back they stall the pipe
-                cor[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[0], cor[0][j], 0, 0, 0);
-                cor[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[1], cor[1][j], 0, 0, 0);
-                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[0], acc[0][j], 0, 0, 0);
-                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[1], acc[1][j], 0, 0, 0);
-                cor[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[0], cor[0][j], 0, 0, 0);
-                cor[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[1], cor[1][j], 0, 0, 0);
+            if (j + 2 < WN) {
+                wh[(j + 2) % 3] = *reinterpret_cast<const f16x8*>(b_hi + wbase + (j + 2) * 16 * 32);
+                wl[(j + 2) % 3] = *reinterpret_cast<const f16x8*>(b_lo + wbase + (j + 2) * 16 * 32);
+            }
+            const f16x8 ch = wh[j % 3], cl = wl[j % 3];
+            // dependent MFMAs (same accumulator) are kept 4 issues apart
+            cor[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cl, xh[0], cor[0][j], 0, 0, 0);
+            cor[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cl, xh[1], cor[1][j], 0, 0, 0);
+            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, xh[0], acc[0][j], 0, 0, 0);
+            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, xh[1], acc[1][j], 0, 0, 0);
+            cor[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, xl[0], cor[0][j], 0, 0, 0);
+            cor[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, xl[1], cor[1][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (kc + 1 < a.nchunks32) store_chunk(buf ^ 1);
         __syncthreads();
