@@ -18,7 +18,7 @@ namespace {
 
 template <int NT>
 __global__ __launch_bounds__(64 * NT) void window_attn_kernel(
-    const float* __restrict__ qkv, float* __restrict__ out, float* __restrict__ motion,
+    const float* __restrict__ qkv, const RowSink out, float* __restrict__ motion,
     const int* __restrict__ labels, int N, int nW, int ws, int heads, int hd, int C, int Bw, int kv_shift,
     float scale) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(64 * NT) void window_attn_kernel(
 
     // ---- O^T = V^T P^T ----
     const int ndt = (hd + 15) >> 4;
-    float* orow = out + ((long long)b * N + (qok ? q : 0)) * C + h * hd;
+    const long long orow = (long long)b * N + (qok ? q : 0);
     for (int dt = 0; dt < ndt; ++dt) {
         f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
         const int dcol = 16 * dt + r;
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(64 * NT) void window_attn_kernel(
                 o = __builtin_amdgcn_mfma_f32_16x16x4f32(vf, s[kt][ks], o, 0, 0, 0);
             }
         const int d = 16 * dt + 4 * g;
-        if (qok && d < hd) *reinterpret_cast<f32x4*>(orow + d) = o;
+        if (qok && d < hd) sink_store4(out, orow, h * hd + d, o);
     }
 }
 
@@ -184,7 +184,7 @@ __global__ void motion_head_kernel(const float* __restrict__ motion, const int* 
 }
 
 template <int NT>
-int launch_attn(const float* qkv, float* out, float* motion, const int* labels, int Bw, int nW, int N, int ws,
+int launch_attn(const float* qkv, const RowSink out, float* motion, const int* labels, int Bw, int nW, int N, int ws,
                 int heads, int hd, int kv_shift, hipStream_t s) {
     const int stride = hd + ((hd & 7) ? 0 : 4);
     const size_t lds = (size_t)(2 * NT * 16 * stride + NT * 16) * sizeof(float);
@@ -204,19 +204,23 @@ int launch_attn(const float* qkv, float* out, float* motion, const int* labels, 
 }  // namespace
 
 extern "C" int atmvfi_window_attention(const float* qkv, float* out, float* motion, const int32_t* labels, int Bw,
-                                        int nW, int ws, int heads, int hd, int kv_shift, void* stream) {
-    ATMVFI_REQUIRE(qkv && out, ATMVFI_EINVAL, "window_attention: null pointer");
+                                        int nW, int ws, int heads, int hd, int kv_shift, void* out_hi, void* out_lo,
+                                        int plane_ld, void* stream) {
+    ATMVFI_REQUIRE(qkv, ATMVFI_EINVAL, "window_attention: null pointer");
+    ATMVFI_REQUIRE(sink_ok(out, heads * hd, heads * hd, out_hi, out_lo, plane_ld), ATMVFI_EALIGN,
+                   "window_attention: output needs fp32 rows and/or both fp16 planes (ld %% 8 == 0, >= C), 16-byte aligned");
+    const RowSink sink{out, heads * hd, (_Float16*)out_hi, (_Float16*)out_lo, plane_ld};
     ATMVFI_REQUIRE(Bw > 0 && nW > 0 && Bw % nW == 0, ATMVFI_EINVAL, "window_attention: Bw %d must be a positive multiple of nW %d", Bw, nW);
     ATMVFI_REQUIRE(ws >= 1 && ws <= 16, ATMVFI_EINVAL, "window_attention: window size %d outside 1..16", ws);
     ATMVFI_REQUIRE(heads > 0 && hd > 0 && hd % 4 == 0, ATMVFI_EINVAL, "window_attention: head dim %d must be a multiple of 4", hd);
     ATMVFI_REQUIRE(kv_shift >= 0 && kv_shift < Bw, ATMVFI_EINVAL, "window_attention: kv_shift out of range");
-    ATMVFI_REQUIRE(atmvfi::aligned16(qkv) && atmvfi::aligned16(out), ATMVFI_EALIGN, "window_attention: qkv/out must be 16-byte aligned");
+    ATMVFI_REQUIRE(atmvfi::aligned16(qkv), ATMVFI_EALIGN, "window_attention: qkv must be 16-byte aligned");
     ATMVFI_REQUIRE((long long)Bw * heads < (1ll << 31), ATMVFI_EINVAL, "window_attention: grid too large");
     const int N = ws * ws;
     const int nt = (N + 15) / 16;
     hipStream_t s = (hipStream_t)stream;
 #define ATMVFI_ATTN_CASE(k) \
-    case k: return launch_attn<k>(qkv, out, motion, labels, Bw, nW, N, ws, heads, hd, kv_shift, s);
+    case k: return launch_attn<k>(qkv, sink, motion, labels, Bw, nW, N, ws, heads, hd, kv_shift, s);
     switch (nt) {
         ATMVFI_ATTN_CASE(1) ATMVFI_ATTN_CASE(2) ATMVFI_ATTN_CASE(3) ATMVFI_ATTN_CASE(4) ATMVFI_ATTN_CASE(5)
         ATMVFI_ATTN_CASE(6) ATMVFI_ATTN_CASE(7) ATMVFI_ATTN_CASE(8) ATMVFI_ATTN_CASE(9) ATMVFI_ATTN_CASE(10)
@@ -232,12 +236,12 @@ extern "C" int atmvfi_window_attn_cross_motion(const float* qkv, float* out, flo
                                                 int Bw, int nW, int ws, int heads, int hd, void* stream) {
     ATMVFI_REQUIRE(motion, ATMVFI_EINVAL, "window_attn_cross_motion: motion output required");
     ATMVFI_REQUIRE(Bw % 2 == 0, ATMVFI_EINVAL, "window_attn_cross_motion: Bw must be even (two frames)");
-    return atmvfi_window_attention(qkv, out, motion, labels, Bw, nW, ws, heads, hd, Bw / 2, stream);
+    return atmvfi_window_attention(qkv, out, motion, labels, Bw, nW, ws, heads, hd, Bw / 2, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int atmvfi_window_attn_self(const float* qkv, float* out, const int32_t* labels, int Bw, int nW, int ws,
                                         int heads, int hd, void* stream) {
-    return atmvfi_window_attention(qkv, out, nullptr, labels, Bw, nW, ws, heads, hd, 0, stream);
+    return atmvfi_window_attention(qkv, out, nullptr, labels, Bw, nW, ws, heads, hd, 0, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int atmvfi_motion_head(const float* motion, const int32_t* row_map, const float* w0, const float* b0,

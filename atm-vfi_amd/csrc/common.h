@@ -15,6 +15,17 @@ int check_launch(const char* what);
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+// compute units of the current device rounded down to a multiple of 8 (persistent grids keep block % 8 == XCD group)
+static inline int cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8)
+            cus = 256;
+        n = cus / 8 * 8;
+    }
+    return n;
+}
 
 }  // namespace atmvfi
 
@@ -27,6 +38,39 @@ static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b;
     } while (0)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// Output of a row-producing kernel: fp32 rows, and/or the split-plane pair (hi = fp16(x), lo = fp16((x - hi) * 1024), both
+// saturating) that the split GEMM (gemm_split.hip) reads by LDS-DMA.  Either side may be null.
+struct RowSink {
+    float* f32;
+    long long ld;
+    _Float16* hi;
+    _Float16* lo;
+    long long pl_ld;
+};
+__device__ __forceinline__ void sink_store4(const RowSink& s, long long row, int c, const f32x4 v) {
+    if (s.f32) *reinterpret_cast<f32x4*>(s.f32 + row * s.ld + c) = v;
+    if (s.hi) {
+        const float x[4] = {v.x, v.y, v.z, v.w};
+        f16x4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const _Float16 hh = (_Float16)fminf(fmaxf(x[e], -65504.0f), 65504.0f);
+            h[e] = hh;
+            l[e] = (_Float16)fminf(fmaxf((x[e] - (float)hh) * 1024.0f, -65504.0f), 65504.0f);
+        }
+        *reinterpret_cast<f16x4*>(s.hi + row * s.pl_ld + c) = h;
+        *reinterpret_cast<f16x4*>(s.lo + row * s.pl_ld + c) = l;
+    }
+}
+static inline bool sink_ok(const void* f32, int ld, int C, const void* hi, const void* lo, int pl_ld) {
+    if (!f32 && !hi) return false;
+    if (f32 && (ld % 4 != 0 || ld < C || (reinterpret_cast<uintptr_t>(f32) & 15u))) return false;
+    if ((hi == nullptr) != (lo == nullptr)) return false;
+    if (hi && (pl_ld % 8 != 0 || pl_ld < C || (reinterpret_cast<uintptr_t>(hi) & 15u) || (reinterpret_cast<uintptr_t>(lo) & 15u))) return false;
+    return true;
+}
 
 // exact GELU (erf form), as nn.GELU() default
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

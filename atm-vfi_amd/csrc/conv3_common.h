@@ -19,6 +19,7 @@ struct Conv3Dev {
     const float* bias;
     const float* prelu;
     int tiles_x, tiles_y;
+    int nblocks;    // column blocks per spatial tile (set by the launcher)
     unsigned long long* stamp;   // diagnostic builds only (ATMVFI_STAMP)
 };
 // conv3x3_f16x3_row.hip: three taps (one kernel row) per stage, single-buffered halo

@@ -43,13 +43,19 @@ __global__ __launch_bounds__(512) void conv3x3_f16x3_row_kernel(const Conv3Dev a
     const int r = lane & 15;
     const int g = lane >> 4;
 
-    int bid = blockIdx.x;
+    // XCD-aware order: blocks b and b+8 share an XCD, so the column blocks that re-read one halo tile are dealt to
+    // one XCD back to back (halo from HBM once, from that XCD's L2 afterwards)
+    const int slot = blockIdx.x >> 3;
+    const int sgrp = slot / a.nblocks;
+    const int nblk = slot - sgrp * a.nblocks;
+    int bid = sgrp * 8 + (blockIdx.x & 7);
+    if (bid >= a.N * a.tiles_x * a.tiles_y) return;
     const int txb = bid % a.tiles_x;
     bid /= a.tiles_x;
     const int tyb = bid % a.tiles_y;
     const int img = bid / a.tiles_y;
     const int ox0 = txb * TW, oy0 = tyb * TH;
-    const int n0 = blockIdx.y * BN;
+    const int n0 = nblk * BN;
 
     // ---- halo tasks: T = tid + 512*k -> (halo pixel, 8-channel group) ----
     const float* hsrc[HALO_TPT];
@@ -277,7 +283,7 @@ __global__ __launch_bounds__(512) void conv3x3_f16x3_row_kernel(const Conv3Dev a
     STAMP(6)
 #ifdef ATMVFI_STAMP
     if (a.stamp && lane == 0) {
-        unsigned long long* o = a.stamp + (((long long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 8;
+        unsigned long long* o = a.stamp + ((long long)blockIdx.x * 8 + wave) * 8;
         for (int k = 0; k < 8; ++k) o[k] = st_[k];
     }
 #endif
@@ -294,14 +300,15 @@ int launch_row(const Conv3Dev& d, int ntiles, hipStream_t s) {
         ATMVFI_REQUIRE(e == hipSuccess, ATMVFI_ELAUNCH, "conv3x3_f16x3_row: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    dim3 grid((unsigned)((long long)d.N * d.tiles_x * d.tiles_y), (unsigned)((ntiles + WN - 1) / WN));
-#ifdef ATMVFI_STAMP
     Conv3Dev ds = d;
+    ds.nblocks = (ntiles + WN - 1) / WN;
+    const long long sgroups = ((long long)d.N * d.tiles_x * d.tiles_y + 7) / 8;
+    ATMVFI_REQUIRE(sgroups * 8 * ds.nblocks < (1LL << 31), ATMVFI_EINVAL, "conv3x3_f16x3_row: grid too large");
+    dim3 grid((unsigned)(sgroups * 8 * ds.nblocks));
+#ifdef ATMVFI_STAMP
     ds.stamp = g_stamp_buf;
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, ds);
-#else
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, d);
 #endif
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, ds);
     return atmvfi::check_launch("conv3x3_f16x3_row");
 }
 

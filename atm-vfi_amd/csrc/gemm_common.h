@@ -39,6 +39,12 @@ struct GemmDev {
     int cpt32;        // 32-channel chunks per tap
     int nchunks32;    // taps * cpt32
     int ktot32;       // halves per split weight row = taps * cin_pad32
+    const _Float16* a_hi;   // split-plane activations (gemm_split.hip), else null
+    const _Float16* a_lo;
+    unsigned long long* stamp;   // diagnostic builds only (ATMVFI_STAMP)
+    int dbg;          // diagnostic ablations (gemm_split.hip, env ATMVFI_SPLIT_DEBUG): 1 = no stores, 2 = one k-step
+    int vblocks;      // virtual blocks (tiles incl. XCD padding) walked by the persistent grid
+    int nblocks;      // column blocks per row tile (set by the launcher; XCD-aware tile order)
 };
 
 
@@ -124,5 +130,7 @@ __device__ __forceinline__ void gemm_store4(const GemmDev& a, float* orow, const
 
 // gemm_f16x3.hip
 int launch_gemm_f16x3(const GemmDev& d, int ngemm, hipStream_t stream);
+// gemm_split.hip (LINEAR rows read from fp16 hi/lo planes by LDS-DMA)
+int launch_gemm_split(const GemmDev& d, int ngemm, hipStream_t stream);
 
 }  // namespace atmvfi

@@ -248,16 +248,25 @@ extern "C" int atmvfi_pack_weight(int mode, const float* src, float* dst, int Co
 
 extern "C" int atmvfi_gemm(const atmvfi_gemm_params* p, void* stream) {
     ATMVFI_REQUIRE(p, ATMVFI_EINVAL, "gemm: null params");
-    ATMVFI_REQUIRE(p->in && p->weight && p->out, ATMVFI_EINVAL, "gemm: null tensor pointer");
+    const bool planes = p->in_hi || p->in_lo;
+    ATMVFI_REQUIRE((p->in || planes) && p->weight && p->out, ATMVFI_EINVAL, "gemm: null tensor pointer");
+    if (planes) {
+        ATMVFI_REQUIRE(p->in_hi && p->in_lo && p->precision == ATMVFI_PREC_F16X3 && p->mode == ATMVFI_GEMM_LINEAR && !p->in_prelu,
+                       ATMVFI_EINVAL, "gemm: split-plane input needs both planes, precision f16x3, LINEAR mode and no in_prelu");
+        ATMVFI_REQUIRE(p->in_ld % 8 == 0 && p->in_gstride % 8 == 0 && atmvfi::aligned16(p->in_hi) && atmvfi::aligned16(p->in_lo),
+                       ATMVFI_EALIGN, "gemm: split planes need 16-byte aligned pointers, in_ld/in_gstride multiples of 8 halves");
+        ATMVFI_REQUIRE(p->in_ld >= atmvfi::round_up(p->Cin, 32), ATMVFI_EALIGN, "gemm: split-plane rows must hold round_up(Cin,32)=%d halves (in_ld %d)",
+                       atmvfi::round_up(p->Cin, 32), p->in_ld);
+    }
     ATMVFI_REQUIRE(p->mode >= 0 && p->mode <= 2, ATMVFI_EINVAL, "gemm: bad mode %d", p->mode);
     ATMVFI_REQUIRE(p->Cin > 0 && p->Cout > 0, ATMVFI_EINVAL, "gemm: bad channel counts");
-    ATMVFI_REQUIRE(p->in_ld >= atmvfi::round_up(p->Cin, 4) && p->in_ld % 4 == 0, ATMVFI_EALIGN,
+    ATMVFI_REQUIRE(planes || (p->in_ld >= atmvfi::round_up(p->Cin, 4) && p->in_ld % 4 == 0), ATMVFI_EALIGN,
                    "gemm: in_ld %d must be a multiple of 4 and >= Cin rounded to 4 (Cin %d)", p->in_ld, p->Cin);
     ATMVFI_REQUIRE(p->out_ld % 4 == 0 && p->out_ld >= atmvfi::round_up(p->Cout, 4), ATMVFI_EALIGN,
                    "gemm: out_ld %d must be a multiple of 4 and >= Cout rounded to 4 (Cout %d)", p->out_ld, p->Cout);
-    ATMVFI_REQUIRE(atmvfi::aligned16(p->in) && atmvfi::aligned16(p->out) && atmvfi::aligned16(p->weight), ATMVFI_EALIGN,
+    ATMVFI_REQUIRE((planes || atmvfi::aligned16(p->in)) && atmvfi::aligned16(p->out) && atmvfi::aligned16(p->weight), ATMVFI_EALIGN,
                    "gemm: in/out/weight must be 16-byte aligned");
-    ATMVFI_REQUIRE(p->in_gstride % 4 == 0 && p->out_gstride % 4 == 0, ATMVFI_EALIGN, "gemm: group strides must be multiples of 4");
+    ATMVFI_REQUIRE((planes || p->in_gstride % 4 == 0) && p->out_gstride % 4 == 0, ATMVFI_EALIGN, "gemm: group strides must be multiples of 4");
     if (p->residual)
         ATMVFI_REQUIRE(p->res_ld >= p->Cout, ATMVFI_EINVAL, "gemm: res_ld %d < Cout %d", p->res_ld, p->Cout);
     if (p->in_prelu) ATMVFI_REQUIRE(atmvfi::aligned16(p->in_prelu), ATMVFI_EALIGN, "gemm: in_prelu must be 16-byte aligned");
@@ -306,6 +315,12 @@ extern "C" int atmvfi_gemm(const atmvfi_gemm_params* p, void* stream) {
     d.out_row_map = p->out_row_map;
     d.bias = p->bias; d.prelu = p->prelu; d.in_prelu = p->in_prelu; d.residual = p->residual; d.res_ld = p->res_ld;
     ATMVFI_REQUIRE(d.M < (1ll << 40), ATMVFI_EINVAL, "gemm: M too large");
+    d.a_hi = (const _Float16*)p->in_hi;
+    d.a_lo = (const _Float16*)p->in_lo;
+    d.nblocks = 0;
+    d.dbg = 0;
+    d.vblocks = 0;
+    d.stamp = nullptr;
     d.w_hi = (const _Float16*)p->weight_hi;
     d.w_lo = (const _Float16*)p->weight_lo;
     d.cin_pad32 = atmvfi::round_up(p->Cin, 32);
@@ -316,6 +331,7 @@ extern "C" int atmvfi_gemm(const atmvfi_gemm_params* p, void* stream) {
         ATMVFI_REQUIRE(p->weight_hi && p->weight_lo, ATMVFI_EINVAL, "gemm: precision f16x3 needs weight_hi/weight_lo");
         ATMVFI_REQUIRE(atmvfi::aligned16(p->weight_hi) && atmvfi::aligned16(p->weight_lo), ATMVFI_EALIGN,
                        "gemm: split weights must be 16-byte aligned");
+        if (planes) return atmvfi::launch_gemm_split(d, ngemm, (hipStream_t)stream);
         return atmvfi::launch_gemm_f16x3(d, ngemm, (hipStream_t)stream);
     }
 

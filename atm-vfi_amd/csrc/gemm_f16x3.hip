@@ -15,6 +15,15 @@
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+#ifdef ATMVFI_STAMP
+// Diagnostic build only (`make stamp`, tools/stamp_gemm.py): per-wave tick sums of the phases of the persistent loop.
+static unsigned long long* g_gemm_stamp = nullptr;
+extern "C" void atmvfi_debug_set_gemm_stamp_buffer(void* p) { g_gemm_stamp = (unsigned long long*)p; }
+#define GSTAMP(k) do { if (a.stamp) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tsum[k] += t_ - tlast; tlast = t_; } } while (0)
+#else
+#define GSTAMP(k) do { } while (0)
+#endif
+
 namespace {
 
 using atmvfi::GemmDev;
@@ -51,42 +60,19 @@ __global__ __launch_bounds__(512) void gemm_f16x3_kernel(const GemmDev a) {
     const int wave = tid >> 6;
     const int r = lane & 15;
     const int g = lane >> 4;
-    const long long m0 = (long long)blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
-
-    // ---- A tasks: T = tid + 512*i -> (row = T>>2, 8-channel group q = T&3) ----
+    // ---- A tasks: T = tid + 512*i -> (row = T>>2, 8-channel group q = T&3); weight pieces: P = tid + 512*k ----
     const int q = tid & 3;
     const float* rbase[2];
     int iy0[2], ix0[2], adst[2];
     bool rok[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (tid >> 2) + 128 * i;
-        const long long m = m0 + row;
-        rok[i] = m < a.M;
-        const long long mm = rok[i] ? m : 0;
-        if (a.mode == ATMVFI_GEMM_CONV) {
-            const int hw = a.Ho * a.Wo;
-            const int n = (int)(mm / hw);
-            const int rem = (int)(mm - (long long)n * hw);
-            const int oy = rem / a.Wo;
-            const int ox = rem - oy * a.Wo;
-            iy0[i] = oy * a.stride - a.pad;
-            ix0[i] = ox * a.stride - a.pad;
-            rbase[i] = a.in + (((long long)n * a.H + iy0[i]) * a.W + ix0[i]) * a.in_ld;
-        } else {
-            iy0[i] = 0;
-            ix0[i] = 0;
-            const long long off = (a.in_rpg > 0) ? (mm / a.in_rpg) * a.in_gstride + (mm % a.in_rpg) * (long long)a.in_ld
-                                                 : mm * (long long)a.in_ld;
-            rbase[i] = a.in + off;
-        }
-        adst[i] = row * 32 + ((q ^ swz64(row)) << 3);
-    }
-    // ---- weight pieces: P = tid + 512*k -> (plane, row, slot) ----
     const _Float16* wsrc[B_PPT];
     int wdst[B_PPT];
     bool wok[B_PPT], wact[B_PPT], wlo[B_PPT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (tid >> 2) + 128 * i;
+        adst[i] = row * 32 + ((q ^ swz64(row)) << 3);
+    }
 #pragma unroll
     for (int k = 0; k < B_PPT; ++k) {
         const int P = tid + 512 * k;
@@ -94,12 +80,55 @@ __global__ __launch_bounds__(512) void gemm_f16x3_kernel(const GemmDev a) {
         const int plane = (P >= BN * 4) ? 1 : 0;
         const int rem = P - plane * BN * 4;
         const int row = wact[k] ? (rem >> 2) : 0;
-        const int slot = rem & 3;
         wlo[k] = plane == 1;
-        wok[k] = wact[k] && (n0 + row) < a.wrows;
-        wsrc[k] = (plane ? a.w_lo : a.w_hi) + (long long)(wok[k] ? n0 + row : 0) * a.ktot32 + slot * 8;
-        wdst[k] = row * 32 + ((slot ^ swz64(row)) << 3);
+        wdst[k] = row * 32 + (((rem & 3) ^ swz64(row)) << 3);
     }
+    // XCD-aware tile order.  Virtual blocks b and b+8 share an XCD (and its 4 MiB L2), so the NB column blocks that
+    // re-read one 256-row activation tile are dealt to ONE XCD back to back: the tile comes from HBM once and
+    // from that L2 NB-1 times.  The grid is persistent (a multiple of 8 workgroups, each walking b, b+grid, ...), so
+    // a workgroup stays on the XCD its tiles were dealt to.
+    auto tile_origin = [&](int vb, long long& m0, int& n0) {
+        const int xcd = vb & 7;
+        const int slot = vb >> 3;
+        const int mgrp = slot / a.nblocks;
+        const int nblk = slot - mgrp * a.nblocks;
+        m0 = ((long long)mgrp * 8 + xcd) * BM;
+        n0 = nblk * BN;
+    };
+    auto setup_tile = [&](long long m0, int n0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (tid >> 2) + 128 * i;
+            const long long m = m0 + row;
+            rok[i] = m < a.M;
+            const long long mm = rok[i] ? m : 0;
+            if (a.mode == ATMVFI_GEMM_CONV) {
+                const int hw = a.Ho * a.Wo;
+                const int n = (int)(mm / hw);
+                const int rem = (int)(mm - (long long)n * hw);
+                const int oy = rem / a.Wo;
+                const int ox = rem - oy * a.Wo;
+                iy0[i] = oy * a.stride - a.pad;
+                ix0[i] = ox * a.stride - a.pad;
+                rbase[i] = a.in + (((long long)n * a.H + iy0[i]) * a.W + ix0[i]) * a.in_ld;
+            } else {
+                iy0[i] = 0;
+                ix0[i] = 0;
+                const long long off = (a.in_rpg > 0) ? (mm / a.in_rpg) * a.in_gstride + (mm % a.in_rpg) * (long long)a.in_ld
+                                                     : mm * (long long)a.in_ld;
+                rbase[i] = a.in + off;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < B_PPT; ++k) {
+            const int P = tid + 512 * k;
+            const int plane = (P >= BN * 4) ? 1 : 0;
+            const int rem = P - plane * BN * 4;
+            const int row = wact[k] ? (rem >> 2) : 0;
+            wok[k] = wact[k] && (n0 + row) < a.wrows;
+            wsrc[k] = (plane ? a.w_lo : a.w_hi) + (long long)(wok[k] ? n0 + row : 0) * a.ktot32 + (rem & 3) * 8;
+        }
+    };
 
     f32x4 acc[2][WN], cor[2][WN];
 #pragma unroll
@@ -110,8 +139,8 @@ __global__ __launch_bounds__(512) void gemm_f16x3_kernel(const GemmDev a) {
             cor[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
 
-    f32x4 ra[2][2];
-    int anv[2], ac[2];
+    f32x4 ra[2][2], rp[2][2];              // rp: in_prelu slopes of the same 8 channels, fetched WITH the activations
+    int anv[2];
     f16x8 wr[B_PPT];
 
     auto load_chunk = [&](int kc) {
@@ -133,9 +162,13 @@ __global__ __launch_bounds__(512) void gemm_f16x3_kernel(const GemmDev a) {
             const f32x4 va = *reinterpret_cast<const f32x4*>(p);
             const f32x4 vb = *reinterpret_cast<const f32x4*>(p + (nv > 4 ? 4 : 0));
             anv[i] = nv;                       // masking / in_prelu happen at store time: no early consumer of the loads
-            ac[i] = ok ? c : 0;
             ra[i][0] = va;
             ra[i][1] = vb;
+            if (a.in_prelu) {                  // host pads in_prelu to a multiple of 32 (uniform branch); a load issued at
+                const int pc = ok ? c : 0;     // store time instead exposed an L2 round trip per chunk (deconv stages: 88 TF/s)
+                rp[i][0] = *reinterpret_cast<const f32x4*>(a.in_prelu + pc);
+                rp[i][1] = *reinterpret_cast<const f32x4*>(a.in_prelu + pc + 4);
+            }
         }
         const long long koff = (long long)kc * 32;
 #pragma unroll
@@ -157,9 +190,8 @@ __global__ __launch_bounds__(512) void gemm_f16x3_kernel(const GemmDev a) {
             vb.y = nv > 5 ? vb.y : 0.f;
             vb.z = nv > 6 ? vb.z : 0.f;
             vb.w = nv > 7 ? vb.w : 0.f;
-            if (a.in_prelu) {       // host pads in_prelu to a multiple of 32 (uniform branch)
-                const f32x4 al = *reinterpret_cast<const f32x4*>(a.in_prelu + ac[i]);
-                const f32x4 bl = *reinterpret_cast<const f32x4*>(a.in_prelu + ac[i] + 4);
+            if (a.in_prelu) {
+                const f32x4 al = rp[i][0], bl = rp[i][1];
                 va.x = va.x > 0.f ? va.x : al.x * va.x;
                 va.y = va.y > 0.f ? va.y : al.y * va.y;
                 va.z = va.z > 0.f ? va.z : al.z * va.z;
@@ -180,64 +212,109 @@ __global__ __launch_bounds__(512) void gemm_f16x3_kernel(const GemmDev a) {
                     wok[k] ? wr[k] : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
     };
 
+    // Persistent tile loop.  The first chunk of the NEXT tile is fetched (registers) before the epilogue of the current
+    // one, so its HBM round trip runs under the epilogue's stores, and those drain under the next k-loop.
+#ifdef ATMVFI_STAMP
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#endif
+    long long m0;
+    int n0;
+    int vb = blockIdx.x;
+    for (;; vb += gridDim.x) {                 // skip virtual blocks past the row count (grid padding to 8 XCDs)
+        if (vb >= a.vblocks) return;
+        tile_origin(vb, m0, n0);
+        if (m0 < a.M) break;
+    }
+    setup_tile(m0, n0);
     load_chunk(0);
-    store_chunk(0);
-    __syncthreads();
-    for (int kc = 0; kc < a.nchunks32; ++kc) {
-        const int buf = kc & 1;
-        if (kc + 1 < a.nchunks32) load_chunk(kc + 1);
-        f16x8 xh[2], xl[2];
+    GSTAMP(0);
+    for (;;) {
+        store_chunk(0);
+        __syncthreads();
+        GSTAMP(1);
+        for (int kc = 0; kc < a.nchunks32; ++kc) {
+            const int buf = kc & 1;
+            if (kc + 1 < a.nchunks32) load_chunk(kc + 1);
+            GSTAMP(2);
+            f16x8 xh[2], xl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = 32 * wave + 16 * i + r;
+                const int off = buf * BM * 32 + row * 32 + ((g ^ swz64(row)) << 3);
+                xh[i] = *reinterpret_cast<const f16x8*>(a_hi + off);
+                xl[i] = *reinterpret_cast<const f16x8*>(a_lo + off);
+            }
+            // weight fragments run two n-tiles ahead of their MFMAs (3-slot ring, static indices, order pinned): left
+            // alone, hipcc folds the ring into one register and stalls on a just-issued ds_read every 6 MFMAs
+            const int wbase = buf * BN * 32 + r * 32 + ((g ^ swz64(r)) << 3);      // swz64(16j + r) == swz64(r)
+            f16x8 wh[3], wl[3];
+            wh[0] = *reinterpret_cast<const f16x8*>(b_hi + wbase);
+            wl[0] = *reinterpret_cast<const f16x8*>(b_lo + wbase);
+            if (WN > 1) {
+                wh[1] = *reinterpret_cast<const f16x8*>(b_hi + wbase + 16 * 32);
+                wl[1] = *reinterpret_cast<const f16x8*>(b_lo + wbase + 16 * 32);
+            }
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                if (j + 2 < WN) {
+                    wh[(j + 2) % 3] = *reinterpret_cast<const f16x8*>(b_hi + wbase + (j + 2) * 16 * 32);
+                    wl[(j + 2) % 3] = *reinterpret_cast<const f16x8*>(b_lo + wbase + (j + 2) * 16 * 32);
+                }
+                const f16x8 ch = wh[j % 3], cl = wl[j % 3];
+                // dependent MFMAs (same accumulator) are kept 4 issues apart
+                cor[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cl, xh[0], cor[0][j], 0, 0, 0);
+                cor[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cl, xh[1], cor[1][j], 0, 0, 0);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, xh[0], acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, xh[1], acc[1][j], 0, 0, 0);
+                cor[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, xl[0], cor[0][j], 0, 0, 0);
+                cor[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, xl[1], cor[1][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            GSTAMP(3);
+            if (kc + 1 < a.nchunks32) store_chunk(buf ^ 1);
+            GSTAMP(4);
+            __syncthreads();
+            GSTAMP(5);
+        }
+
+        // output rows of THIS tile, then the next tile's origin, task set-up and first chunk (in flight under the stores)
+        float* orow[2];
+        const float* rrow[2];
+        bool live[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int row = 32 * wave + 16 * i + r;
-            const int off = buf * BM * 32 + row * 32 + ((g ^ swz64(row)) << 3);
-            xh[i] = *reinterpret_cast<const f16x8*>(a_hi + off);
-            xl[i] = *reinterpret_cast<const f16x8*>(a_lo + off);
+            const long long m = m0 + 32 * wave + 16 * i + r;
+            live[i] = m < a.M && atmvfi::gemm_out_row(a, m, orow[i], rrow[i]);
         }
-        // weight fragments run two n-tiles ahead of their MFMAs (3-slot ring, static indices, order pinned): left
-        // alone, hipcc folds the ring into one register and stalls on a just-issued ds_read every 6 MFMAs
-        const int wbase = buf * BN * 32 + r * 32 + ((g ^ swz64(r)) << 3);      // swz64(16j + r) == swz64(r)
-        f16x8 wh[3], wl[3];
-        wh[0] = *reinterpret_cast<const f16x8*>(b_hi + wbase);
-        wl[0] = *reinterpret_cast<const f16x8*>(b_lo + wbase);
-        if (WN > 1) {
-            wh[1] = *reinterpret_cast<const f16x8*>(b_hi + wbase + 16 * 32);
-            wl[1] = *reinterpret_cast<const f16x8*>(b_lo + wbase + 16 * 32);
+        const int n0_cur = n0;
+        bool more = false;
+        for (vb += gridDim.x; vb < a.vblocks; vb += gridDim.x) {
+            tile_origin(vb, m0, n0);
+            if (m0 < a.M) { more = true; break; }
         }
+        if (more) {
+            setup_tile(m0, n0);
+            load_chunk(0);
+        }
+        GSTAMP(6);
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
-            if (j + 2 < WN) {
-                wh[(j + 2) % 3] = *reinterpret_cast<const f16x8*>(b_hi + wbase + (j + 2) * 16 * 32);
-                wl[(j + 2) % 3] = *reinterpret_cast<const f16x8*>(b_lo + wbase + (j + 2) * 16 * 32);
+            const atmvfi::ChanVec cv = atmvfi::gemm_chan_vec(a, n0_cur + 16 * j + 4 * g);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (live[i]) atmvfi::gemm_store4(a, orow[i], rrow[i], cv, acc[i][j] + cor[i][j] * LO_UNSCALE);
+                acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                cor[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
-            const f16x8 ch = wh[j % 3], cl = wl[j % 3];
-            // dependent MFMAs (same accumulator) are kept 4 issues apart
-            cor[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cl, xh[0], cor[0][j], 0, 0, 0);
-            cor[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cl, xh[1], cor[1][j], 0, 0, 0);
-            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, xh[0], acc[0][j], 0, 0, 0);
-            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, xh[1], acc[1][j], 0, 0, 0);
-            cor[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, xl[0], cor[0][j], 0, 0, 0);
-            cor[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, xl[1], cor[1][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
         }
-        if (kc + 1 < a.nchunks32) store_chunk(buf ^ 1);
-        __syncthreads();
-    }
-
-    float* orow[2];
-    const float* rrow[2];
-    bool live[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const long long m = m0 + 32 * wave + 16 * i + r;
-        live[i] = m < a.M && atmvfi::gemm_out_row(a, m, orow[i], rrow[i]);
-    }
-#pragma unroll
-    for (int j = 0; j < WN; ++j) {
-        const atmvfi::ChanVec cv = atmvfi::gemm_chan_vec(a, n0 + 16 * j + 4 * g);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            if (live[i]) atmvfi::gemm_store4(a, orow[i], rrow[i], cv, acc[i][j] + cor[i][j] * LO_UNSCALE);
+        GSTAMP(7);
+#ifdef ATMVFI_STAMP
+        if (!more && a.stamp && lane == 0) {
+            unsigned long long* o = a.stamp + ((long long)blockIdx.x * 8 + wave) * 8;
+            for (int k = 0; k < 8; ++k) o[k] = tsum[k];
+        }
+#endif
+        if (!more) return;
     }
 }
 
@@ -252,8 +329,18 @@ int launch(const GemmDev& d, int ntiles, hipStream_t s) {
         ATMVFI_REQUIRE(e == hipSuccess, ATMVFI_ELAUNCH, "gemm_f16x3: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    dim3 grid((unsigned)atmvfi::ceil_div64(d.M, 256), (unsigned)((ntiles + WN - 1) / WN));
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, d);
+    GemmDev dd = d;
+    dd.nblocks = (ntiles + WN - 1) / WN;
+    const long long mgroups = (atmvfi::ceil_div64(d.M, 256) + 7) / 8;
+    ATMVFI_REQUIRE(mgroups * 8 * dd.nblocks < (1LL << 31), ATMVFI_EINVAL, "gemm_f16x3: too many tiles");
+    dd.vblocks = (int)(mgroups * 8 * dd.nblocks);
+#ifdef ATMVFI_STAMP
+    dd.stamp = g_gemm_stamp;
+#endif
+    // persistent: one workgroup per CU (LDS and registers allow no more), a multiple of 8 so that b mod 8 is kept
+    const int ncu = atmvfi::cu_count();
+    dim3 grid((unsigned)(dd.vblocks < ncu ? dd.vblocks : ncu));
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, dd);
     return atmvfi::check_launch("gemm_f16x3");
 }
 

@@ -1,0 +1,319 @@
+// Split-plane GEMM for gfx950: the "f16x3" arithmetic of gemm_f16x3.hip on activations that are ALREADY stored as
+// two fp16 planes (hi, lo' = (x - hi) * 1024), so the operand path is pure LDS-DMA:
+//   global_load_lds_dwordx4 (16 B per lane, no VGPR destination, no VALU split) -> 3-stage LDS ring ->
+//   ds_read_b128 fragments -> v_mfma_f32_16x16x32_f16.
+// The fp32-input engine splits every activation tile once per COLUMN block (12x for a 1536-wide layer) on the
+// VALU and stages it through registers; here the producer kernel splits once, in its epilogue.
+//
+// Block = 512 threads = 8 wavefronts as 4 (rows) x 2 (columns); each wave owns 64 rows x 64 columns
+// (4 x 4 MFMA tiles, acc + cor), block tile BM = 256 rows x BN = 128 columns, K in steps of 32.
+// One LDS stage = A_hi[256][32] A_lo[256][32] W_hi[128][32] W_lo[128][32] halves = 48 KiB; three stages.
+// LDS rows are 64 B; the slot swizzle ((row>>2)&1)<<1 is applied on the SOURCE address of the DMA (its
+// destination is lane-linear) and again on the fragment read.
+// Per k-step: s_waitcnt vmcnt(6) (own pieces of this stage landed) -> s_barrier (everyone's landed, everyone is
+// done with the previous stage) -> DMA stage k+2 into the buffer of stage k-1 -> 16 ds_read_b128 + 48 MFMA.
+#include "common.h"
+#include "gemm_common.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+#ifdef ATMVFI_STAMP
+// Diagnostic build only (`make stamp`, tools/stamp_split.py): shader-clock and wall-clock stamps around the k-loop.
+static unsigned long long* g_split_stamp = nullptr;
+extern "C" void atmvfi_debug_set_split_stamp_buffer(void* p) { g_split_stamp = (unsigned long long*)p; }
+#define SPLIT_STAMP(i) do { if (a.stamp) { tstamp[i] = __builtin_amdgcn_s_memtime(); rstamp[i] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define SPLIT_STAMP(i) do { } while (0)
+#endif
+
+namespace {
+
+using atmvfi::GemmDev;
+
+constexpr float LO_UNSCALE = 1.0f / 1024.0f;
+
+__device__ __forceinline__ int swz64(int row) { return ((row >> 2) & 1) << 1; }
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+__device__ __forceinline__ void dma16(const _Float16* src, _Float16* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (lds_ptr_t)lds_wave_base, 16, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// WGM x WGN wavefronts, each owning 64 rows x 64 columns (4 x 4 MFMA tiles, acc + cor); three LDS stages.
+//
+// Software pipeline (per wave, all register indices static):
+//   * the four weight fragment pairs w[j] of a k-step stay in registers for the whole step;
+//   * the activation fragment pairs x[i] sit in a 4-slot ring, fetched two "items" (12 MFMAs each) ahead of use;
+//   * item i = { fetch x[i+2] ; 8 MFMAs (wl*xh, wh*xh) ; 4 MFMAs (wh*xl) }, and the last item refills w[j] for the
+//     NEXT k-step right behind the last MFMA that reads it -- so no ds_read latency is exposed at a step boundary.
+//   * fragments of stage k+1 are first read in item 2 of step k: the one barrier per step sits between items 1 and 2,
+//     behind s_waitcnt vmcnt (own DMA pieces of stage k+1 landed) and lgkmcnt(0) (own reads of stage k complete),
+//     and right after it the DMA for stage k+3 is issued into the buffer stage k just vacated (two steps of lookahead).
+template <int WGM, int WGN>
+__global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_split_kernel(const GemmDev a) {
+    constexpr int NW = WGM * WGN;
+    constexpr int NT = 64 * NW;
+    constexpr int BM = 64 * WGM, BN = 64 * WGN;
+    constexpr int STAGE_HALVES = (2 * BM + 2 * BN) * 32;
+    constexpr int A_LO_OFF = BM * 32, W_HI_OFF = 2 * BM * 32;
+    constexpr int APT = BM * 8 / NT, WPT = BN * 8 / NT;             // 16-byte DMA pieces per thread per stage
+    constexpr int PIECES = APT + WPT;
+    static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "pieces must divide evenly");
+    static_assert(APT == 4 && WPT == 2, "issue_pair assumes 4 + 2 pieces per thread");
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int r = lane & 15;
+    const int g = lane >> 4;
+    const int wm = wave / WGN, wn = wave % WGN;
+
+    // XCD-aware tile order: blocks b and b+8 share an XCD, so the column blocks of one row tile go to one L2
+    const int xcd = blockIdx.x & 7;
+    const int slot = blockIdx.x >> 3;
+    const int mgrp = slot / a.nblocks;
+    const int nblk = slot - mgrp * a.nblocks;
+    const long long m0 = ((long long)mgrp * 8 + xcd) * BM;
+    if (m0 >= a.M) return;
+    const int n0 = nblk * BN;
+
+    // ---- DMA pieces: P = (i*NW + wave)*64 + lane.  A: plane = P / (4*BM), row = (P>>2) % BM, physical slot = lane&3;
+    //      the LDS image is linear in P (hi plane then lo plane), i.e. wave-uniform base + lane*16 B as LDS-DMA requires.
+    const _Float16* asrc[APT];
+    int adst[APT];
+#pragma unroll
+    for (int i = 0; i < APT; ++i) {
+        const int P = (i * NW + wave) * 64 + lane;
+        const int plane = P / (4 * BM);
+        const int row = (P >> 2) % BM;
+        const int ls = (lane & 3) ^ swz64(row);
+        long long m = m0 + row;
+        if (m >= a.M) m = a.M - 1;                                  // tail rows: valid address, result never stored
+        const long long off = (a.in_rpg > 0) ? (m / a.in_rpg) * a.in_gstride + (m % a.in_rpg) * (long long)a.in_ld : m * (long long)a.in_ld;
+        asrc[i] = (plane ? a.a_lo : a.a_hi) + off + ls * 8;
+        adst[i] = (i * NW + wave) * 64 * 8;
+    }
+    const _Float16* wsrc[WPT];
+    int wdst[WPT];
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+        const int P = (i * NW + wave) * 64 + lane;
+        const int plane = P / (4 * BN);
+        const int row = (P >> 2) % BN;
+        const int ls = (lane & 3) ^ swz64(row);
+        int n = n0 + row;
+        if (n >= a.wrows) n = a.wrows - 1;                          // columns past the packed rows: never stored
+        wsrc[i] = (plane ? a.w_lo : a.w_hi) + (long long)n * a.ktot32 + ls * 8;
+        wdst[i] = W_HI_OFF + (i * NW + wave) * 64 * 8;
+    }
+    auto issue = [&](int kc, int buf) {
+        _Float16* st = smem + buf * STAGE_HALVES;
+#pragma unroll
+        for (int i = 0; i < APT; ++i) dma16(asrc[i] + kc * 32, st + adst[i]);
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) dma16(wsrc[i] + kc * 32, st + wdst[i]);
+    };
+    // one third of a stage's pieces (PIECES == 6: A pieces 0-3, W pieces 0-1)
+    auto issue_pair = [&](int kc, int buf, int p) {
+        _Float16* st = smem + buf * STAGE_HALVES;
+        if (p == 0) { dma16(asrc[0] + kc * 32, st + adst[0]); dma16(asrc[1] + kc * 32, st + adst[1]); }
+        if (p == 1) { dma16(asrc[2] + kc * 32, st + adst[2]); dma16(asrc[3] + kc * 32, st + adst[3]); }
+        if (p == 2) { dma16(wsrc[0] + kc * 32, st + wdst[0]); dma16(wsrc[1] + kc * 32, st + wdst[1]); }
+    };
+    // The DMA of one stage is spread over three items (an LDS-DMA instruction holds the wave's issue for 60-180 cycles)
+    // and the two wave groups of a SIMD (waves 0-3 / 4-7) take different items, so one group's MFMAs cover the other's
+    // DMA issue.  slot: 0 = item 2 (right behind the barrier), 1 = item 3, 2 = item 0 of the next step, 3 = item 1.
+    const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
+    int ikc = 0x7fffffff, ibuf = 0;                                      // stage being issued (ikc >= nk: nothing)
+
+    f32x4 acc[4][4], cor[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            cor[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+
+    // fragment offsets (halves) inside a stage; swz64(16*i + row) == swz64(row), so tile i is a constant +16*32*i away
+    const int xrow = 64 * wm + r, wrow = 64 * wn + r;
+    const int xoff = xrow * 32 + ((g ^ swz64(xrow)) << 3);
+    const int woff = W_HI_OFF + wrow * 32 + ((g ^ swz64(wrow)) << 3);
+    f16x8 xh[4], xl[4], wh[4], wl[4];
+    auto load_x = [&](const _Float16* st, int i) {
+        xh[i] = *reinterpret_cast<const f16x8*>(st + xoff + i * 512);
+        xl[i] = *reinterpret_cast<const f16x8*>(st + xoff + i * 512 + A_LO_OFF);
+    };
+    auto mma_main = [&](int i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            cor[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j], xh[i], cor[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xh[i], acc[i][j], 0, 0, 0);
+        }
+    };
+    auto mma_cross = [&](int i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cor[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xl[i], cor[i][j], 0, 0, 0);
+    };
+
+#ifdef ATMVFI_STAMP
+    unsigned long long tstamp[4], rstamp[4];
+#endif
+    SPLIT_STAMP(0);
+    const int nk = (a.dbg & 2) ? 1 : a.nchunks32;
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    if (nk > 2) issue(2, 2);
+    if (nk > 2) wait_vmcnt<2 * PIECES>();
+    else if (nk > 1) wait_vmcnt<PIECES>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        wh[j] = *reinterpret_cast<const f16x8*>(smem + woff + j * 512);
+        wl[j] = *reinterpret_cast<const f16x8*>(smem + woff + j * 512 + BN * 32);
+    }
+    load_x(smem, 0);
+    load_x(smem, 1);
+
+    int buf = 0;
+    SPLIT_STAMP(1);
+    for (int kc = 0; kc < nk; ++kc) {
+        const _Float16* st = smem + buf * STAGE_HALVES;
+        const int nbuf = buf == 2 ? 0 : buf + 1;
+        const _Float16* sn = smem + nbuf * STAGE_HALVES;
+        const bool more = kc + 1 < nk;
+        // item 0
+        load_x(st, 2);
+        if (ikc < nk) issue_pair(ikc, ibuf, 2 - grp);
+        mma_main(0);
+        mma_cross(0);
+        __builtin_amdgcn_sched_barrier(0);
+        // item 1
+        load_x(st, 3);
+        if (ikc < nk && grp == 1) issue_pair(ikc, ibuf, 2);
+        mma_main(1);
+        mma_cross(1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+            // stage kc+1: own DMA pieces landed (stage kc+2 may still be in flight); own reads of stage kc complete
+            if (kc + 2 < nk) wait_vmcnt<PIECES>();
+            else wait_vmcnt<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            ikc = kc + 3;
+            ibuf = buf;
+            load_x(sn, 0);
+            if (ikc < nk && grp == 0) issue_pair(ikc, ibuf, 0);
+        } else {
+            ikc = 0x7fffffff;
+        }
+        // item 2
+        mma_main(2);
+        mma_cross(2);
+        __builtin_amdgcn_sched_barrier(0);
+        // item 3 (+ weight fragments of the next step, each right behind the last MFMA that reads the old one)
+        if (more) load_x(sn, 1);
+        if (ikc < nk) issue_pair(ikc, ibuf, 1 - grp);
+        mma_main(3);
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wl[j] = *reinterpret_cast<const f16x8*>(sn + woff + j * 512 + BN * 32);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            cor[3][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xl[3], cor[3][j], 0, 0, 0);
+            if (more) wh[j] = *reinterpret_cast<const f16x8*>(sn + woff + j * 512);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        buf = nbuf;
+    }
+    SPLIT_STAMP(2);
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long long m = m0 + 64 * wm + 16 * i + r;
+        float* orow;
+        const float* rrow;
+        bool live = m < a.M && atmvfi::gemm_out_row(a, m, orow, rrow);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const atmvfi::ChanVec cv = atmvfi::gemm_chan_vec(a, n0 + 64 * wn + 16 * j + 4 * g);
+            if ((a.dbg & 1) && acc[i][j].x != 12345.678f) live = false;
+            if (live) atmvfi::gemm_store4(a, orow, rrow, cv, acc[i][j] + cor[i][j] * LO_UNSCALE);
+        }
+    }
+#ifdef ATMVFI_STAMP
+    SPLIT_STAMP(3);
+    if (a.stamp && lane == 0) {
+        unsigned long long* o = a.stamp + ((long long)blockIdx.x * NW + wave) * 8;
+        for (int k = 0; k < 3; ++k) { o[k] = tstamp[k + 1] - tstamp[k]; o[4 + k] = rstamp[k + 1] - rstamp[k]; }
+        o[3] = (unsigned long long)nk;
+    }
+#endif
+}
+
+// fp32 rows -> (hi, lo') planes; one thread per 8 channels.  Pad channels (>= C, < ld_out) are written as zero.
+__global__ void split_planes_kernel(const float* __restrict__ in, int in_ld, long long M, int C, _Float16* hi, _Float16* lo, int ld) {
+    const int groups = ld / 8;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= M * groups) return;
+    const long long m = t / groups;
+    const int c0 = (int)(t - m * groups) * 8;
+    f16x8 h, l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = (c0 + e < C) ? in[m * in_ld + c0 + e] : 0.f;
+        const _Float16 hh = (_Float16)fminf(fmaxf(x, -65504.0f), 65504.0f);
+        h[e] = hh;
+        l[e] = (_Float16)fminf(fmaxf((x - (float)hh) * 1024.0f, -65504.0f), 65504.0f);
+    }
+    *reinterpret_cast<f16x8*>(hi + m * ld + c0) = h;
+    *reinterpret_cast<f16x8*>(lo + m * ld + c0) = l;
+}
+
+template <int WGM, int WGN>
+int launch_split(const GemmDev& d, int ngemm, hipStream_t s) {
+    constexpr int BM = 64 * WGM, BN = 64 * WGN;
+    const size_t lds = (size_t)3 * (2 * BM + 2 * BN) * 32 * sizeof(_Float16);
+    auto kern = gemm_split_kernel<WGM, WGN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        ATMVFI_REQUIRE(e == hipSuccess, ATMVFI_ELAUNCH, "gemm_split: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    GemmDev dd = d;
+    static const int dbg = [] { const char* e = getenv("ATMVFI_SPLIT_DEBUG"); return e ? atoi(e) : 0; }();
+    dd.dbg = dbg;
+#ifdef ATMVFI_STAMP
+    dd.stamp = g_split_stamp;
+#endif
+    dd.nblocks = (ngemm + BN - 1) / BN;
+    const long long mgroups = (atmvfi::ceil_div64(d.M, BM) + 7) / 8;
+    ATMVFI_REQUIRE(mgroups * 8 * dd.nblocks < (1LL << 31), ATMVFI_EINVAL, "gemm_split: grid too large");
+    hipLaunchKernelGGL(kern, dim3((unsigned)(mgroups * 8 * dd.nblocks)), dim3(64 * WGM * WGN), lds, s, dd);
+    return atmvfi::check_launch("gemm_split");
+}
+
+}  // namespace
+
+int atmvfi::launch_gemm_split(const GemmDev& d, int ngemm, hipStream_t s) {
+    return launch_split<4, 2>(d, ngemm, s);
+}
+
+extern "C" int atmvfi_split_planes(const float* in, int in_ld, int64_t M, int C, void* hi, void* lo, int ld, void* stream) {
+    ATMVFI_REQUIRE(in && hi && lo && M > 0 && C > 0, ATMVFI_EINVAL, "split_planes: bad arguments");
+    ATMVFI_REQUIRE(ld % 8 == 0 && ld >= C && in_ld >= C, ATMVFI_EALIGN, "split_planes: ld %d must be a multiple of 8 and >= C %d", ld, C);
+    ATMVFI_REQUIRE(atmvfi::aligned16(hi) && atmvfi::aligned16(lo), ATMVFI_EALIGN, "split_planes: planes must be 16-byte aligned");
+    const long long n = (long long)M * (ld / 8);
+    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, in_ld, (long long)M, C,
+                       (_Float16*)hi, (_Float16*)lo, ld);
+    return atmvfi::check_launch("split_planes");
+}

@@ -12,18 +12,17 @@ namespace {
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ in, int in_ld, long long in_gstride,
                                                         int in_rpg, const int* __restrict__ src_map,
-                                                        float* __restrict__ out, int out_ld,
+                                                        const RowSink out,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         long long rows, int C) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    float* orow = out + row * (long long)out_ld;
     const int c4n = C >> 2;
     long long src = src_map ? src_map[row] : row;
     if (src < 0) {   // zero-padded token: LayerNorm(0) == beta exactly
         for (int i = lane; i < c4n; i += 64)
-            *reinterpret_cast<f32x4*>(orow + 4 * i) = *reinterpret_cast<const f32x4*>(beta + 4 * i);
+            sink_store4(out, row, 4 * i, *reinterpret_cast<const f32x4*>(beta + 4 * i));
         return;
     }
     const float* irow = in + ((in_rpg > 0) ? (src / in_rpg) * in_gstride + (src % in_rpg) * (long long)in_ld
@@ -54,7 +53,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         y.y = (v.y - mean) * rstd * gm.y + bt.y;
         y.z = (v.z - mean) * rstd * gm.z + bt.z;
         y.w = (v.w - mean) * rstd * gm.w + bt.w;
-        *reinterpret_cast<f32x4*>(orow + 4 * i) = y;
+        sink_store4(out, row, 4 * i, y);
     }
 }
 
@@ -62,7 +61,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // depth-wise 3x3 (pad 1) + bias + exact GELU, NHWC, 4 channels per lane
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dwconv_gelu_kernel(const float* __restrict__ in, int in_ld,
-                                                          float* __restrict__ out, int out_ld,
+                                                          const RowSink out,
                                                           const float* __restrict__ w9, const float* __restrict__ bias,
                                                           int N, int H, int W, int C) {
     const int c4n = C >> 2;
@@ -95,7 +94,7 @@ __global__ __launch_bounds__(256) void dwconv_gelu_kernel(const float* __restric
         o.y = gelu_erf(acc.y);
         o.z = gelu_erf(acc.z);
         o.w = gelu_erf(acc.w);
-        *reinterpret_cast<f32x4*>(out + pix * out_ld + c) = o;
+        sink_store4(out, pix, c, o);
     }
 }
 
@@ -106,7 +105,7 @@ __global__ __launch_bounds__(256) void dwconv_gelu_kernel(const float* __restric
 // (measured on the per-pixel kernel: 7x the algorithmic read traffic, profiles/r01_pmc_hbm_traffic.json).
 template <int RS>
 __global__ __launch_bounds__(256) void dwconv_gelu_rows_kernel(const float* __restrict__ in, int in_ld,
-                                                               float* __restrict__ out, int out_ld,
+                                                               const RowSink out,
                                                                const float* __restrict__ w9, const float* __restrict__ bias,
                                                                int N, int H, int W, int C, int xblocks, int cblocks, int strips) {
     int bid = blockIdx.x;
@@ -161,7 +160,7 @@ __global__ __launch_bounds__(256) void dwconv_gelu_rows_kernel(const float* __re
             o.y = gelu_erf(acc.y);
             o.z = gelu_erf(acc.z);
             o.w = gelu_erf(acc.w);
-            *reinterpret_cast<f32x4*>(out + (((long long)n * H + y) * W + x) * out_ld + c) = o;
+            sink_store4(out, ((long long)n * H + y) * W + x, c, o);
         }
     }
 }
@@ -410,24 +409,31 @@ inline unsigned grid_for(long long total) {
 
 extern "C" int atmvfi_layernorm(const float* in, int in_ld, int64_t in_gstride, int in_rpg, const int32_t* src_row_map,
                                  float* out, int out_ld, const float* gamma, const float* beta, int64_t rows, int C,
-                                 void* stream) {
-    ATMVFI_REQUIRE(in && out && gamma && beta, ATMVFI_EINVAL, "layernorm: null pointer");
+                                 void* out_hi, void* out_lo, int plane_ld, void* stream) {
+    ATMVFI_REQUIRE(in && gamma && beta, ATMVFI_EINVAL, "layernorm: null pointer");
     ATMVFI_REQUIRE(rows > 0 && C > 0 && C % 4 == 0, ATMVFI_EINVAL, "layernorm: C %d must be a positive multiple of 4", C);
-    ATMVFI_REQUIRE(in_ld % 4 == 0 && out_ld % 4 == 0 && in_ld >= C && out_ld >= C && in_gstride % 4 == 0, ATMVFI_EALIGN,
+    ATMVFI_REQUIRE(in_ld % 4 == 0 && in_ld >= C && in_gstride % 4 == 0, ATMVFI_EALIGN,
                    "layernorm: leading dimensions must be multiples of 4 and >= C");
-    ATMVFI_REQUIRE(atmvfi::aligned16(in) && atmvfi::aligned16(out) && atmvfi::aligned16(gamma) && atmvfi::aligned16(beta),
+    ATMVFI_REQUIRE(sink_ok(out, out_ld, C, out_hi, out_lo, plane_ld), ATMVFI_EALIGN,
+                   "layernorm: output needs fp32 rows (ld %% 4 == 0) and/or both fp16 planes (ld %% 8 == 0), 16-byte aligned, ld >= C");
+    ATMVFI_REQUIRE(atmvfi::aligned16(in) && atmvfi::aligned16(gamma) && atmvfi::aligned16(beta),
                    ATMVFI_EALIGN, "layernorm: pointers must be 16-byte aligned");
     const unsigned blocks = (unsigned)((rows + 3) / 4);
+    const RowSink sink{out, out_ld, (_Float16*)out_hi, (_Float16*)out_lo, plane_ld};
     hipLaunchKernelGGL(layernorm_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, in_ld, (long long)in_gstride,
-                       in_rpg, src_row_map, out, out_ld, gamma, beta, (long long)rows, C);
+                       in_rpg, src_row_map, sink, gamma, beta, (long long)rows, C);
     return atmvfi::check_launch("layernorm");
 }
 
 extern "C" int atmvfi_dwconv3x3_gelu(const float* in, int in_ld, float* out, int out_ld, const float* weight9,
-                                      const float* bias, int N, int H, int W, int C, void* stream) {
-    ATMVFI_REQUIRE(in && out && weight9 && bias, ATMVFI_EINVAL, "dwconv3x3_gelu: null pointer");
+                                      const float* bias, int N, int H, int W, int C, void* out_hi, void* out_lo,
+                                      int plane_ld, void* stream) {
+    ATMVFI_REQUIRE(in && weight9 && bias, ATMVFI_EINVAL, "dwconv3x3_gelu: null pointer");
     ATMVFI_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, ATMVFI_EINVAL, "dwconv3x3_gelu: bad shape");
-    ATMVFI_REQUIRE(in_ld % 4 == 0 && out_ld % 4 == 0 && in_ld >= C && out_ld >= C, ATMVFI_EALIGN, "dwconv3x3_gelu: bad ld");
+    ATMVFI_REQUIRE(in_ld % 4 == 0 && in_ld >= C, ATMVFI_EALIGN, "dwconv3x3_gelu: bad ld");
+    ATMVFI_REQUIRE(sink_ok(out, out_ld, C, out_hi, out_lo, plane_ld), ATMVFI_EALIGN,
+                   "dwconv3x3_gelu: output needs fp32 rows (ld %% 4 == 0) and/or both fp16 planes (ld %% 8 == 0), 16-byte aligned, ld >= C");
+    const RowSink sink{out, out_ld, (_Float16*)out_hi, (_Float16*)out_lo, plane_ld};
     ATMVFI_REQUIRE(atmvfi::aligned16(in) && atmvfi::aligned16(out) && atmvfi::aligned16(weight9) && atmvfi::aligned16(bias),
                    ATMVFI_EALIGN, "dwconv3x3_gelu: pointers must be 16-byte aligned");
     if (C % 64 == 0) {     // sliding-window kernel: 16 x-positions x 64 channels per block, 8-row strips
@@ -435,12 +441,12 @@ extern "C" int atmvfi_dwconv3x3_gelu(const float* in, int in_ld, float* out, int
         const int xblocks = (W + 15) / 16, cblocks = C / 64, strips = (H + RS - 1) / RS;
         const long long blocks = (long long)N * strips * xblocks * cblocks;
         ATMVFI_REQUIRE(blocks < (1ll << 31), ATMVFI_EINVAL, "dwconv3x3_gelu: grid too large");
-        hipLaunchKernelGGL(dwconv_gelu_rows_kernel<RS>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, in_ld, out,
-                           out_ld, weight9, bias, N, H, W, C, xblocks, cblocks, strips);
+        hipLaunchKernelGGL(dwconv_gelu_rows_kernel<RS>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, in_ld, sink,
+                           weight9, bias, N, H, W, C, xblocks, cblocks, strips);
         return atmvfi::check_launch("dwconv3x3_gelu");
     }
     const long long total = (long long)N * H * W * (C / 4);
-    hipLaunchKernelGGL(dwconv_gelu_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, in_ld, out, out_ld,
+    hipLaunchKernelGGL(dwconv_gelu_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, in_ld, sink,
                        weight9, bias, N, H, W, C);
     return atmvfi::check_launch("dwconv3x3_gelu");
 }

@@ -50,6 +50,7 @@ class GemmParams(ctypes.Structure):
         ("bias", c_f), ("prelu", c_f), ("in_prelu", c_f), ("residual", c_f),
         ("res_ld", ctypes.c_int32),
         ("precision", ctypes.c_int32), ("weight_hi", c_f), ("weight_lo", c_f),
+        ("in_hi", c_f), ("in_lo", c_f),
     ]
 
 
@@ -58,6 +59,7 @@ SIGNATURES = {
     "atmvfi_version": (c_i, []),
     "atmvfi_last_error": (ctypes.c_char_p, []),
     "atmvfi_gemm": (c_i, [ctypes.POINTER(GemmParams), c_f]),
+    "atmvfi_split_planes": (c_i, [c_f, c_i, c_l, c_i, c_f, c_f, c_i, c_f]),
     "atmvfi_conv2d": (c_i, [ctypes.POINTER(GemmParams), c_f]),
     "atmvfi_linear": (c_i, [ctypes.POINTER(GemmParams), c_f]),
     "atmvfi_deconv2x2": (c_i, [ctypes.POINTER(GemmParams), c_f]),
@@ -66,10 +68,10 @@ SIGNATURES = {
     "atmvfi_split_weight_halves": (c_l, [c_i, c_i, c_i, c_i, c_i]),
     "atmvfi_pack_weight_split": (c_i, [c_i, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     "atmvfi_conv3x3_f16x3": (c_i, [c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_i, c_f, c_f, c_f]),
-    "atmvfi_layernorm": (c_i, [c_f, c_i, c_l, c_i, c_f, c_f, c_i, c_f, c_f, c_l, c_i, c_f]),
-    "atmvfi_dwconv3x3_gelu": (c_i, [c_f, c_i, c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
+    "atmvfi_layernorm": (c_i, [c_f, c_i, c_l, c_i, c_f, c_f, c_i, c_f, c_f, c_l, c_i, c_f, c_f, c_i, c_f]),
+    "atmvfi_dwconv3x3_gelu": (c_i, [c_f, c_i, c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f]),
     "atmvfi_pack_dw_weight": (c_i, [c_f, c_f, c_i, c_f]),
-    "atmvfi_window_attention": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f]),
+    "atmvfi_window_attention": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f]),
     "atmvfi_window_attn_cross_motion": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
     "atmvfi_window_attn_self": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
     "atmvfi_motion_head": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_l, c_i, c_l, c_i, c_f]),
@@ -108,6 +110,31 @@ class PackedWeight:
     packed: Optional[torch.Tensor]     # GEMM layout on the device (None only for test doubles)
     hi: Optional[torch.Tensor] = None  # split-precision planes (fp16) for the f16x3 3x3 kernel
     lo: Optional[torch.Tensor] = None
+
+
+class Planes:
+    """Split-plane activation rows: one fp16 tensor [2, rows, ld] (plane 0 = hi, plane 1 = lo' = (x - hi) * 1024) holding
+    `c` real channels per row; ld is a multiple of 32 and the pad channels are finite (zero).  Producers write it in
+    their epilogue; the split GEMM reads it by LDS-DMA."""
+
+    def __init__(self, t: torch.Tensor, c: int):
+        if t.dtype != torch.float16 or t.dim() != 3 or t.shape[0] != 2 or not t.is_contiguous() or t.shape[2] % 32 or c > t.shape[2]:
+            raise ValueError(f"Planes: expected contiguous fp16 [2, rows, ld%32==0] with ld >= C, got {tuple(t.shape)} {t.dtype} C={c}")
+        if not t.is_cuda:
+            raise TypeError("Planes: tensor must live on the GPU")
+        self.t, self.c = t, c
+
+    @property
+    def rows(self):
+        return self.t.shape[1]
+
+    @property
+    def ld(self):
+        return self.t.shape[2]
+
+    @staticmethod
+    def alloc(rows: int, c: int, device) -> "Planes":
+        return Planes(torch.zeros(2, rows, (c + 31) // 32 * 32, dtype=torch.float16, device=device), c)
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -279,8 +306,24 @@ class HipOps:
                 "shape": f"M{n * h * wd} N{4 * cout} K{cin}"}
         self._run("deconv2x2_f16x3" if p.precision else "deconv2x2", meta, self.lib.atmvfi_deconv2x2, ctypes.byref(p), self._stream())
 
+    split_planes_ok = True        # this backend has the split-plane sinks and the LDS-DMA GEMM
+
+    def split_planes(self, x, out: Planes):
+        ld, m, c, gs, _ = rows_view(x, "split_planes.in")
+        if gs != 0 or m != out.rows or c != out.c:
+            raise ValueError("split_planes: expected a plain [rows,C] view matching the planes")
+        meta = {"bytes": 4.0 * m * c + 4.0 * m * out.ld}
+        self._run("split_planes", meta, self.lib.atmvfi_split_planes, _ptr(x), ld, m, c, out.t[0].data_ptr(), out.t[1].data_ptr(),
+                  out.ld, self._stream())
+
     def linear(self, x, w: PackedWeight, out, bias=None, residual=None, out_row_map=None):
-        ld, m, cin, gs, rpg = rows_view(x, "linear.in")
+        planes = x if isinstance(x, Planes) else None
+        if planes is not None:
+            if self.precision != "f16x3" or w.hi is None:
+                raise ValueError("linear: split-plane input needs the f16x3 engine and split weights")
+            ld, m, cin, gs, rpg = planes.ld, planes.rows, planes.c, 0, 0
+        else:
+            ld, m, cin, gs, rpg = rows_view(x, "linear.in")
         old, mo, cout, ogs, orpg = rows_view(out, "linear.out")
         if cin != w.cin or cout != w.cout or w.kh != 1 or w.mode == GEMM_DECONV:
             raise ValueError(f"linear: shape mismatch in {tuple(x.shape)} w ({w.cout},{w.cin}) out {tuple(out.shape)}")
@@ -293,50 +336,79 @@ class HipOps:
             res_ld, rm, rc, rgs, _ = rows_view(residual, "linear.residual")
             if rm != m or rc != cout or rgs != 0:
                 raise ValueError("linear: residual must be a plain [M,Cout] view")
-        p = GemmParams(mode=GEMM_LINEAR, in_=x.data_ptr(), in_ld=ld, N=1, H=1, W=1, Cin=cin, in_gstride=gs, in_rpg=rpg,
+        p = GemmParams(mode=GEMM_LINEAR, in_=None if planes is not None else x.data_ptr(), in_ld=ld, N=1, H=1, W=1, Cin=cin, in_gstride=gs, in_rpg=rpg,
                        weight=w.packed.data_ptr(), Cout=cout, kh=1, kw=1, stride=1, pad=0, dil=1, Ho=1, Wo=1, M=m,
                        out=out.data_ptr(), out_ld=old, out_gstride=ogs, out_rpg=orpg, out_row_map=_ptr(out_row_map),
                        bias=_ptr(bias), prelu=None, in_prelu=None, residual=_ptr(residual), res_ld=res_ld)
         p.precision, p.weight_hi, p.weight_lo = self._prec(w)
+        if planes is not None:
+            p.in_hi, p.in_lo = planes.t[0].data_ptr(), planes.t[1].data_ptr()
         meta = {"flops": 2.0 * m * cout * cin, "bytes": 4.0 * (m * cin + m * cout + cout * cin), "shape": f"M{m} N{cout} K{cin}"}
-        self._run("linear_f16x3" if p.precision else "linear", meta, self.lib.atmvfi_linear, ctypes.byref(p), self._stream())
+        self._run("linear_split" if planes is not None else "linear_f16x3" if p.precision else "linear", meta, self.lib.atmvfi_linear, ctypes.byref(p), self._stream())
 
     # ------------------------------------------------------------- transformer
-    def layernorm(self, x, out, gamma, beta, src_row_map=None):
+    @staticmethod
+    def _sink(planes: Optional[Planes], rows: int, c: int, what: str):
+        """(hi, lo, ld) arguments of a kernel's split-plane sink (all null when the caller wants fp32 only)."""
+        if planes is None:
+            return None, None, 0
+        if planes.rows != rows or planes.c != c:
+            raise ValueError(f"{what}: planes hold {planes.rows} x {planes.c}, kernel writes {rows} x {c}")
+        return planes.t[0].data_ptr(), planes.t[1].data_ptr(), planes.ld
+
+    def layernorm(self, x, out, gamma, beta, src_row_map=None, planes: Optional[Planes] = None):
+        """``out`` (fp32 rows) may be None when only the split planes are wanted."""
         ld, m, c, gs, rpg = rows_view(x, "layernorm.in")
-        old, mo, co, ogs, _ = rows_view(out, "layernorm.out")
+        if out is None:
+            if planes is None:
+                raise ValueError("layernorm: no output")
+            old, mo, co, ogs = 0, planes.rows, planes.c, 0
+        else:
+            old, mo, co, ogs, _ = rows_view(out, "layernorm.out")
         if co != c or ogs != 0:
             raise ValueError("layernorm: output must be a plain [rows,C] view")
         if src_row_map is None and mo != m:
             raise ValueError("layernorm: row count mismatch")
         if src_row_map is not None and src_row_map.numel() != mo:
             raise ValueError("layernorm: src_row_map needs one entry per output row")
-        meta = {"bytes": 4.0 * 2 * mo * c}
+        hi, lo, pld = self._sink(planes, mo, c, "layernorm")
+        meta = {"bytes": 4.0 * mo * c * (1 + (out is not None) + (planes is not None))}
         self._run("layernorm", meta, self.lib.atmvfi_layernorm, _ptr(x), ld, gs, rpg, _ptr(src_row_map), _ptr(out), old,
-                  _ptr(gamma), _ptr(beta), mo, c, self._stream())
+                  _ptr(gamma), _ptr(beta), mo, c, hi, lo, pld, self._stream())
 
-    def dwconv_gelu(self, x, out, w9, bias):
+    def dwconv_gelu(self, x, out, w9, bias, planes: Optional[Planes] = None):
         ld, n, h, w, c = nhwc_view(x, "dwconv.in")
-        old, on, oh, ow, oc = nhwc_view(out, "dwconv.out")
-        if (on, oh, ow, oc) != (n, h, w, c):
-            raise ValueError("dwconv: shape mismatch")
-        meta = {"bytes": 4.0 * 2 * n * h * w * c}
+        old = 0
+        if out is not None:
+            old, on, oh, ow, oc = nhwc_view(out, "dwconv.out")
+            if (on, oh, ow, oc) != (n, h, w, c):
+                raise ValueError("dwconv: shape mismatch")
+        elif planes is None:
+            raise ValueError("dwconv: no output")
+        hi, lo, pld = self._sink(planes, n * h * w, c, "dwconv")
+        meta = {"bytes": 4.0 * n * h * w * c * (1 + (out is not None) + (planes is not None))}
         self._run("dwconv3x3_gelu", meta, self.lib.atmvfi_dwconv3x3_gelu, _ptr(x), ld, _ptr(out), old, _ptr(w9), _ptr(bias),
-                  n, h, w, c, self._stream())
+                  n, h, w, c, hi, lo, pld, self._stream())
 
-    def window_attention(self, qkv, out, motion, labels, bw, nw, ws, heads, hd, kv_shift):
-        _chk(qkv, "attn.qkv"); _chk(out, "attn.out")
+    def window_attention(self, qkv, out, motion, labels, bw, nw, ws, heads, hd, kv_shift, planes: Optional[Planes] = None):
+        _chk(qkv, "attn.qkv")
         n = ws * ws
         c = heads * hd
-        if tuple(qkv.shape) != (bw * n, 3 * c) or not qkv.is_contiguous() or tuple(out.shape) != (bw * n, c) or not out.is_contiguous():
-            raise ValueError(f"window_attention: qkv {tuple(qkv.shape)} / out {tuple(out.shape)} do not match Bw {bw} N {n} C {c}")
+        if out is None and planes is None:
+            raise ValueError("window_attention: no output")
+        if out is not None:
+            _chk(out, "attn.out")
+        if tuple(qkv.shape) != (bw * n, 3 * c) or not qkv.is_contiguous() or (
+                out is not None and (tuple(out.shape) != (bw * n, c) or not out.is_contiguous())):
+            raise ValueError(f"window_attention: qkv {tuple(qkv.shape)} / out do not match Bw {bw} N {n} C {c}")
         if motion is not None and (tuple(motion.shape) != (bw * n, heads, 2) or not motion.is_contiguous()):
             raise ValueError("window_attention: motion must be contiguous [Bw*N, heads, 2]")
         if labels is not None and (tuple(labels.shape) != (nw, n) or labels.dtype != torch.int32 or not labels.is_cuda):
             raise ValueError("window_attention: labels must be CUDA int32 [nW, N]")
         meta = {"flops": 4.0 * bw * heads * n * n * hd, "bytes": 4.0 * bw * n * 4 * c}
+        hi, lo, pld = self._sink(planes, bw * n, c, "window_attention")
         self._run("window_attention", meta, self.lib.atmvfi_window_attention, _ptr(qkv), _ptr(out), _ptr(motion), _ptr(labels),
-                  bw, nw, ws, heads, hd, kv_shift, self._stream())
+                  bw, nw, ws, heads, hd, kv_shift, hi, lo, pld, self._stream())
 
     def motion_head(self, motion, row_map, w0, b0, w1, b1, out):
         old, mo, co, ogs, orpg = rows_view(out, "motion_head.out")

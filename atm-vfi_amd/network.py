@@ -22,13 +22,14 @@ There is no CPU path: ``forward`` requires CUDA(HIP) tensors and the built libra
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
 import torch.nn as nn
 
 from . import schema as S
-from .hip_ops import GEMM_CONV, GEMM_DECONV, GEMM_LINEAR, HipOps, PackedWeight
+from .hip_ops import GEMM_CONV, GEMM_DECONV, GEMM_LINEAR, HipOps, PackedWeight, Planes
 from .windows import WindowGeometry, build_window_geometry
 
 
@@ -81,6 +82,7 @@ class Network(nn.Module):
         # ---- runtime state (not part of the state dict) ----
         self._ops_obj = None
         self._precision = "f16x3"
+        self.use_split_planes = os.environ.get("ATMVFI_SPLIT_PLANES", "1") != "0"     # A/B switch (tools/profile_layers.py)
         self._prepared: Dict[str, object] = {}
         self._prepared_sig = None
         self._bufs: Dict[Tuple, torch.Tensor] = {}
@@ -163,6 +165,15 @@ class Network(nn.Module):
             t = self._ops_obj.empty(*shape)
             self._bufs[key] = t
         return t
+
+    def planes(self, name: str, rows: int, c: int) -> Planes:
+        """Workspace rows in the split-plane format (zero-initialised once: the pad channels must stay finite)."""
+        key = ("planes", name, rows, c)
+        p = self._bufs.get(key)
+        if p is None:
+            p = Planes.alloc(rows, c, self._ops_obj.device)
+            self._bufs[key] = p
+        return p
 
     def release_workspace(self):
         self._bufs.clear()
@@ -261,26 +272,41 @@ class Network(nn.Module):
         geo, row_map, labels = self.geometry(frames, h, w, ws, shift)
         mw = frames * geo.n_windows * geo.tokens
         bw = frames * geo.n_windows
+        # With the f16x3 engine every nn.Linear input is written by its producer as split planes (fp16 hi / lo', same
+        # bytes as fp32) and read by the GEMM through LDS-DMA; fp32 copies are kept only where something else reads them
+        # (xn is the residual of proj: the reference adds onto the post-norm tensor).
+        pl = getattr(ops, "precision", None) == "f16x3" and getattr(ops, "split_planes_ok", False) and self.use_split_planes
         xn = self.buf(f"{tag}xn", mw, c)
-        ops.layernorm(x, xn, P[f"{p}.norm1.weight"], P[f"{p}.norm1.bias"], src_row_map=row_map)
+        xn_p = self.planes(f"{tag}xn_p", mw, c) if pl else None
+        ops.layernorm(x, xn, P[f"{p}.norm1.weight"], P[f"{p}.norm1.bias"], src_row_map=row_map, **({"planes": xn_p} if pl else {}))
         qkv = self.buf(f"{tag}qkv", mw, 3 * c)
-        ops.linear(xn, P[f"pk:{p}.attn.qkv.weight"], qkv)
-        ao = self.buf(f"{tag}ao", mw, c)
+        ops.linear(xn_p if pl else xn, P[f"pk:{p}.attn.qkv.weight"], qkv)
+        ao = None if pl else self.buf(f"{tag}ao", mw, c)
+        ao_p = self.planes(f"{tag}ao_p", mw, c) if pl else None
         mo = self.buf(f"{tag}mo", mw, heads, 2) if cross else None
-        ops.window_attention(qkv, ao, mo, labels, bw, geo.n_windows, ws, heads, hd, bw // 2 if cross else 0)
+        ops.window_attention(qkv, ao, mo, labels, bw, geo.n_windows, ws, heads, hd, bw // 2 if cross else 0,
+                             **({"planes": ao_p} if pl else {}))
         xb = self.buf(f"{tag}xb", frames * h * w, c)
-        ops.linear(ao, P[f"pk:{p}.attn.proj.weight"], xb, bias=P[f"{p}.attn.proj.bias"], residual=xn, out_row_map=row_map)
+        ops.linear(ao_p if pl else ao, P[f"pk:{p}.attn.proj.weight"], xb, bias=P[f"{p}.attn.proj.bias"], residual=xn, out_row_map=row_map)
         if cross:
             ops.motion_head(mo, row_map, P[f"{p}.attn.mlp.0.weight"], P[f"{p}.attn.mlp.0.bias"],
                             P[f"{p}.attn.mlp.2.weight"], P[f"{p}.attn.mlp.2.bias"], motion_dst)
-        y = self.buf(f"{tag}ln2", frames * h * w, c)
-        ops.layernorm(xb, y, P[f"{p}.norm2.weight"], P[f"{p}.norm2.bias"])
         hid = P[f"{p}.mlp.fc1.bias"].shape[0]
         f1 = self.buf(f"{tag}fc1", frames, h, w, hid)
-        ops.linear(y, P[f"pk:{p}.mlp.fc1.weight"], f1.reshape(frames * h * w, hid), bias=P[f"{p}.mlp.fc1.bias"])
-        f2 = self.buf(f"{tag}dw", frames, h, w, hid)
-        ops.dwconv_gelu(f1, f2, P[f"pk:{p}.mlp.dwconv.dwconv.weight"], P[f"{p}.mlp.dwconv.dwconv.bias"])
-        ops.linear(f2.reshape(frames * h * w, hid), P[f"pk:{p}.mlp.fc2.weight"], out, bias=P[f"{p}.mlp.fc2.bias"], residual=xb)
+        if pl:
+            y_p = self.planes(f"{tag}ln2_p", frames * h * w, c)
+            ops.layernorm(xb, None, P[f"{p}.norm2.weight"], P[f"{p}.norm2.bias"], planes=y_p)
+            ops.linear(y_p, P[f"pk:{p}.mlp.fc1.weight"], f1.reshape(frames * h * w, hid), bias=P[f"{p}.mlp.fc1.bias"])
+            f2_p = self.planes(f"{tag}dw_p", frames * h * w, hid)
+            ops.dwconv_gelu(f1, None, P[f"pk:{p}.mlp.dwconv.dwconv.weight"], P[f"{p}.mlp.dwconv.dwconv.bias"], planes=f2_p)
+            ops.linear(f2_p, P[f"pk:{p}.mlp.fc2.weight"], out, bias=P[f"{p}.mlp.fc2.bias"], residual=xb)
+        else:
+            y = self.buf(f"{tag}ln2", frames * h * w, c)
+            ops.layernorm(xb, y, P[f"{p}.norm2.weight"], P[f"{p}.norm2.bias"])
+            ops.linear(y, P[f"pk:{p}.mlp.fc1.weight"], f1.reshape(frames * h * w, hid), bias=P[f"{p}.mlp.fc1.bias"])
+            f2 = self.buf(f"{tag}dw", frames, h, w, hid)
+            ops.dwconv_gelu(f1, f2, P[f"pk:{p}.mlp.dwconv.dwconv.weight"], P[f"{p}.mlp.dwconv.dwconv.bias"])
+            ops.linear(f2.reshape(frames * h * w, hid), P[f"pk:{p}.mlp.fc2.weight"], out, bias=P[f"{p}.mlp.fc2.bias"], residual=xb)
 
     @staticmethod
     def _stacked(buf, off, c):

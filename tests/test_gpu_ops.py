@@ -430,3 +430,129 @@ def test_gemm_modes_both_precisions(precision, hip, cpu, dev):
             assert maxdiff(og, oc) <= 1e-4
     finally:
         hip.precision = "f16x3"
+
+
+# ------------------------------------------------------------------ split-plane activations (LDS-DMA GEMM)
+def planes_to_f32(p):
+    """hi + lo'/1024: the value the split GEMM sees (fp64 so that the reconstruction itself adds nothing)."""
+    t = p.t.double().cpu()
+    return (t[0] + t[1] / 1024.0)[:, :p.c]
+
+
+def test_split_planes_format(hip, dev):
+    g = torch.Generator().manual_seed(21)
+    x = torch.cat([rnd(g, 50, 70, scale=3.0), rnd(g, 50, 70, scale=1e-3), rnd(g, 50, 70, scale=7e4)])      # incl. > fp16 max
+    x[0, :4] = torch.tensor([0.0, -0.0, 65504.0, -1e30])
+    buf = torch.zeros(150, 72)
+    buf[:, :70] = x
+    p = hip_ops.Planes.alloc(150, 70, dev)
+    assert p.ld == 96
+    hip.split_planes(buf.to(dev)[:, :70], p)
+    torch.cuda.synchronize()
+    hi = x.clamp(-65504, 65504).half()
+    lo = ((x.clamp(-3e38, 3e38) - hi.float()) * 1024).clamp(-65504, 65504).half()
+    assert torch.equal(p.t[0, :, :70].cpu(), hi) and torch.equal(p.t[1, :, :70].cpu(), lo)
+    assert (p.t[:, :, 70:] == 0).all()                                    # pad channels are written as zero
+    err = (planes_to_f32(p) - x.double()).abs()
+    normal = (x.abs() <= 65504) & (x.abs() >= 2.0 ** -14)
+    assert (err / x.double().abs().clamp_min(1e-30))[normal].max().item() <= 2.0 ** -21    # ~22 significant bits in fp16's normal range
+    assert err[x.abs() < 2.0 ** -14].max().item() <= 2.0 ** -34                            # below it: fp16-subnormal lo' / 1024
+
+
+LIN_SPLIT_CASES = [
+    # M, N, K, bias, residual, scatter
+    (1000, 200, 100, True, True, False),        # every tail: rows, columns, K (100 -> 128)
+    (256, 128, 32, False, False, False),        # exactly one tile, one k-step
+    (257, 129, 64, True, False, False),         # one row / one column past a tile, two k-steps (prologue tails)
+    (777, 672, 672, True, True, False),         # 21 k-steps
+    (3000, 384, 1536, True, True, False),       # fc2 shape (long K)
+    (1920, 96, 96, True, True, True),           # scatter through a window map
+]
+
+
+@pytest.mark.parametrize("case", LIN_SPLIT_CASES, ids=lambda c: f"M{c[0]}_N{c[1]}_K{c[2]}" + ("_scatter" if c[5] else ""))
+def test_linear_from_split_planes(case, hip, dev):
+    """The LDS-DMA GEMM must give bit-identical results to the fp32-input f16x3 GEMM (same split, same
+    accumulation order), and agree with fp64 to fp32 accuracy."""
+    m, n, k, use_b, use_r, scatter = case
+    g = torch.Generator().manual_seed(m + n + k)
+    x = rnd(g, m, k, scale=2.0).to(dev)
+    w = rnd(g, n, k, scale=1.0 / k ** 0.5).to(dev)
+    b = rnd(g, n, scale=0.5).to(dev) if use_b else None
+    r = rnd(g, m, n, scale=0.5).to(dev) if use_r else None
+    rows_out = m
+    rmap = None
+    if scatter:
+        geo = windows.build_window_geometry(2, 30, 30, 8, 4)
+        assert geo.row_map.numel() >= m
+        rmap = geo.row_map[:m].contiguous().to(dev)
+        rows_out = 2 * 30 * 30
+    pw = hip.pack_weight(GEMM_LINEAR, w)
+    n4 = (n + 3) // 4 * 4                                                   # views need ld % 4 == 0
+    y0 = torch.full((rows_out, n4), 5.0, device=dev)[:, :n]
+    y1 = torch.full((rows_out, n4), 5.0, device=dev)[:, :n]
+    if r is not None:
+        r = torch.cat([r, torch.zeros(m, n4 - n, device=dev)], 1)[:, :n]
+    p = hip_ops.Planes.alloc(m, k, dev)
+    hip.split_planes(x, p)
+    hip.linear(x, pw, y0, b, r, rmap)
+    hip.linear(p, pw, y1, b, r, rmap)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
+    if not scatter:
+        ref = x.double() @ w.double().t() + (b.double() if use_b else 0) + (r.double() if use_r else 0)
+        assert (y1.double() - ref).abs().max().item() <= 2e-5
+
+
+def test_split_plane_sinks(hip, cpu, dev):
+    """LayerNorm / dwconv+GELU / window attention writing their result as split planes (with and without the fp32
+    copy): the planes must be the exact split of the fp32 result."""
+    g = torch.Generator().manual_seed(31)
+
+    def split_of(t):
+        hi = t.clamp(-65504, 65504).half()
+        return hi, ((t - hi.float()) * 1024).clamp(-65504, 65504).half()
+    # LayerNorm with a gather map (zero-padded tokens -> beta)
+    frames, h, w, ws, shift, C = 2, 5, 6, 4, 2, 224
+    geo = windows.build_window_geometry(frames, h, w, ws, shift)
+    src = rnd(g, frames * h * w, C, scale=3.0).to(dev)
+    gamma, beta = (1 + rnd(g, C, scale=0.2)).to(dev), rnd(g, C, scale=0.2).to(dev)
+    rows = geo.row_map.numel()
+    of = torch.empty(rows, C, device=dev)
+    hip.layernorm(src, of, gamma, beta, geo.row_map.to(dev))
+    for keep in (True, False):
+        o2 = torch.empty(rows, C, device=dev) if keep else None
+        p = hip_ops.Planes.alloc(rows, C, dev)
+        hip.layernorm(src, o2, gamma, beta, geo.row_map.to(dev), planes=p)
+        torch.cuda.synchronize()
+        hi, lo = split_of(of)
+        assert torch.equal(p.t[0, :, :C], hi) and torch.equal(p.t[1, :, :C], lo)
+        if keep:
+            assert torch.equal(o2, of)
+    # dwconv + GELU (both kernels: C % 64 == 0 and not)
+    for n, hh, ww, c in ((2, 7, 9, 448), (1, 5, 6, 100)):
+        x = rnd(g, n, hh, ww, c, scale=2.0).to(dev)
+        wt = hip.pack_dw_weight(rnd(g, c, 1, 3, 3, scale=0.5).to(dev))
+        b = rnd(g, c, scale=0.3).to(dev)
+        of = torch.empty(n, hh, ww, c, device=dev)
+        hip.dwconv_gelu(x, of, wt, b)
+        p = hip_ops.Planes.alloc(n * hh * ww, c, dev)
+        hip.dwconv_gelu(x, None, wt, b, planes=p)
+        torch.cuda.synchronize()
+        hi, lo = split_of(of.reshape(-1, c))
+        assert torch.equal(p.t[0, :, :c], hi) and torch.equal(p.t[1, :, :c], lo)
+    # window attention
+    ws, hd, heads = 8, 28, 8
+    geo = windows.build_window_geometry(2, 12, 20, ws, 4)
+    bw, n, C = 2 * geo.n_windows, ws * ws, heads * hd
+    qkv = rnd(g, bw * n, 3 * C, scale=1.5).to(dev)
+    of = torch.empty(bw * n, C, device=dev)
+    lab = geo.labels.to(dev)
+    hip.window_attention(qkv, of, None, lab, bw, geo.n_windows, ws, heads, hd, bw // 2)
+    p = hip_ops.Planes.alloc(bw * n, C, dev)
+    hip.window_attention(qkv, None, None, lab, bw, geo.n_windows, ws, heads, hd, bw // 2, planes=p)
+    torch.cuda.synchronize()
+    hi, lo = split_of(of)
+    assert torch.equal(p.t[0, :, :C], hi) and torch.equal(p.t[1, :, :C], lo)
+    with pytest.raises(ValueError):
+        hip.layernorm(src, None, gamma, beta)                              # no output at all

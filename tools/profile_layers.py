@@ -35,3 +35,10 @@ for n, m, t in best:
     tf = m.get("flops", 0) / (t * 1e-3) / 1e12
     gb = m.get("bytes", 0) / (t * 1e-3) / 1e9
     print(f"{n:18s} {m.get('shape', ''):28s} {t:8.3f} ms {tf:7.1f} TF/s {gb:8.1f} GB/s")
+fam = {}
+for n, m, t in best:
+    f = fam.setdefault(n, [0, 0.0, 0.0, 0.0])
+    f[0] += 1; f[1] += t; f[2] += m.get("flops", 0); f[3] += m.get("bytes", 0)
+print("--- by family")
+for n, (c, t, fl, by) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
+    print(f"{n:18s} x{c:3d} {t:8.3f} ms {100 * t / tot:5.1f} %  {fl / (t * 1e-3) / 1e12:7.1f} TF/s {by / (t * 1e-3) / 1e9:8.1f} GB/s")

@@ -1,0 +1,33 @@
+"""In-kernel clock and phase cycles of gemm_split_kernel from the diagnostic (ATMVFI_STAMP) library."""
+import ctypes, importlib, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT]
+hip_ops = importlib.import_module("atm-vfi_amd.hip_ops")
+hip_ops.LIB_PATH = os.path.join(ROOT, "atm-vfi_amd", "libatmvfi_hip_stamp.so")
+hip_ops.load_library.__defaults__ = (hip_ops.LIB_PATH,)
+dev = torch.device("cuda:0")
+ops = hip_ops.HipOps(dev)
+g = torch.Generator().manual_seed(0)
+for m, n, k in [(65280, 1536, 384), (65280, 384, 1536), (16320, 2688, 672)]:
+    x = (torch.rand(m, k, generator=g) * 2 - 1).to(dev)
+    w = ((torch.rand(n, k, generator=g) * 2 - 1) / k ** 0.5).to(dev)
+    pw = ops.pack_weight(1, w)
+    y = torch.empty(m, n, device=dev)
+    pl = hip_ops.Planes.alloc(m, k, dev)
+    ops.split_planes(x, pl)
+    nblk = ((m + 255) // 256 + 7) // 8 * 8 * ((n + 127) // 128)
+    buf = torch.zeros(nblk * 8 * 8, dtype=torch.int64, device=dev)
+    ops.lib.atmvfi_debug_set_split_stamp_buffer.argtypes = [ctypes.c_void_p]
+    ops.lib.atmvfi_debug_set_split_stamp_buffer(ctypes.c_void_p(buf.data_ptr()))
+    for _ in range(200):           # keep the chip loaded so the clock settles
+        ops.linear(pl, pw, y)
+    torch.cuda.synchronize()
+    t = buf.reshape(-1, 8).double()
+    t = t[t[:, 3] > 0]
+    nk = t[0, 3].item()
+    pro, loop, epi = (t[:, i].median().item() for i in range(3))
+    rpro, rloop, repi = (t[:, 4 + i].median().item() for i in range(3))
+    clk = loop / rloop * 100.0 if rloop else float("nan")     # s_memrealtime ticks at 100 MHz
+    print(f"M{m} N{n} K{k}: k-steps {nk:.0f}; cycles prologue {pro:.0f}  loop {loop:.0f} ({loop / nk:.0f}/step)  epilogue {epi:.0f};"
+          f" in-kernel clock {clk:.0f} MHz; loop {rloop / 100:.2f} us", flush=True)
