@@ -87,6 +87,9 @@ class Network(nn.Module):
         self._prepared_sig = None
         self._bufs: Dict[Tuple, torch.Tensor] = {}
         self._geo: Dict[Tuple, Tuple[WindowGeometry, torch.Tensor, Optional[torch.Tensor]]] = {}
+        self.use_graphs = False
+        self._graphs: Dict[Tuple, Tuple] = {}
+        self._graph_sig = None
 
     # ------------------------------------------------------------------ API parity
     def __set_local_window_size__(self, window_size):       # network_base.py:262-265
@@ -136,6 +139,7 @@ class Network(nn.Module):
         default is the HIP library and nothing else)."""
         self._ops_obj = ops
         self._prepared_sig = None
+        self._graphs.clear()
         self._bufs.clear()
         self._geo.clear()
 
@@ -176,6 +180,7 @@ class Network(nn.Module):
         return p
 
     def release_workspace(self):
+        self._graphs.clear()          # captured graphs launch into the workspace
         self._bufs.clear()
 
     def geometry(self, frames, h, w, ws, shift):
@@ -393,7 +398,44 @@ class Network(nn.Module):
         return sel0[pick, idx].contiguous(), sel1[pick, idx].contiguous()
 
     # ------------------------------------------------------------------ forward
+    def enable_graphs(self, flag: bool = True):
+        """Replay ``forward`` from a captured HIP graph (one per input shape / mode): the ~140 kernel launches of a pass are
+        submitted as one graph launch, which removes the launch gaps (a few % at 1080p, most of the time on small frames).
+        The returned tensors are the graph's static outputs: they are overwritten by the next call with the same shape.
+        Not part of the reference's API; off by default."""
+        self.use_graphs = bool(flag)
+        if not flag:
+            self._graphs.clear()
+
     def forward(self, im0: torch.Tensor, im1: torch.Tensor):
+        if not self.use_graphs or not im0.is_cuda:
+            return self._forward_eager(im0, im1)
+        ops = self._ops(im0.device)
+        self._prepare(ops)
+        if self._graph_sig != self._prepared_sig:            # parameters changed: the captured launches hold stale weights
+            self._graphs.clear()
+            self._graph_sig = self._prepared_sig
+        key = (tuple(im0.shape), tuple(im1.shape), str(im0.device), self.global_motion, self.ensemble_global_motion,
+               self._precision, self.use_split_planes, self.local_motion_args["window_size"], self.global_motion_args["window_size"])
+        ent = self._graphs.get(key)
+        if ent is None:
+            for _ in range(2):                               # validation, workspace, window maps, packed weights, kernel attributes
+                self._forward_eager(im0, im1)
+            torch.cuda.synchronize(im0.device)
+            s0 = im0.detach().float().contiguous().clone()
+            s1 = im1.detach().float().contiguous().clone()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self._forward_eager(s0, s1)
+            ent = (graph, s0, s1, out)
+            self._graphs[key] = ent
+        graph, s0, s1, out = ent
+        s0.copy_(im0)
+        s1.copy_(im1)
+        graph.replay()
+        return out
+
+    def _forward_eager(self, im0: torch.Tensor, im1: torch.Tensor):
         if im0.shape != im1.shape or im0.dim() != 4 or im0.shape[1] != 3:
             raise ValueError(f"expected two [B,3,H,W] frames, got {tuple(im0.shape)} and {tuple(im1.shape)}")
         ops = self._ops(im0.device)

@@ -208,3 +208,30 @@ def test_exact_fp32_engine_end_to_end(dev, weights):
     print("f32", {k: f"{v:.1e}" for k, v in errs.items()}, "f16x3", {k: f"{v:.1e}" for k, v in errs2.items()})
     # the two engines agree far inside the parity budget
     assert (out["I_t"] - out2["I_t"]).abs().max().item() <= 2e-4
+
+
+def test_graph_replay_equals_eager(dev, weights):
+    """Network.enable_graphs(): the captured HIP graph must reproduce the eager forward bit for bit, follow new inputs,
+    new shapes and a changed parameter (the graph is re-captured when the packed weights are refreshed)."""
+    net = pkg.NetworkLite()
+    net.load_state_dict(weights("lite"), strict=True)
+    net.to(dev).eval()
+    a0, a1 = pairs.smooth_pair(1, 128, 192, seed=81)
+    b0, b1 = pairs.random_pair(1, 128, 192, seed=82)
+    c0, c1 = pairs.smooth_pair(2, 64, 128, seed=83)
+    eager = [{k: (v.clone() if torch.is_tensor(v) else [t.clone() for t in v]) for k, v in net(x.to(dev), y.to(dev)).items()}
+             for x, y in ((a0, a1), (b0, b1), (c0, c1))]
+    net.enable_graphs(True)
+    for rep in range(2):
+        for (x, y), ref in zip(((a0, a1), (b0, b1), (c0, c1)), eager):
+            out = net(x.to(dev), y.to(dev))
+            torch.cuda.synchronize()
+            assert torch.equal(out["I_t"], ref["I_t"]) and torch.equal(out["opt_flow_0"], ref["opt_flow_0"])
+            assert all(torch.equal(p, q) for p, q in zip(out["im_t_list"], ref["im_t_list"]))
+    assert len(net._graphs) == 2
+    with torch.no_grad():
+        dict(net.named_parameters())["refine_head.1.0.weight"].mul_(0.5)          # in-place parameter update -> packed weights and graphs are rebuilt
+    out = net(a0.to(dev), a1.to(dev))["I_t"].clone()
+    net.enable_graphs(False)
+    assert torch.equal(out, net(a0.to(dev), a1.to(dev))["I_t"])
+    assert not torch.equal(out, eager[0]["I_t"])
