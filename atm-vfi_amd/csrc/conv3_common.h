@@ -1,4 +1,4 @@
-// Shared pieces of the split-precision 3x3 kernels (conv3x3_f16x3.hip, conv3x3_f16x3_row.hip).
+// Shared pieces of the split-precision 3x3 convolution (conv3x3_f16x3.hip: entry + packers, conv3x3_f16x3_row.hip: kernel).
 #pragma once
 #include "common.h"
 
@@ -12,7 +12,10 @@ struct Conv3Dev {
     const _Float16* w_hi;
     const _Float16* w_lo;
     int wrows;      // packed weight rows (multiple of 16)
-    int cin_pad;    // Cin rounded up to 32
+    int cf;         // channels covered by full 32-channel chunks
+    int tail;       // 1..8 channels in the tap-packed tail steps, 0 = none
+    int cs;         // per-tap stride of a weight row, halves: cf (+ 32 with a tail)
+    int ktot;       // halves per weight row = 9*cs
     int Cout;
     float* out;
     int out_ld;
@@ -24,8 +27,6 @@ struct Conv3Dev {
 };
 // conv3x3_f16x3_row.hip: three taps (one kernel row) per stage, single-buffered halo
 int launch_conv3x3_row(const Conv3Dev& d, int ntiles, hipStream_t stream);
-// conv3x3_f16x3_half.hip: 256-thread workgroups on 16x8 tiles, two per CU, single-buffered LDS
-int launch_conv3x3_half(const Conv3Dev& d, int ntiles, hipStream_t stream);
 }  // namespace atmvfi
 using atmvfi::Conv3Dev;
 

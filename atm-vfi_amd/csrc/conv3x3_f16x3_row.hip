@@ -78,7 +78,7 @@ __global__ __launch_bounds__(512) void conv3x3_f16x3_row_kernel(const Conv3Dev a
     const _Float16* wsrc[B_PPT];
     int wdst[B_PPT];
     bool wok[B_PPT], wact[B_PPT], wlo[B_PPT];
-    const long long ktot = 9ll * a.cin_pad;
+    const long long ktot = a.ktot;
 #pragma unroll
     for (int k = 0; k < B_PPT; ++k) {
         const int P = tid + 512 * k;
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(512) void conv3x3_f16x3_row_kernel(const Conv3Dev a
         const int slot = rem & 3;
         wlo[k] = plane == 1;
         wok[k] = wact[k] && (n0 + row) < a.wrows;
-        wsrc[k] = (plane ? a.w_lo : a.w_hi) + (long long)(wok[k] ? n0 + row : 0) * ktot + (long long)t * a.cin_pad + slot * 8;
+        wsrc[k] = (plane ? a.w_lo : a.w_hi) + (long long)(wok[k] ? n0 + row : 0) * ktot + (long long)t * a.cs + slot * 8;
         wdst[k] = (t * BN + row) * 32 + ((slot ^ swz64(row)) << 3);
     }
 
@@ -104,8 +104,11 @@ __global__ __launch_bounds__(512) void conv3x3_f16x3_row_kernel(const Conv3Dev a
             cor[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
 
-    const int nchunks = a.cin_pad >> 5;
-    const int nstages = nchunks * 3;
+    // stages: (chunk, kernel row) = three taps x 32 channels each; then ONE stage for the tap-packed channel tail
+    // (three k-steps of 4 taps x 8 channels, conv3x3_f16x3.hip) instead of three more
+    const int nfull = a.cf >> 5;
+    const int nchunks = nfull + (a.tail ? 1 : 0);
+    const int nstages = nfull * 3 + (a.tail ? 1 : 0);
 
     f32x4 hr[HALO_TPT][2];
     int hnv[HALO_TPT];
@@ -146,7 +149,8 @@ __global__ __launch_bounds__(512) void conv3x3_f16x3_row_kernel(const Conv3Dev a
     auto w_load = [&](int stage) {
         const int chunk = stage / 3;
         const int ky = stage - chunk * 3;
-        const long long koff = (long long)(ky * 3) * a.cin_pad + chunk * 32;
+        // the tail stage is (chunk nfull, ky 0) of the same formula: its three k-steps are stored behind taps 0..2
+        const long long koff = (long long)(ky * 3) * a.cs + chunk * 32;
 #pragma unroll
         for (int k = 0; k < B_PPT; ++k) {
             wr[k] = *reinterpret_cast<const f16x8*>(wsrc[k] + koff);         // row-clamped address: always valid; masked at store
@@ -159,6 +163,14 @@ __global__ __launch_bounds__(512) void conv3x3_f16x3_row_kernel(const Conv3Dev a
                 *reinterpret_cast<f16x8*>((wlo[k] ? b_lo : b_hi) + buf * 3 * BN * 32 + wdst[k]) =
                     wok[k] ? wr[k] : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
     };
+
+    int dtail = 0;                 // halo offsets of taps 4t+g, t = 0..2, one byte each (taps 9..11 carry zero weights: any
+#pragma unroll                     // finite data will do, tap 8 again); packed: the WN = 8 instance has no register to spare
+    for (int t = 0; t < 3; ++t) {
+        const int tap = (4 * t + g) < 9 ? 4 * t + g : 8;
+        const int ty = tap / 3;
+        dtail |= (ty * HW_ + (tap - 3 * ty)) << (8 * t);
+    }
 
     STAMP_DECL
     // ---- prologue ----
@@ -175,6 +187,9 @@ __global__ __launch_bounds__(512) void conv3x3_f16x3_row_kernel(const Conv3Dev a
         const int chunk = s / 3;
         const int ky = s - chunk * 3;
         const int wb = s & 1;
+        const bool tail_stage = chunk >= nfull;
+        int dt = dtail;
+        asm volatile("" : "+v"(dt));       // opaque: keeps hipcc from hoisting the six tail-stage offsets out of the loop (spills at WN = 8)
         const bool more_w = (s + 1) < nstages;
         const bool next_halo = (ky == 2) && (chunk + 1 < nchunks);
         if (more_w) w_load(s + 1);
@@ -188,8 +203,11 @@ __global__ __launch_bounds__(512) void conv3x3_f16x3_row_kernel(const Conv3Dev a
             f16x8 xh[2], xl[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int p = (2 * wave + i + ky) * HW_ + t + r;
-                const int off = p * 32 + ((g ^ swz64(p)) << 3);
+                // regular stage: tap (ky, t), lane group g reads channel slot g.  Tail stage: k = (tap 4t+g, tail channels
+                // 0..7), lane group g reads slot 0 of ITS tap's pixel (selects on a uniform flag: no branch in this loop)
+                const int p = (2 * wave + i) * HW_ + r + (tail_stage ? ((dt >> (8 * t)) & 0xff) : ky * HW_ + t);
+                const int sl = tail_stage ? 0 : g;
+                const int off = p * 32 + ((sl ^ swz64(p)) << 3);
                 xh[i] = *reinterpret_cast<const f16x8*>(halo_hi + off);
                 xl[i] = *reinterpret_cast<const f16x8*>(halo_lo + off);
             }

@@ -67,6 +67,8 @@ SIGNATURES = {
     "atmvfi_pack_weight": (c_i, [c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     "atmvfi_split_weight_halves": (c_l, [c_i, c_i, c_i, c_i, c_i]),
     "atmvfi_pack_weight_split": (c_i, [c_i, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
+    "atmvfi_conv3x3_weight_halves": (c_l, [c_i, c_i]),
+    "atmvfi_pack_weight_conv3x3": (c_i, [c_f, c_f, c_f, c_i, c_i, c_f]),
     "atmvfi_conv3x3_f16x3": (c_i, [c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_i, c_f, c_f, c_f]),
     "atmvfi_layernorm": (c_i, [c_f, c_i, c_l, c_i, c_f, c_f, c_i, c_f, c_f, c_l, c_i, c_f, c_f, c_i, c_f]),
     "atmvfi_dwconv3x3_gelu": (c_i, [c_f, c_i, c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f]),
@@ -108,8 +110,10 @@ class PackedWeight:
     kw: int
     orig: torch.Tensor                 # the parameter (OIHW / [out,in] / IOHW)
     packed: Optional[torch.Tensor]     # GEMM layout on the device (None only for test doubles)
-    hi: Optional[torch.Tensor] = None  # split-precision planes (fp16) for the f16x3 3x3 kernel
+    hi: Optional[torch.Tensor] = None  # split-precision planes (fp16) in the generic GEMM layout (gemm_f16x3 / gemm_split)
     lo: Optional[torch.Tensor] = None
+    hi3: Optional[torch.Tensor] = None  # 3x3 weights again in the conv3x3_f16x3 layout (tap-packed channel tail)
+    lo3: Optional[torch.Tensor] = None
 
 
 class Planes:
@@ -248,6 +252,12 @@ class HipOps:
             pw.lo = torch.empty(nh, dtype=torch.float16, device=self.device)
             self._check(self.lib.atmvfi_pack_weight_split(mode, _ptr(w), _ptr(pw.hi), _ptr(pw.lo), cout, cin, kh, kw, self._stream()),
                         "pack_weight_split")
+            if mode == GEMM_CONV and kh == 3 and kw == 3:
+                n3 = self.lib.atmvfi_conv3x3_weight_halves(cout, cin)
+                pw.hi3 = torch.empty(n3, dtype=torch.float16, device=self.device)
+                pw.lo3 = torch.empty(n3, dtype=torch.float16, device=self.device)
+                self._check(self.lib.atmvfi_pack_weight_conv3x3(_ptr(w), _ptr(pw.hi3), _ptr(pw.lo3), cout, cin, self._stream()),
+                            "pack_weight_conv3x3")
         return pw
 
     def pack_dw_weight(self, w: torch.Tensor) -> torch.Tensor:
@@ -280,9 +290,9 @@ class HipOps:
         meta = {"flops": 2.0 * n * oh * ow * cout * cin * w.kh * w.kw,
                 "bytes": 4.0 * (n * h * wd * cin + n * oh * ow * cout + cout * cin * w.kh * w.kw),
                 "shape": f"M{n * oh * ow} N{cout} K{cin * w.kh * w.kw}"}
-        if (self.precision == "f16x3" and w.hi is not None and w.kh == 3 and stride == 1 and pad == 1 and dil == 1
+        if (self.precision == "f16x3" and w.hi3 is not None and w.kh == 3 and stride == 1 and pad == 1 and dil == 1
                 and in_prelu is None):
-            self._run("conv3x3_f16x3", meta, self.lib.atmvfi_conv3x3_f16x3, _ptr(x), ld, n, h, wd, cin, _ptr(w.hi), _ptr(w.lo),
+            self._run("conv3x3_f16x3", meta, self.lib.atmvfi_conv3x3_f16x3, _ptr(x), ld, n, h, wd, cin, _ptr(w.hi3), _ptr(w.lo3),
                       cout, _ptr(out), old, _ptr(bias), _ptr(prelu), self._stream())
             return
         p = GemmParams(mode=GEMM_CONV, in_=x.data_ptr(), in_ld=ld, N=n, H=h, W=wd, Cin=cin, in_gstride=0, in_rpg=0,

@@ -56,6 +56,9 @@ CONV_CASES = [
     (389, 389, 3, 1, 1, 1, 6, 6, 0, 392, 256, 648, 1),     # 25 n-tiles -> five n-blocks
     (64, 5, 1, 1, 0, 1, 10, 14, 0, 64, 768, 776, 2),       # 1x1 motion head into the decoder input
     (116, 64, 3, 1, 1, 1, 12, 20, 0, 116, 64, 128, 1),
+    (33, 20, 3, 1, 1, 1, 10, 12, 0, 36, 0, 20, 1),         # one-channel tail: tap-packed tail block of the 3x3 kernel
+    (104, 48, 3, 1, 1, 1, 19, 17, 0, 104, 0, 48, 2),       # eight-channel tail, ragged tile borders
+    (40, 24, 3, 2, 1, 1, 10, 12, 0, 40, 0, 24, 1),         # same tail through the strided (generic GEMM) path
     (256, 128, 3, 2, 1, 1, 12, 20, 64, 328, 0, 128, 1),    # down2: reads [feat1 | dec1[:192]] slice
 ]
 
