@@ -171,7 +171,7 @@ def main():
             # kernel families and the MFMA peak that bounds them: the f16x3 engines issue three
             # 16-bit MFMAs per algorithmic multiply-add, so their algorithmic peak is 2500/3 TFLOP/s.
             families = {
-                "conv3x3_f16x3_kernel": (["conv3x3_f16x3"], PEAK_F16_MFMA_TFLOPS / 3.0),
+                "conv3x3_f16x3_row_kernel": (["conv3x3_f16x3"], PEAK_F16_MFMA_TFLOPS / 3.0),
                 "gemm_f16x3_kernel (linear + deconv2x2 + strided conv2d)": (["linear_f16x3", "deconv2x2_f16x3", "conv2d_f16x3"], PEAK_F16_MFMA_TFLOPS / 3.0),
                 "gemm_split_kernel (nn.Linear rows from split planes, LDS-DMA)": (["linear_split"], PEAK_F16_MFMA_TFLOPS / 3.0),
                 "gemm_mfma_f32 (exact-fp32 engine)": (["conv2d", "linear", "deconv2x2"], PEAK_F32_MFMA_TFLOPS),
@@ -193,8 +193,9 @@ def main():
             try:
                 if key == ("base", 1088, 1920, True):
                     pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))["per_forward"]
-                    for fam, kn in (("conv3x3_f16x3_kernel", "conv3x3_f16x3_kernel"),
-                                    ("gemm_f16x3_kernel (linear + deconv2x2 + strided conv2d)", "gemm_f16x3_kernel")):
+                    for fam, kn in (("conv3x3_f16x3_row_kernel", "conv3x3_f16x3_row_kernel"),
+                                    ("gemm_f16x3_kernel (linear + deconv2x2 + strided conv2d)", "gemm_f16x3_kernel"),
+                                    ("gemm_split_kernel (nn.Linear rows from split planes, LDS-DMA)", "gemm_split_kernel")):
                         if fam in fam_out and kn in pmc:
                             fam_out[fam]["traffic"] = round(pmc[kn]["traffic_GB_per_launch"] * 1e9)
                             fam_out[fam]["traffic_unit"] = "bytes/launch (PMC, profiles/r01_pmc_hbm_traffic.json)"
