@@ -72,6 +72,27 @@ static inline bool sink_ok(const void* f32, int ld, int C, const void* hi, const
     return true;
 }
 
+// Per-column epilogue constants by LDS-DMA (used by the f16x3 engines; rationale in gemm_common.h): every wave issues exactly ONE
+// 4-byte-per-lane global_load_lds, piece (wave mod NPIECE) of the round_up(2*BN, 64) floats cst[c] = bias[co(c)],
+// cst[BN + c] = slope[co(c)], with 0 / 1 for absent arrays or columns that map to no channel (co < 0).
+namespace {
+__device__ const float kEpilogueDefaults[2] = {0.f, 1.f};
+}
+constexpr int epilogue_const_floats(int BN) { return (2 * BN + 63) / 64 * 64; }
+template <int BN, typename ColToChannel>
+__device__ __forceinline__ void dma_epilogue_consts(const float* bias, const float* slope, int n0, float* cst, int wave, int lane,
+                                                    ColToChannel channel_of) {
+    constexpr int NPIECE = (2 * BN + 63) / 64;
+    const int piece = wave % NPIECE;
+    const int t = piece * 64 + lane;
+    const bool sl = t >= BN;
+    const int co = t < 2 * BN ? channel_of(n0 + (sl ? t - BN : t)) : -1;
+    const float* src = sl ? slope : bias;
+    const float* p = (src && co >= 0) ? src + co : &kEpilogueDefaults[sl ? 1 : 0];
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                     (__attribute__((address_space(3))) void*)(cst + piece * 64), 4, 0, 0);
+}
+
 // exact GELU (erf form), as nn.GELU() default
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }

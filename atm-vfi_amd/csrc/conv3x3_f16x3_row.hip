@@ -36,6 +36,7 @@ __global__ __launch_bounds__(512) void conv3x3_f16x3_row_kernel(const Conv3Dev a
     _Float16* halo_lo = halo_hi + NPIX * 32;
     _Float16* b_hi = halo_lo + NPIX * 32;               // [2][3][BN][32]
     _Float16* b_lo = b_hi + 2 * 3 * BN * 32;
+    float* cst = reinterpret_cast<float*>(b_lo + 2 * 3 * BN * 32);     // bias / PReLU slopes of this column block (common.h)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -174,6 +175,7 @@ __global__ __launch_bounds__(512) void conv3x3_f16x3_row_kernel(const Conv3Dev a
 
     STAMP_DECL
     // ---- prologue ----
+    dma_epilogue_consts<BN>(a.bias, a.prelu, n0, cst, wave, lane, [&](int col) { return col < a.Cout ? col : -1; });
 #pragma unroll
     for (int k = 0; k < HALO_TPT; ++k) halo_load(k, 0);
     w_load(0);
@@ -265,36 +267,27 @@ __global__ __launch_bounds__(512) void conv3x3_f16x3_row_kernel(const Conv3Dev a
     }
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
-        const int co = n0 + 16 * j + 4 * g;
+        const int cl = 16 * j + 4 * g;
+        const int co = n0 + cl;
         const int nvalid = a.Cout - co;
-        if (nvalid <= 0) continue;
-        // bias / PReLU slopes of the tile, one 16-byte load each (host guarantees alignment)
-        f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f}, pv = (f32x4){1.f, 1.f, 1.f, 1.f};
-        if (nvalid >= 4) {
-            if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + co);
-            if (a.prelu) pv = *reinterpret_cast<const f32x4*>(a.prelu + co);
-        } else {
-            float bb[4] = {0.f, 0.f, 0.f, 0.f}, pp[4] = {1.f, 1.f, 1.f, 1.f};
-            for (int e = 0; e < nvalid; ++e) {
-                if (a.bias) bb[e] = a.bias[co + e];
-                if (a.prelu) pp[e] = a.prelu[co + e];
-            }
-            bv = (f32x4){bb[0], bb[1], bb[2], bb[3]};
-            pv = (f32x4){pp[0], pp[1], pp[2], pp[3]};
-        }
+        // bias / PReLU slopes from LDS (0 / 1 where absent): no global load and no wait in this loop, the stores stream out
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(cst + cl);
+        const f32x4 pv = *reinterpret_cast<const f32x4*>(cst + BN + cl);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            if (!live[i]) continue;
             f32x4 v = acc[i][j] + cor[i][j] * LO_UNSCALE + bv;
             v.x = v.x > 0.f ? v.x : pv.x * v.x;
             v.y = v.y > 0.f ? v.y : pv.y * v.y;
             v.z = v.z > 0.f ? v.z : pv.z * v.z;
             v.w = v.w > 0.f ? v.w : pv.w * v.w;
-            if (nvalid >= 4) {
-                *reinterpret_cast<f32x4*>(orow[i] + co) = v;
-            } else {
-                const float vv[4] = {v.x, v.y, v.z, v.w};
-                for (int e = 0; e < nvalid; ++e) orow[i][co + e] = vv[e];
+            if (live[i]) {
+                if (nvalid >= 4) {
+                    *reinterpret_cast<f32x4*>(orow[i] + co) = v;
+                } else if (nvalid > 0) {
+                    orow[i][co] = v.x;
+                    if (nvalid > 1) orow[i][co + 1] = v.y;
+                    if (nvalid > 2) orow[i][co + 2] = v.z;
+                }
             }
         }
     }
@@ -310,7 +303,7 @@ __global__ __launch_bounds__(512) void conv3x3_f16x3_row_kernel(const Conv3Dev a
 template <int WN>
 int launch_row(const Conv3Dev& d, int ntiles, hipStream_t s) {
     constexpr int BN = 16 * WN;
-    const size_t lds = (size_t)(2 * NPIX * 32 + 2 * 2 * 3 * BN * 32) * sizeof(_Float16);
+    const size_t lds = (size_t)(2 * NPIX * 32 + 2 * 2 * 3 * BN * 32) * sizeof(_Float16) + epilogue_const_floats(BN) * sizeof(float);
     auto kern = conv3x3_f16x3_row_kernel<WN>;
     static bool attr_set = false;
     if (!attr_set) {

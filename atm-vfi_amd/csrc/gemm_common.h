@@ -128,6 +128,74 @@ __device__ __forceinline__ void gemm_store4(const GemmDev& a, float* orow, const
     }
 }
 
+// ---- epilogue constants through LDS -------------------------------------------------------------------------------
+// With the constants fetched per n-tile from global memory inside the epilogue (above), hipcc serialises the epilogue into
+// load -> s_waitcnt vmcnt(0) -> store -> s_waitcnt vmcnt(0) round trips (the per-lane tail branches defeat its counting):
+// ~48 dependent L2 round trips = 14 k of the 60 k ticks of a K = 384 tile.  The f16x3 engines therefore fetch the 2*BN
+// constants of their column block ONCE, by LDS-DMA (no VGPR, no early wait), as cst[c] = bias, cst[BN + c] = PReLU slope of
+// GEMM column n0 + c (0 / 1 when absent or out of range) and read them back with one ds_read_b128 each: the epilogue has
+// no global load left (except an optional residual: one batch of loads and one wait per output row).
+template <int BN>
+__device__ __forceinline__ void gemm_dma_consts(const GemmDev& a, int n0, float* cst, int wave, int lane) {
+    dma_epilogue_consts<BN>(a.bias, a.prelu, n0, cst, wave, lane, [&](int col) {
+        int co = col;
+        if (a.mode == ATMVFI_GEMM_DECONV) {
+            const int q = col / a.coutp;
+            co = q < 4 ? col - q * a.coutp : a.Cout;
+        }
+        return co < a.Cout ? co : -1;
+    });
+}
+constexpr int gemm_const_floats(int BN) { return epilogue_const_floats(BN); }
+
+struct ChanPos {
+    int co;        // first output channel (DECONV: within the 2x2 position)
+    int q;         // DECONV: position index a*2+b
+    int nvalid;    // channels to store (<= 0: none)
+};
+__device__ __forceinline__ ChanPos gemm_chan_pos(const GemmDev& a, int nb) {
+    ChanPos c;
+    c.q = 0;
+    c.co = nb;
+    if (a.mode == ATMVFI_GEMM_DECONV) {
+        c.q = (nb >= a.coutp) + (nb >= 2 * a.coutp) + (nb >= 3 * a.coutp);
+        c.co = nb - c.q * a.coutp;
+        if (nb >= 4 * a.coutp) c.co = a.Cout;
+    }
+    c.nvalid = a.Cout - c.co;
+    return c;
+}
+// v: four consecutive GEMM columns of one row; b, p: their bias / slope (from LDS); res: residual values (or zero)
+__device__ __forceinline__ void gemm_finish_store4(const GemmDev& a, float* orow, const ChanPos& c, f32x4 v, const f32x4 b, const f32x4 p,
+                                                   const f32x4 res) {
+    float* optr = orow;
+    if (a.mode == ATMVFI_GEMM_DECONV) optr = orow + ((long long)(c.q >> 1) * a.Wo + (c.q & 1)) * a.out_ld;
+    v += b;
+    v.x = v.x > 0.f ? v.x : p.x * v.x;
+    v.y = v.y > 0.f ? v.y : p.y * v.y;
+    v.z = v.z > 0.f ? v.z : p.z * v.z;
+    v.w = v.w > 0.f ? v.w : p.w * v.w;
+    v += res;
+    if (c.nvalid >= 4) {
+        *reinterpret_cast<f32x4*>(optr + c.co) = v;
+    } else if (c.nvalid > 0) {
+        optr[c.co] = v.x;
+        if (c.nvalid > 1) optr[c.co + 1] = v.y;
+        if (c.nvalid > 2) optr[c.co + 2] = v.z;
+    }
+}
+__device__ __forceinline__ f32x4 gemm_load_residual4(const float* rrow, const ChanPos& c) {
+    f32x4 r = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (c.nvalid >= 4) {
+        r = *reinterpret_cast<const f32x4*>(rrow + c.co);
+    } else if (c.nvalid > 0) {
+        r.x = rrow[c.co];
+        if (c.nvalid > 1) r.y = rrow[c.co + 1];
+        if (c.nvalid > 2) r.z = rrow[c.co + 2];
+    }
+    return r;
+}
+
 // gemm_f16x3.hip
 int launch_gemm_f16x3(const GemmDev& d, int ngemm, hipStream_t stream);
 // gemm_split.hip (LINEAR rows read from fp16 hi/lo planes by LDS-DMA)

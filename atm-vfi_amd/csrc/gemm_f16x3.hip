@@ -13,6 +13,8 @@
 #include "common.h"
 #include "gemm_common.h"
 
+#include <stdlib.h>
+
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 #ifdef ATMVFI_STAMP
@@ -54,6 +56,8 @@ __global__ __launch_bounds__(512) void gemm_f16x3_kernel(const GemmDev a) {
     _Float16* a_lo = a_hi + 2 * BM * 32;
     _Float16* b_hi = a_lo + 2 * BM * 32;             // [2][BN][32]
     _Float16* b_lo = b_hi + 2 * BN * 32;
+    constexpr int CF = atmvfi::gemm_const_floats(BN);
+    float* cst_base = reinterpret_cast<float*>(b_lo + 2 * BN * 32);      // [2][CF] epilogue constants, by tile parity (gemm_common.h)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -226,9 +230,12 @@ __global__ __launch_bounds__(512) void gemm_f16x3_kernel(const GemmDev a) {
         if (m0 < a.M) break;
     }
     setup_tile(m0, n0);
+    int par = 0;
+    atmvfi::gemm_dma_consts<BN>(a, n0, cst_base, wave, lane);
     load_chunk(0);
     GSTAMP(0);
     for (;;) {
+        const float* cst = cst_base + par * CF;
         store_chunk(0);
         __syncthreads();
         GSTAMP(1);
@@ -294,19 +301,32 @@ __global__ __launch_bounds__(512) void gemm_f16x3_kernel(const GemmDev a) {
         }
         if (more) {
             setup_tile(m0, n0);
+            // next tile's constants into the other parity buffer: it was last read in the previous tile's epilogue, and every
+            // wave has passed this tile's barriers since
+            atmvfi::gemm_dma_consts<BN>(a, n0, cst_base + (par ^ 1) * CF, wave, lane);
             load_chunk(0);
         }
         GSTAMP(6);
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
-            const atmvfi::ChanVec cv = atmvfi::gemm_chan_vec(a, n0_cur + 16 * j + 4 * g);
+            const int cl = 16 * j + 4 * g;
+            const atmvfi::ChanPos cp = atmvfi::gemm_chan_pos(a, n0_cur + cl);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(cst + cl);
+            const f32x4 p = *reinterpret_cast<const f32x4*>(cst + BN + cl);
+            f32x4 res[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                if (live[i]) atmvfi::gemm_store4(a, orow[i], rrow[i], cv, acc[i][j] + cor[i][j] * LO_UNSCALE);
+                res[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (a.residual && live[i]) res[i] = atmvfi::gemm_load_residual4(rrow[i], cp);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (live[i]) atmvfi::gemm_finish_store4(a, orow[i], cp, acc[i][j] + cor[i][j] * LO_UNSCALE, b, p, res[i]);
                 acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 cor[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
+        par ^= 1;
         GSTAMP(7);
 #ifdef ATMVFI_STAMP
         if (!more && a.stamp && lane == 0) {
@@ -321,7 +341,7 @@ __global__ __launch_bounds__(512) void gemm_f16x3_kernel(const GemmDev a) {
 template <int WN>
 int launch(const GemmDev& d, int ntiles, hipStream_t s) {
     constexpr int BN = 16 * WN;
-    const size_t lds = (size_t)(4 * 256 * 32 + 4 * BN * 32) * sizeof(_Float16);
+    const size_t lds = (size_t)(4 * 256 * 32 + 4 * BN * 32) * sizeof(_Float16) + 2 * atmvfi::gemm_const_floats(BN) * sizeof(float);
     auto kern = gemm_f16x3_kernel<WN>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -348,11 +368,14 @@ int launch(const GemmDev& d, int ntiles, hipStream_t s) {
 
 int atmvfi::launch_gemm_f16x3(const GemmDev& d, int ngemm, hipStream_t s) {
     const int ntiles = (ngemm + 15) / 16;
+    // tile width: MFMA work ~ padded tiles, operand staging (incl. the fp32 -> fp16-pair split, redone per column block) ~ 1/WN;
+    // the split makes narrow tiles dearer here than in the exact-fp32 engine: weight 2 measured best (deconv 788x389: -12 %)
+    static const float cfac = [] { const char* e = getenv("ATMVFI_WN_COST"); return e ? (float)atof(e) : 2.0f; }();
     int best = 1;
     float best_cost = 1e30f;
     for (int wn = 1; wn <= 8; ++wn) {
         const int padded = (ntiles + wn - 1) / wn * wn;
-        const float cost = (float)padded * (1.0f + 1.0f / (float)wn);
+        const float cost = (float)padded * (1.0f + cfac / (float)wn);
         if (cost <= best_cost) { best_cost = cost; best = wn; }
     }
     switch (best) {

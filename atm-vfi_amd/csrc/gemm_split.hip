@@ -81,6 +81,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_split_kernel(const Gem
     const long long m0 = ((long long)mgrp * 8 + xcd) * BM;
     if (m0 >= a.M) return;
     const int n0 = nblk * BN;
+    float* cst = reinterpret_cast<float*>(smem + 3 * STAGE_HALVES);       // epilogue constants of this column block (gemm_common.h)
 
     // ---- DMA pieces: P = (i*NW + wave)*64 + lane.  A: plane = P / (4*BM), row = (P>>2) % BM, physical slot = lane&3;
     //      the LDS image is linear in P (hi plane then lo plane), i.e. wave-uniform base + lane*16 B as LDS-DMA requires.
@@ -166,6 +167,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_split_kernel(const Gem
 #endif
     SPLIT_STAMP(0);
     const int nk = (a.dbg & 2) ? 1 : a.nchunks32;
+    atmvfi::gemm_dma_consts<BN>(a, n0, cst, wave, lane);      // oldest DMA of the wave: landed whenever stage 0 has
     issue(0, 0);
     if (nk > 1) issue(1, 1);
     if (nk > 2) issue(2, 2);
@@ -242,11 +244,21 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_split_kernel(const Gem
         float* orow;
         const float* rrow;
         bool live = m < a.M && atmvfi::gemm_out_row(a, m, orow, rrow);
+        if (a.dbg & 1) live = live && acc[i][0].x == 12345.678f;
+        // residual vectors of the whole row first (one wait), then the four stores back to back
+        f32x4 res[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const atmvfi::ChanVec cv = atmvfi::gemm_chan_vec(a, n0 + 64 * wn + 16 * j + 4 * g);
-            if ((a.dbg & 1) && acc[i][j].x != 12345.678f) live = false;
-            if (live) atmvfi::gemm_store4(a, orow, rrow, cv, acc[i][j] + cor[i][j] * LO_UNSCALE);
+            res[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (a.residual && live) res[j] = atmvfi::gemm_load_residual4(rrow, atmvfi::gemm_chan_pos(a, n0 + 64 * wn + 16 * j + 4 * g));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int cl = 64 * wn + 16 * j + 4 * g;
+            const atmvfi::ChanPos cp = atmvfi::gemm_chan_pos(a, n0 + cl);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(cst + cl);
+            const f32x4 p = *reinterpret_cast<const f32x4*>(cst + BN + cl);
+            if (live) atmvfi::gemm_finish_store4(a, orow, cp, acc[i][j] + cor[i][j] * LO_UNSCALE, b, p, res[j]);
         }
     }
 #ifdef ATMVFI_STAMP
@@ -281,7 +293,7 @@ __global__ void split_planes_kernel(const float* __restrict__ in, int in_ld, lon
 template <int WGM, int WGN>
 int launch_split(const GemmDev& d, int ngemm, hipStream_t s) {
     constexpr int BM = 64 * WGM, BN = 64 * WGN;
-    const size_t lds = (size_t)3 * (2 * BM + 2 * BN) * 32 * sizeof(_Float16);
+    const size_t lds = (size_t)3 * (2 * BM + 2 * BN) * 32 * sizeof(_Float16) + atmvfi::gemm_const_floats(BN) * sizeof(float);
     auto kern = gemm_split_kernel<WGM, WGN>;
     static bool attr_set = false;
     if (!attr_set) {
