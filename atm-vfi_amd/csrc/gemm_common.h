@@ -198,6 +198,8 @@ __device__ __forceinline__ f32x4 gemm_load_residual4(const float* rrow, const Ch
 
 // gemm_f16x3.hip
 int launch_gemm_f16x3(const GemmDev& d, int ngemm, hipStream_t stream);
+// conv_small.hip (first layer: 3 input channels, direct on the vector ALU)
+bool try_launch_conv3x3_small(const GemmDev& d, int kh, int* rc, hipStream_t stream);
 // gemm_split.hip (LINEAR rows read from fp16 hi/lo planes by LDS-DMA)
 int launch_gemm_split(const GemmDev& d, int ngemm, hipStream_t stream);
 

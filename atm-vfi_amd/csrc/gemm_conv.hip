@@ -335,6 +335,10 @@ extern "C" int atmvfi_gemm(const atmvfi_gemm_params* p, void* stream) {
         return atmvfi::launch_gemm_f16x3(d, ngemm, (hipStream_t)stream);
     }
 
+    {
+        int rc = 0;
+        if (atmvfi::try_launch_conv3x3_small(d, p->kh, &rc, (hipStream_t)stream)) return rc;
+    }
     // choose the wave tile width WN (block = 128 x 16*WN): MFMA work scales with the padded tile
     // count, operand traffic per MFMA with (1/BM + 1/BN) -- a narrow tile re-reads the activation
     // panel once per n-block (measured: N=197 as 13 x WN=1 ran at 30 TF/s, as 2 x WN=7 at ~90).
