@@ -29,8 +29,6 @@ namespace {
 template <int WN>
 __global__ __launch_bounds__(512) void conv3x3_f16x3_row_kernel(const Conv3Dev a) {
     constexpr int BN = 16 * WN;
-    constexpr int BP = 3 * BN * 8;                  // 16-byte weight pieces per stage: 3 taps x (hi + lo) planes
-    constexpr int B_PPT = (BP + 511) / 512;
     extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
     _Float16* halo_hi = smem;                           // [NPIX][32]
     _Float16* halo_lo = halo_hi + NPIX * 32;
@@ -75,25 +73,24 @@ __global__ __launch_bounds__(512) void conv3x3_f16x3_row_kernel(const Conv3Dev a
         hdst[k] = hp * 32 + ((q ^ swz64(hp)) << 3);
         hq[k] = q;
     }
-    // ---- weight pieces: P = tid + 512*k -> (plane, tap-in-row t, row, slot) ----
-    const _Float16* wsrc[B_PPT];
-    int wdst[B_PPT];
-    bool wok[B_PPT], wact[B_PPT], wlo[B_PPT];
-    const long long ktot = a.ktot;
+    // ---- weights by LDS-DMA: the fp16 planes go global -> LDS without touching registers (no wr[] staging, no ds_write
+    // phase).  One wave-instruction = 16 rows x 64 B of one (plane, tap): wave-piece q = wave + 8k -> plane = q / (3 WN),
+    // tap t = (q / WN) % 3, row group q % WN; lane = (row in group, physical slot), the swizzle goes on the SOURCE slot. ----
+    constexpr int NWPIECE = 6 * WN;                       // wave-pieces per stage
+    constexpr int NWP = (NWPIECE + 7) / 8;                // per wave (the last one may be inactive: wave-uniform)
+    const _Float16* wsrc[NWP];
+    int wdst[NWP];
 #pragma unroll
-    for (int k = 0; k < B_PPT; ++k) {
-        const int P = tid + 512 * k;
-        wact[k] = P < BP;
-        const int plane = (P >= 3 * BN * 4) ? 1 : 0;
-        int rem = P - plane * 3 * BN * 4;
-        const int t = wact[k] ? rem / (BN * 4) : 0;
-        rem -= t * BN * 4;
-        const int row = wact[k] ? (rem >> 2) : 0;
-        const int slot = rem & 3;
-        wlo[k] = plane == 1;
-        wok[k] = wact[k] && (n0 + row) < a.wrows;
-        wsrc[k] = (plane ? a.w_lo : a.w_hi) + (long long)(wok[k] ? n0 + row : 0) * ktot + (long long)t * a.cs + slot * 8;
-        wdst[k] = (t * BN + row) * 32 + ((slot ^ swz64(row)) << 3);
+    for (int k = 0; k < NWP; ++k) {
+        const int qq = wave + 8 * k;
+        const int qc = qq < NWPIECE ? qq : 0;
+        const int plane = qc / (3 * WN);
+        const int t = (qc / WN) % 3;
+        const int row = 16 * (qc % WN) + (lane >> 2);
+        const int ls = (lane & 3) ^ swz64(row);
+        const int nrow = (n0 + row) < a.wrows ? n0 + row : a.wrows - 1;      // rows past the packed ones: columns never stored
+        wsrc[k] = (plane ? a.w_lo : a.w_hi) + (long long)nrow * a.ktot + (long long)t * a.cs + ls * 8;
+        wdst[k] = plane * (2 * 3 * BN * 32) + (t * BN + 16 * (qc % WN)) * 32;      // halves from b_hi (b_lo = b_hi + 2*3*BN*32)
     }
 
     f32x4 acc[2][WN], cor[2][WN];
@@ -113,7 +110,6 @@ __global__ __launch_bounds__(512) void conv3x3_f16x3_row_kernel(const Conv3Dev a
 
     f32x4 hr[HALO_TPT][2];
     int hnv[HALO_TPT];
-    f16x8 wr[B_PPT];
 
     auto halo_load = [&](int k, int chunk) {
         // Unconditional loads from a clamped, always-valid address, zeroed afterwards by selects: a
@@ -147,22 +143,16 @@ __global__ __launch_bounds__(512) void conv3x3_f16x3_row_kernel(const Conv3Dev a
             *reinterpret_cast<f16x8*>(halo_lo + hdst[k]) = lo;
         }
     };
-    auto w_load = [&](int stage) {
+    auto w_dma = [&](int stage, int buf) {
         const int chunk = stage / 3;
         const int ky = stage - chunk * 3;
         // the tail stage is (chunk nfull, ky 0) of the same formula: its three k-steps are stored behind taps 0..2
         const long long koff = (long long)(ky * 3) * a.cs + chunk * 32;
 #pragma unroll
-        for (int k = 0; k < B_PPT; ++k) {
-            wr[k] = *reinterpret_cast<const f16x8*>(wsrc[k] + koff);         // row-clamped address: always valid; masked at store
-        }
-    };
-    auto w_store = [&](int buf) {
-#pragma unroll
-        for (int k = 0; k < B_PPT; ++k)
-            if (wact[k])
-                *reinterpret_cast<f16x8*>((wlo[k] ? b_lo : b_hi) + buf * 3 * BN * 32 + wdst[k]) =
-                    wok[k] ? wr[k] : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        for (int k = 0; k < NWP; ++k)
+            if (wave + 8 * k < NWPIECE)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[k] + koff),
+                                                 (__attribute__((address_space(3))) void*)(b_hi + buf * 3 * BN * 32 + wdst[k]), 16, 0, 0);
     };
 
     int dtail = 0;                 // halo offsets of taps 4t+g, t = 0..2, one byte each (taps 9..11 carry zero weights: any
@@ -178,10 +168,10 @@ __global__ __launch_bounds__(512) void conv3x3_f16x3_row_kernel(const Conv3Dev a
     dma_epilogue_consts<BN>(a.bias, a.prelu, n0, cst, wave, lane, [&](int col) { return col < a.Cout ? col : -1; });
 #pragma unroll
     for (int k = 0; k < HALO_TPT; ++k) halo_load(k, 0);
-    w_load(0);
+    w_dma(0, 0);
 #pragma unroll
     for (int k = 0; k < HALO_TPT; ++k) halo_store(k);
-    w_store(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // own DMA pieces have landed; the barrier publishes everyone's
     __syncthreads();
     STAMP(0)
 
@@ -194,7 +184,7 @@ __global__ __launch_bounds__(512) void conv3x3_f16x3_row_kernel(const Conv3Dev a
         asm volatile("" : "+v"(dt));       // opaque: keeps hipcc from hoisting the six tail-stage offsets out of the loop (spills at WN = 8)
         const bool more_w = (s + 1) < nstages;
         const bool next_halo = (ky == 2) && (chunk + 1 < nchunks);
-        if (more_w) w_load(s + 1);
+        if (more_w) w_dma(s + 1, wb ^ 1);       // that buffer was last read in stage s-1: everyone has passed its barrier
         if (next_halo) {
 #pragma unroll
             for (int k = 0; k < HALO_TPT; ++k) halo_load(k, chunk + 1);
@@ -244,7 +234,7 @@ __global__ __launch_bounds__(512) void conv3x3_f16x3_row_kernel(const Conv3Dev a
             }
         }
         STAMP(2)
-        if (more_w) w_store(wb ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next stage's weights (issued a whole stage ago) and next chunk's halo loads
         STAMP(3)
         __syncthreads();
         STAMP(4)
