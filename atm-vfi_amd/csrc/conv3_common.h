@@ -23,6 +23,8 @@ struct Conv3Dev {
     const float* prelu;
     int tiles_x, tiles_y;
     int nblocks;    // column blocks per spatial tile (set by the launcher)
+    int legacy_order;   // A/B switch (ATMVFI_LEGACY_ORDER=1): round-robin tiles over XCDs
+    int tchunk;     // spatial tiles per XCD = ceil(tiles / 8) (set by the launcher)
     unsigned long long* stamp;   // diagnostic builds only (ATMVFI_STAMP)
 };
 // conv3x3_f16x3_row.hip: three taps (one kernel row) per stage, single-buffered halo

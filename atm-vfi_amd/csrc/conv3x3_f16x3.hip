@@ -127,6 +127,8 @@ extern "C" int atmvfi_conv3x3_f16x3(const float* in, int in_ld, int N, int H, in
     d.Cout = Cout; d.out = out; d.out_ld = out_ld; d.bias = bias; d.prelu = prelu;
     d.stamp = nullptr;
     d.nblocks = 0;
+    d.tchunk = 0;
+    d.legacy_order = 0;
     d.tiles_x = (W + TW - 1) / TW;
     d.tiles_y = (H + TH - 1) / TH;
     ATMVFI_REQUIRE((long long)N * d.tiles_x * d.tiles_y < (1ll << 31), ATMVFI_EINVAL, "conv3x3_f16x3: grid too large");

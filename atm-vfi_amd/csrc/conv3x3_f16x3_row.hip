@@ -13,6 +13,8 @@
 // Weight fragments are read one n-tile ahead of the MFMAs that consume them.
 #include "conv3_common.h"
 
+#include <stdlib.h>
+
 #ifdef ATMVFI_STAMP
 // Diagnostic build only (`make stamp`, tools/stamp_conv.py): per-wave cycle sums of the phases of a stage.
 static unsigned long long* g_stamp_buf = nullptr;
@@ -42,17 +44,25 @@ __global__ __launch_bounds__(512) void conv3x3_f16x3_row_kernel(const Conv3Dev a
     const int r = lane & 15;
     const int g = lane >> 4;
 
-    // XCD-aware order: blocks b and b+8 share an XCD, so the column blocks that re-read one halo tile are dealt to
-    // one XCD back to back (halo from HBM once, from that XCD's L2 afterwards)
+    // XCD-aware order.  Blocks b and b+8 share an XCD and its 4 MiB L2, so (1) the column blocks that re-read one halo tile are
+    // dealt to one XCD back to back, and (2) each XCD takes one contiguous eighth of the tiles in an order that keeps halo
+    // neighbours close: groups of 8 tile rows walked column by column (vertical neighbours are consecutive, the next column is
+    // 8 tiles later), so the 2-of-18 halo rows / columns shared by adjacent tiles are fetched from HBM once.
     const int slot = blockIdx.x >> 3;
     const int sgrp = slot / a.nblocks;
     const int nblk = slot - sgrp * a.nblocks;
-    int bid = sgrp * 8 + (blockIdx.x & 7);
-    if (bid >= a.N * a.tiles_x * a.tiles_y) return;
-    const int txb = bid % a.tiles_x;
-    bid /= a.tiles_x;
-    const int tyb = bid % a.tiles_y;
-    const int img = bid / a.tiles_y;
+    int L = (blockIdx.x & 7) * a.tchunk + sgrp;                  // position in the tile order
+    const int per_img = a.tiles_x * a.tiles_y;
+    if (a.legacy_order) L = sgrp * 8 + (blockIdx.x & 7);
+    if (L >= a.N * per_img) return;
+    const int img = L / per_img;
+    L -= img * per_img;
+    const int grp = L / (8 * a.tiles_x);
+    const int rem = L - grp * 8 * a.tiles_x;
+    const int rows_here = (a.tiles_y - 8 * grp) < 8 ? a.tiles_y - 8 * grp : 8;
+    int txb = rem / rows_here;
+    int tyb = 8 * grp + (rem - txb * rows_here);
+    if (a.legacy_order) { txb = L % a.tiles_x; tyb = L / a.tiles_x; }
     const int ox0 = txb * TW, oy0 = tyb * TH;
     const int n0 = nblk * BN;
 
@@ -304,6 +314,9 @@ int launch_row(const Conv3Dev& d, int ntiles, hipStream_t s) {
     Conv3Dev ds = d;
     ds.nblocks = (ntiles + WN - 1) / WN;
     const long long sgroups = ((long long)d.N * d.tiles_x * d.tiles_y + 7) / 8;
+    ds.tchunk = (int)sgroups;
+    static const int legacy = [] { const char* e = getenv("ATMVFI_LEGACY_ORDER"); return e ? atoi(e) : 0; }();
+    ds.legacy_order = legacy;
     ATMVFI_REQUIRE(sgroups * 8 * ds.nblocks < (1LL << 31), ATMVFI_EINVAL, "conv3x3_f16x3_row: grid too large");
     dim3 grid((unsigned)(sgroups * 8 * ds.nblocks));
 #ifdef ATMVFI_STAMP

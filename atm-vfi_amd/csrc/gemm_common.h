@@ -43,6 +43,7 @@ struct GemmDev {
     const _Float16* a_lo;
     unsigned long long* stamp;   // diagnostic builds only (ATMVFI_STAMP)
     int dbg;          // diagnostic ablations (gemm_split.hip, env ATMVFI_SPLIT_DEBUG): 1 = no stores, 2 = one k-step
+    int mchunk;       // row tiles per XCD = ceil(row tiles / 8)
     int vblocks;      // virtual blocks (tiles incl. XCD padding) walked by the persistent grid
     int nblocks;      // column blocks per row tile (set by the launcher; XCD-aware tile order)
 };

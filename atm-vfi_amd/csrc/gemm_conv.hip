@@ -320,6 +320,7 @@ extern "C" int atmvfi_gemm(const atmvfi_gemm_params* p, void* stream) {
     d.nblocks = 0;
     d.dbg = 0;
     d.vblocks = 0;
+    d.mchunk = 0;
     d.stamp = nullptr;
     d.w_hi = (const _Float16*)p->weight_hi;
     d.w_lo = (const _Float16*)p->weight_lo;

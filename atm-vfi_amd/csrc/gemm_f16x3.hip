@@ -96,7 +96,9 @@ __global__ __launch_bounds__(512) void gemm_f16x3_kernel(const GemmDev a) {
         const int slot = vb >> 3;
         const int mgrp = slot / a.nblocks;
         const int nblk = slot - mgrp * a.nblocks;
-        m0 = ((long long)mgrp * 8 + xcd) * BM;
+        // each XCD owns one contiguous eighth of the row tiles: consecutive row tiles of a CONV layer read overlapping input rows
+        m0 = ((long long)xcd * a.mchunk + mgrp) * BM;
+        if (a.dbg & 8) m0 = ((long long)mgrp * 8 + xcd) * BM;     // A/B switch (ATMVFI_LEGACY_ORDER=1)
         n0 = nblk * BN;
     };
     auto setup_tile = [&](long long m0, int n0) {
@@ -354,6 +356,9 @@ int launch(const GemmDev& d, int ntiles, hipStream_t s) {
     const long long mgroups = (atmvfi::ceil_div64(d.M, 256) + 7) / 8;
     ATMVFI_REQUIRE(mgroups * 8 * dd.nblocks < (1LL << 31), ATMVFI_EINVAL, "gemm_f16x3: too many tiles");
     dd.vblocks = (int)(mgroups * 8 * dd.nblocks);
+    dd.mchunk = (int)mgroups;
+    static const int legacy = [] { const char* e = getenv("ATMVFI_LEGACY_ORDER"); return e ? atoi(e) : 0; }();
+    dd.dbg = legacy ? 8 : 0;
 #ifdef ATMVFI_STAMP
     dd.stamp = g_gemm_stamp;
 #endif
