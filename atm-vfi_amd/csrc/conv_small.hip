@@ -17,6 +17,7 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(const GemmDev a) {
     constexpr int K = 9 * CIN;
     __shared__ __attribute__((aligned(16))) float wl[K * COUT];           // [k = tap*CIN + c][cout]
     __shared__ __attribute__((aligned(16))) float tile[18 * 18 * 4];      // halo, 4 floats per pixel
+    __shared__ __attribute__((aligned(16))) float outp[256 * COUT];       // results, [pixel of the tile][cout]
     const int tid = threadIdx.x;
     for (int i = tid; i < K * COUT; i += 256) {
         const int k = i / COUT, o = i - k * COUT;
@@ -55,9 +56,6 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(const GemmDev a) {
 #pragma unroll
         for (int c = 0; c < CIN; ++c) x[t * CIN + c] = e[c];
     }
-    const int oy = oy0 + py, ox = ox0 + px;
-    const bool live = oy < a.H && ox < a.W;
-    float* orow = a.out + (((long long)img * a.H + (live ? oy : 0)) * a.W + (live ? ox : 0)) * a.out_ld;
 #pragma unroll
     for (int o4 = 0; o4 < CO4; ++o4) {
         f32x4 acc = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + 4 * o4) : (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -76,7 +74,30 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(const GemmDev a) {
             acc.z = acc.z > 0.f ? acc.z : p.z * acc.z;
             acc.w = acc.w > 0.f ? acc.w : p.w * acc.w;
         }
-        if (live) *reinterpret_cast<f32x4*>(orow + 4 * o4) = acc;
+        *reinterpret_cast<f32x4*>(outp + tid * COUT + 4 * o4) = acc;
+    }
+    // Store through LDS in memory order: a thread's COUT floats are COUT*4 bytes apart from its neighbour's, so direct 16-byte
+    // stores touch every line COUT/4 times with partial sectors (PMC: 2.2x the output bytes written).  Each wave owns 4 tile rows
+    // of 16 pixels; piece q = 16 bytes of the wave's [4][16 pixels][COUT] image, written out 1 KiB per instruction.
+    const int lane = tid & 63, wave = tid >> 6;
+    if (a.out_ld == COUT) {
+#pragma unroll
+        for (int k = 0; k < CO4; ++k) {
+            const int q = k * 64 + lane;                        // 0 .. 4*16*CO4
+            const int row = q / (16 * CO4);
+            const int off = q - row * (16 * CO4);               // 16-byte piece inside the row: pixel off / CO4, channels 4*(off % CO4)
+            const int oy = oy0 + 4 * wave + row, ox = ox0 + off / CO4;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(outp + (wave * 64 + row * 16) * COUT + 4 * off);
+            if (oy < a.H && ox < a.W)
+                *reinterpret_cast<f32x4*>(a.out + (((long long)img * a.H + oy) * a.W + ox0) * COUT + 4 * off) = v;
+        }
+    } else {                                                   // channel-slice output view: pixel records are not contiguous
+        const int oy = oy0 + py, ox = ox0 + px;
+        if (oy < a.H && ox < a.W) {
+            float* orow = a.out + (((long long)img * a.H + oy) * a.W + ox) * a.out_ld;
+#pragma unroll
+            for (int o4 = 0; o4 < CO4; ++o4) *reinterpret_cast<f32x4*>(orow + 4 * o4) = *reinterpret_cast<const f32x4*>(outp + tid * COUT + 4 * o4);
+        }
     }
 }
 

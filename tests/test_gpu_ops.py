@@ -46,7 +46,9 @@ def maxdiff(a, b):
 # ------------------------------------------------------------------ contractions
 CONV_CASES = [
     # cin, cout, k, stride, pad, dil, H, W, in_off, in_ld, out_off, out_ld, N
-    (3, 24, 3, 1, 1, 1, 20, 28, 0, 4, 0, 24, 2),          # first layer: NHWC4 input, Cin=3
+    (3, 24, 3, 1, 1, 1, 20, 28, 0, 4, 0, 24, 2),          # first layer: NHWC4 input, Cin=3 (direct vector-ALU kernel)
+    (3, 16, 3, 1, 1, 1, 21, 19, 0, 4, 8, 32, 1),          # lite's first layer, written into a channel slice, ragged tiles
+    (3, 32, 3, 1, 1, 1, 16, 16, 0, 4, 0, 32, 1),
     (24, 48, 3, 2, 1, 1, 20, 28, 0, 24, 0, 48, 2),
     (48, 48, 3, 4, 1, 1, 24, 40, 0, 48, 96, 384, 2),       # fusion conv, stride 4, writes a slice
     (48, 48, 3, 4, 2, 2, 24, 40, 0, 48, 144, 384, 2),      # stride 4, dilation 2
