@@ -362,6 +362,47 @@ __global__ __launch_bounds__(256) void pack_frames_kernel(const float* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Host-boundary frames (demo_2x.py:64-85 inference_2frame, benchmark/utils.py:57-80 InputPadder):
+//   uint8 HWC (BGR or RGB) -> fp32 planar RGB in [0,1] (x / 255, a true fp32 division as torch does), centred replicate padding
+//   fp32 planar -> unpad -> np.round(x * 255) (round half to even) -> uint8 HWC
+// Integer / byte work: bit-exact against the numpy path by construction.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void frame_u8_to_f32_kernel(const unsigned char* __restrict__ src, int H, int W, int bgr,
+                                                              float* __restrict__ dst, int Hp, int Wp, int pad_top, int pad_left) {
+    const long long total = (long long)Hp * Wp;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int y = (int)(idx / Wp), x = (int)(idx - (long long)y * Wp);
+        int sy = y - pad_top, sx = x - pad_left;                 // replicate: clamp to the source frame
+        sy = sy < 0 ? 0 : (sy >= H ? H - 1 : sy);
+        sx = sx < 0 ? 0 : (sx >= W ? W - 1 : sx);
+        const unsigned char* p = src + ((long long)sy * W + sx) * 3;
+        const float c0 = (float)p[0] / 255.0f, c1 = (float)p[1] / 255.0f, c2 = (float)p[2] / 255.0f;
+        dst[idx] = bgr ? c2 : c0;
+        dst[total + idx] = c1;
+        dst[2 * total + idx] = bgr ? c0 : c2;
+    }
+}
+
+__global__ __launch_bounds__(256) void frame_f32_to_u8_kernel(const float* __restrict__ src, int Hp, int Wp, int pad_top, int pad_left,
+                                                              unsigned char* __restrict__ dst, int H, int W, int bgr) {
+    const long long total = (long long)H * W, plane = (long long)Hp * Wp;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int y = (int)(idx / W), x = (int)(idx - (long long)y * W);
+        const float* p = src + (long long)(y + pad_top) * Wp + (x + pad_left);
+        int v[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int q = __float2int_rn(p[c * plane] * 255.0f);        // rint: half to even, as np.round
+            v[c] = q < 0 ? 0 : (q > 255 ? 255 : q);
+        }
+        unsigned char* o = dst + idx * 3;
+        o[0] = (unsigned char)(bgr ? v[2] : v[0]);
+        o[1] = (unsigned char)v[1];
+        o[2] = (unsigned char)(bgr ? v[0] : v[2]);
+    }
+}
+
 __global__ __launch_bounds__(256) void final_residual_kernel(const float* __restrict__ it, const float* __restrict__ r, int r_ld,
                                                              float* __restrict__ it_sum, float* __restrict__ it_clamped,
                                                              int B, int H, int W) {
@@ -512,6 +553,26 @@ extern "C" int atmvfi_pack_frames(const float* im0, const float* im1, float* dst
     hipLaunchKernelGGL(pack_frames_kernel, dim3(grid_for(2ll * B * H * W)), dim3(256), 0, (hipStream_t)stream, im0, im1, dst,
                        B, H, W);
     return atmvfi::check_launch("pack_frames");
+}
+
+extern "C" int atmvfi_frame_u8_to_f32(const void* src, int H, int W, int bgr, float* dst, int Hp, int Wp, int pad_top, int pad_left,
+                                       void* stream) {
+    ATMVFI_REQUIRE(src && dst && H > 0 && W > 0 && Hp >= H && Wp >= W && pad_top >= 0 && pad_left >= 0 && pad_top + H <= Hp &&
+                       pad_left + W <= Wp,
+                   ATMVFI_EINVAL, "frame_u8_to_f32: bad geometry (H %d W %d -> Hp %d Wp %d, pad %d %d)", H, W, Hp, Wp, pad_top, pad_left);
+    hipLaunchKernelGGL(frame_u8_to_f32_kernel, dim3(grid_for((long long)Hp * Wp)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned char*)src, H, W, bgr, dst, Hp, Wp, pad_top, pad_left);
+    return atmvfi::check_launch("frame_u8_to_f32");
+}
+
+extern "C" int atmvfi_frame_f32_to_u8(const float* src, int Hp, int Wp, int pad_top, int pad_left, void* dst, int H, int W, int bgr,
+                                       void* stream) {
+    ATMVFI_REQUIRE(src && dst && H > 0 && W > 0 && Hp >= H && Wp >= W && pad_top >= 0 && pad_left >= 0 && pad_top + H <= Hp &&
+                       pad_left + W <= Wp,
+                   ATMVFI_EINVAL, "frame_f32_to_u8: bad geometry (Hp %d Wp %d -> H %d W %d, pad %d %d)", Hp, Wp, H, W, pad_top, pad_left);
+    hipLaunchKernelGGL(frame_f32_to_u8_kernel, dim3(grid_for((long long)H * W)), dim3(256), 0, (hipStream_t)stream, src, Hp, Wp,
+                       pad_top, pad_left, (unsigned char*)dst, H, W, bgr);
+    return atmvfi::check_launch("frame_f32_to_u8");
 }
 
 extern "C" int atmvfi_final_residual(const float* it, const float* r, int r_ld, float* it_sum, float* it_clamped, int B,

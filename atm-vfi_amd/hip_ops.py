@@ -82,6 +82,8 @@ SIGNATURES = {
     "atmvfi_warp_blend": (c_i, [c_f, c_f, c_f, c_i, c_l, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i,
                                 c_i, c_i, c_i, c_f]),
     "atmvfi_resize_bilinear_ac": (c_i, [c_f, c_l, c_l, c_l, c_l, c_f, c_i, c_i, c_i, c_i, c_i, c_i, ctypes.c_float, c_f]),
+    "atmvfi_frame_u8_to_f32": (c_i, [c_f, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_f]),
+    "atmvfi_frame_f32_to_u8": (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_f]),
     "atmvfi_pack_frames": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_f]),
     "atmvfi_final_residual": (c_i, [c_f, c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_f]),
     "atmvfi_l1_mean": (c_i, [c_f, c_f, c_f, c_i, c_l, c_f]),
@@ -477,6 +479,26 @@ class HipOps:
         meta = {"bytes": 4.0 * b * c * (hi * wi + dst.shape[2] * dst.shape[3])}
         self._run("resize_bilinear_ac", meta, self.lib.atmvfi_resize_bilinear_ac, _ptr(src), src.stride(0), src.stride(1),
                   src.stride(2), src.stride(3), _ptr(dst), b, c, hi, wi, dst.shape[2], dst.shape[3], float(value_scale), self._stream())
+
+    def frame_u8_to_f32(self, src_u8, dst, pad_top: int, pad_left: int, bgr: bool):
+        """uint8 [H,W,3] device tensor -> fp32 planar [3,Hp,Wp] (x / 255, replicate padding, optional BGR -> RGB)."""
+        if src_u8.dtype != torch.uint8 or src_u8.dim() != 3 or src_u8.shape[2] != 3 or not src_u8.is_contiguous() or not src_u8.is_cuda:
+            raise ValueError("frame_u8_to_f32: source must be a contiguous CUDA uint8 [H,W,3] tensor")
+        if dst.dtype != torch.float32 or dst.dim() != 3 or dst.shape[0] != 3 or not dst.is_contiguous() or not dst.is_cuda:
+            raise ValueError("frame_u8_to_f32: destination must be a contiguous CUDA fp32 [3,Hp,Wp] tensor")
+        h, w = src_u8.shape[:2]
+        self._run("frame_u8_to_f32", {"bytes": 3.0 * h * w + 12.0 * dst.shape[1] * dst.shape[2]}, self.lib.atmvfi_frame_u8_to_f32,
+                  src_u8.data_ptr(), h, w, int(bgr), _ptr(dst), dst.shape[1], dst.shape[2], pad_top, pad_left, self._stream())
+
+    def frame_f32_to_u8(self, src, dst_u8, pad_top: int, pad_left: int, bgr: bool):
+        """fp32 planar [3,Hp,Wp] -> crop -> np.round(x * 255) -> uint8 [H,W,3] device tensor (optional RGB -> BGR)."""
+        if src.dtype != torch.float32 or src.dim() != 3 or src.shape[0] != 3 or not src.is_contiguous() or not src.is_cuda:
+            raise ValueError("frame_f32_to_u8: source must be a contiguous CUDA fp32 [3,Hp,Wp] tensor")
+        if dst_u8.dtype != torch.uint8 or dst_u8.dim() != 3 or dst_u8.shape[2] != 3 or not dst_u8.is_contiguous() or not dst_u8.is_cuda:
+            raise ValueError("frame_f32_to_u8: destination must be a contiguous CUDA uint8 [H,W,3] tensor")
+        h, w = dst_u8.shape[:2]
+        self._run("frame_f32_to_u8", {"bytes": 3.0 * h * w + 12.0 * h * w}, self.lib.atmvfi_frame_f32_to_u8, _ptr(src), src.shape[1],
+                  src.shape[2], pad_top, pad_left, dst_u8.data_ptr(), h, w, int(bgr), self._stream())
 
     def pack_frames(self, im0, im1, dst):
         _planar(im0, 3, "pack_frames.im0"); _planar(im1, 3, "pack_frames.im1")

@@ -27,6 +27,7 @@ import os
 import sys
 import time
 
+import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -57,6 +58,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f32"])
+    ap.add_argument("--no-host-io", action="store_true", help="skip the PCIe-inclusive measurement (uint8 frames in host memory in and out)")
     ap.add_argument("--graph", action="store_true", help="replay the forward from a captured HIP graph (Network.enable_graphs); measured "
                     "within 0.5 %% of eager launches at 1080p and at 256x448: the stream is already back to back")
     return ap.parse_args()
@@ -210,6 +212,25 @@ def main():
                                      **({"gbs": round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1)} if d["bytes"] and d["ms"] > 0 else {})}
                                  for k, d in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
             result["kernels"]["_sum_ms"] = round(total_ms, 3)
+        # ---- PCIe-inclusive rate (never `value`): uint8 frames in host memory -> uint8 frame in host memory through
+        #      host_io.FramePipeline (pinned slots, H2D / D2H on side streams under the previous / next forward) ----
+        if world == 1 and not args.no_host_io:
+            rng = np.random.default_rng(0)
+            u8 = [rng.integers(0, 256, (args.height, args.width, 3), dtype=np.uint8) for _ in range(3)]
+            pairs_u8 = [(u8[i % 3], u8[(i + 1) % 3]) for i in range(max(args.steps, 30))]      # long enough to amortise fill and drain
+            hio = {}
+            for depth in (1, 3):
+                pipe = host_io.FramePipeline(net, args.height, args.width, isBGR=True, divisor=64, depth=depth)
+                for _ in pipe.run(pairs_u8[:2]):
+                    pass
+                torch.cuda.synchronize()
+                tp = time.perf_counter()
+                n_out = sum(1 for _ in pipe.run(pairs_u8))
+                torch.cuda.synchronize()
+                tp = time.perf_counter() - tp
+                hio["sequential" if depth == 1 else "overlapped_depth3"] = round(n_out / tp, 3)
+            result["host_io"] = {"unit": "frames/s, uint8 HWC BGR frames in pageable host memory in and out (pre/post kernels, pinned staging, PCIe both ways)",
+                                 **hio, "bytes_over_pcie_per_frame": 3 * args.height * args.width * 3}
         # ---- CPU baseline: the oracle on this node's host cores, bounded sample ----
         if world == 1 and not args.no_cpu_baseline:
             from oracle import atmvfi_oracle as O

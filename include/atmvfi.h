@@ -239,6 +239,13 @@ int atmvfi_pack_frames(const float* im0, const float* im1, float* dst /*[2B,H,W,
 int atmvfi_final_residual(const float* it /*[B,3,H,W]*/, const float* r, int r_ld,
                           float* it_sum, float* it_clamped, int B, int H, int W, void* stream);
 
+/* Host-boundary frame formats (demo_2x.py:64-85 inference_2frame + benchmark/utils.py:57-80 InputPadder), SURVEY 8f-2.
+ *   u8_to_f32: uint8 [H,W,3] (BGR if `bgr`, as cv2 delivers) -> fp32 planar RGB [3,Hp,Wp] = x / 255 with replicate padding,
+ *              the source frame sitting at (pad_top, pad_left) of the padded canvas;
+ *   f32_to_u8: the inverse: crop, np.round(x * 255) (half to even), uint8 [H,W,3].  Bit-exact against the numpy path. */
+int atmvfi_frame_u8_to_f32(const void* src, int H, int W, int bgr, float* dst, int Hp, int Wp, int pad_top, int pad_left, void* stream);
+int atmvfi_frame_f32_to_u8(const float* src, int Hp, int Wp, int pad_top, int pad_left, void* dst, int H, int W, int bgr, void* stream);
+
 /* mean |a - b| per sample: global_alignmentness (network_base.py:560-561).  out[B] must be zeroed by the caller. */
 int atmvfi_l1_mean(const float* a, const float* b, float* out, int B, int64_t per_sample, void* stream);
 

@@ -235,3 +235,32 @@ def test_graph_replay_equals_eager(dev, weights):
     net.enable_graphs(False)
     assert torch.equal(out, net(a0.to(dev), a1.to(dev))["I_t"])
     assert not torch.equal(out, eager[0]["I_t"])
+
+
+def test_frame_pipeline_matches_sequential(nets, dev):
+    """host_io.FramePipeline (pinned slots, copies on side streams) returns exactly what one-at-a-time inference_2frame returns,
+    in order, for more pairs than slots; and the generic torch path of inference_2frame (any nn.Module) agrees with the HIP one."""
+    net = nets["lite"]
+    net.global_motion = True
+    net.ensemble_global_motion = False
+    rng = np.random.default_rng(5)
+    frames = [rng.integers(0, 256, (100, 150, 3), dtype=np.uint8) for _ in range(6)]
+    pairs_ = list(zip(frames[:-1], frames[1:]))
+    seq = [host_io.inference_2frame(a, b, net, isBGR=True) for a, b in pairs_]
+    pipe = host_io.FramePipeline(net, 100, 150, isBGR=True, divisor=64, depth=2)
+    got = list(pipe.run(pairs_))
+    assert len(got) == len(seq) and all(np.array_equal(g, s) for g, s in zip(got, seq))
+    assert list(pipe.run([])) == []
+
+    class Wrapped(torch.nn.Module):           # hides the HIP backend: forces the reference-style torch pre/post path
+        def __init__(self, inner):
+            super().__init__()
+            self.inner = inner
+
+        def forward(self, a, b):
+            return self.inner(a, b)
+    generic = host_io.inference_2frame(pairs_[0][0], pairs_[0][1], Wrapped(net), isBGR=True)
+    # torch's GPU "x / 255." multiplies by the reciprocal (1 ulp off the true division the CPU reference, the golden fixtures and the
+    # HIP pre-kernel compute), so a rounding may flip here and there; never more than one level
+    d = np.abs(generic.astype(np.int32) - seq[0].astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 5e-3

@@ -561,3 +561,37 @@ def test_split_plane_sinks(hip, cpu, dev):
     assert torch.equal(p.t[0, :, :C], hi) and torch.equal(p.t[1, :, :C], lo)
     with pytest.raises(ValueError):
         hip.layernorm(src, None, gamma, beta)                              # no output at all
+
+
+# ------------------------------------------------------------------ host-boundary frame formats
+@pytest.mark.parametrize("geom", [(37, 53, 64), (64, 128, 64), (270, 480, 64), (45, 33, 32)], ids=lambda g: f"{g[0]}x{g[1]}_div{g[2]}")
+@pytest.mark.parametrize("bgr", [True, False], ids=["bgr", "rgb"])
+def test_frame_u8_f32_roundtrip_bit_exact(geom, bgr, hip, dev):
+    """uint8 HWC -> fp32 planar (+ flip, /255, replicate pad) and back (unpad, np.round(x*255)): bit-exact vs the numpy/torch path of
+    inference_2frame (demo_2x.py:64-85) and InputPadder (benchmark/utils.py:57-80)."""
+    host_io = importlib.import_module("atm-vfi_amd.host_io")
+    h, w, div = geom
+    rng = np.random.default_rng(h * 1000 + w)
+    img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    pad = host_io.InputPadder((1, 3, h, w), divisor=div)
+    l, r, t, b = pad._pad
+    hp, wp = h + t + b, w + l + r
+    ref_in = img[:, :, ::-1].copy() if bgr else img
+    ref = pad.pad((torch.tensor(ref_in.transpose(2, 0, 1)) / 255.).unsqueeze(0))[0]          # the reference's arithmetic, on CPU
+    out = torch.empty(3, hp, wp, device=dev)
+    hip.frame_u8_to_f32(torch.from_numpy(img).to(dev), out, t, l, bgr)
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), ref)
+    # back: arbitrary fp32 values in [0,1] incl. exact .5 ties after scaling
+    f = torch.rand(3, hp, wp, generator=torch.Generator().manual_seed(h))
+    f[:, :4, :4] = torch.tensor([0.5 / 255, 1.5 / 255, 2.5 / 255, 254.5 / 255]).repeat(3, 4, 1)
+    f[0, 5, 5], f[1, 5, 5], f[2, 5, 5] = 0.0, 1.0, 0.999999
+    want = np.round(pad.unpad(f.unsqueeze(0))[0].numpy().transpose(1, 2, 0) * 255).astype(np.uint8)
+    if bgr:
+        want = want[:, :, ::-1].copy()
+    got = torch.empty(h, w, 3, dtype=torch.uint8, device=dev)
+    hip.frame_f32_to_u8(f.to(dev), got, t, l, bgr)
+    torch.cuda.synchronize()
+    assert np.array_equal(got.cpu().numpy(), want)
+    with pytest.raises(RuntimeError):
+        hip.frame_f32_to_u8(f.to(dev), got, t + 100, l, bgr)
