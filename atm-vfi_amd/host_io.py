@@ -146,6 +146,52 @@ class FramePipeline:
             yield old["h_out"].numpy().copy()
 
 
+def interpolate_video_2x(frames, model, isBGR: bool = True, divisor: int = 64, depth: int = 3):
+    """The frame loop of demo_2x.py:144-163 over any iterable of uint8 [H,W,3] frames (decoding / encoding stays with the caller):
+    yields f0, I(f0,f1), f1, I(f1,f2), ..., f_{n-1} -- 2n-1 frames -- with the pairs running through ``FramePipeline``."""
+    from collections import deque
+    it = iter(frames)
+    first = next(it, None)
+    if first is None:
+        return
+    originals = deque([first])
+
+    def pairs():
+        prev = first
+        for cur in it:
+            originals.append(cur)
+            yield prev, cur
+            prev = cur
+    pipe = FramePipeline(model, first.shape[0], first.shape[1], isBGR=isBGR, divisor=divisor, depth=depth)
+    for pred in pipe.run(pairs()):
+        yield originals.popleft()
+        yield pred
+    yield originals.popleft()          # the last frame is written once (demo_2x.py:160)
+
+
+def forward_tta(model, im0, im1):
+    """Flip test-time augmentation of benchmark/test_snufilm.py:135-139: average of the prediction and the un-flipped prediction
+    on the frames flipped along H and W.  Returns ``I_t`` [B,3,H,W]."""
+    pred = model.forward(im0, im1)["I_t"]
+    pred_flip = model.forward(im0.flip(2).flip(3).contiguous(), im1.flip(2).flip(3).contiguous())["I_t"]
+    return (pred + pred_flip.flip(2).flip(3)) / 2
+
+
+def psnr(a, b) -> float:
+    """-10 log10(mean((a - b)^2)) on [0,1] images (benchmark/psnr_ssim.py:133-135, test_snufilm.py:147)."""
+    a = torch.as_tensor(a, dtype=torch.float64)
+    b = torch.as_tensor(b, dtype=torch.float64)
+    mse = ((a - b) ** 2).mean().item()
+    return float("inf") if mse == 0 else -10.0 * float(np.log10(mse))
+
+
+def save_checkpoint(model, path, optimizer=None, meta=None, train_metric=None, val_metric=None):
+    """The trainer's checkpoint wire format (trainer.py:438-446): a 5-key dict that every loader of the reference understands."""
+    torch.save({"model_state_dict": model.state_dict(),
+                "optimizer_state_dict": optimizer.state_dict() if optimizer is not None else {},
+                "meta_data": meta or {}, "train_metric": train_metric or {}, "val_metric": val_metric or {}}, path)
+
+
 def strip_lazy_buffers(state):
     """Saved checkpoints carry the reference's lazily registered ``attn_mask``/``HW`` buffers
     (attention.py:304-305); every loader of the reference drops them (demo_2x.py:38-46)."""

@@ -264,3 +264,21 @@ def test_frame_pipeline_matches_sequential(nets, dev):
     # HIP pre-kernel compute), so a rounding may flip here and there; never more than one level
     d = np.abs(generic.astype(np.int32) - seq[0].astype(np.int32))
     assert d.max() <= 1 and (d > 0).mean() < 5e-3
+
+
+def test_video_2x_frame_order(nets, dev):
+    """interpolate_video_2x reproduces the output sequence of the reference's video loop (demo_2x.py:144-163)."""
+    net = nets["lite"]
+    net.global_motion = False
+    rng = np.random.default_rng(9)
+    frames = [rng.integers(0, 256, (64, 96, 3), dtype=np.uint8) for _ in range(5)]
+    out = list(host_io.interpolate_video_2x(iter(frames), net))
+    assert len(out) == 9
+    for i, f in enumerate(frames):
+        assert np.array_equal(out[2 * i], f)
+    for i in range(4):
+        assert np.array_equal(out[2 * i + 1], host_io.inference_2frame(frames[i], frames[i + 1], net, isBGR=True))
+    assert list(host_io.interpolate_video_2x(iter([]), net)) == []
+    one = list(host_io.interpolate_video_2x(iter(frames[:1]), net))
+    assert len(one) == 1 and np.array_equal(one[0], frames[0])
+    net.global_motion = True

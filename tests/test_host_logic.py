@@ -186,3 +186,27 @@ def test_demo_host_path_on_double(nets):
     gold = G.load_npz(case["name"])["pred"]
     d = np.abs(pred.astype(np.int32) - gold.astype(np.int32))
     assert d.max() <= 1 and (d > 0).mean() < 1e-3
+
+
+def test_checkpoint_wire_format_and_tta_helpers(tmp_path, nets):
+    """save_checkpoint writes the trainer's 5-key dict (trainer.py:438-446); forward_tta is the flip-average of
+    benchmark/test_snufilm.py:135-139; psnr is benchmark/psnr_ssim.py:133-135."""
+    net = pkg.NetworkLite()
+    path = tmp_path / "wire.pt"
+    host_io.save_checkpoint(net, str(path), meta={"epoch": 3}, val_metric={"psnr": 30.0})
+    ck = torch.load(str(path), map_location="cpu")
+    assert list(ck.keys()) == ["model_state_dict", "optimizer_state_dict", "meta_data", "train_metric", "val_metric"]
+    assert ck["meta_data"] == {"epoch": 3} and list(ck["model_state_dict"].keys()) == list(net.state_dict().keys())
+    net2 = pkg.NetworkLite()
+    host_io.load_model_checkpoint(net2, str(path))
+    assert all(torch.equal(net2.state_dict()[k], v) for k, v in net.state_dict().items())
+    # TTA through the host-logic double: equals the explicit flip / un-flip average of two forwards
+    m = nets["lite"]
+    m.global_motion = False
+    import pairs
+    a, b = pairs.smooth_pair(1, 64, 64, seed=3)
+    want = (m(a, b)["I_t"] + m(a.flip(2).flip(3), b.flip(2).flip(3))["I_t"].flip(2).flip(3)) / 2
+    assert torch.equal(host_io.forward_tta(m, a, b), want)
+    assert host_io.psnr(torch.zeros(4), torch.zeros(4)) == float("inf")
+    assert abs(host_io.psnr(torch.zeros(100), torch.full((100,), 0.1)) - 20.0) < 1e-5      # 0.1 is a float32 here
+    m.global_motion = True
