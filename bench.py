@@ -79,11 +79,17 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     torch.set_grad_enabled(False)
-    dev = torch.device(f"cuda:{local_rank}")
+    # rehearsal of the N > 1 code path on a one-GPU box: ATMVFI_BENCH_REHEARSAL=1 puts every rank on cuda:0 and uses gloo
+    # (RCCL refuses two ranks on one device); never set by the driver
+    rehearsal = os.environ.get("ATMVFI_BENCH_REHEARSAL") == "1"
+    dev = torch.device("cuda:0" if rehearsal else f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
 
     # ---- model + synthetic inputs (resident in HBM before the timed region) ----
     variant = args.variant
