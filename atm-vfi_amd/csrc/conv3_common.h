@@ -32,9 +32,7 @@ int launch_conv3x3_row(const Conv3Dev& d, int ntiles, hipStream_t stream);
 }  // namespace atmvfi
 using atmvfi::Conv3Dev;
 
-constexpr int TW = 16, TH = 16, HW_ = TW + 2, HH_ = TH + 2, NPIX = HW_ * HH_;   // 18 x 18 = 324 halo pixels
-constexpr int HALO_TASKS = NPIX * 4;                                            // (pixel, 8-channel group)
-constexpr int HALO_TPT = (HALO_TASKS + 511) / 512;                              // 3 tasks per thread
+constexpr int TW = 16, HW_ = TW + 2;     // output tile width and halo width; the tile height is 2 rows per wavefront (conv3x3_f16x3_row.hip)
 
 __device__ __forceinline__ int swz64(int row) { return ((row >> 2) & 1) << 1; }
 

@@ -130,8 +130,8 @@ extern "C" int atmvfi_conv3x3_f16x3(const float* in, int in_ld, int N, int H, in
     d.tchunk = 0;
     d.legacy_order = 0;
     d.tiles_x = (W + TW - 1) / TW;
-    d.tiles_y = (H + TH - 1) / TH;
-    ATMVFI_REQUIRE((long long)N * d.tiles_x * d.tiles_y < (1ll << 31), ATMVFI_EINVAL, "conv3x3_f16x3: grid too large");
+    d.tiles_y = 0;                                  // set by the launcher: the tile height depends on the schedule
+    ATMVFI_REQUIRE((long long)N * d.tiles_x * ((H + 7) / 8) * 8 < (1ll << 31), ATMVFI_EINVAL, "conv3x3_f16x3: grid too large");
     return atmvfi::launch_conv3x3_row(d, (Cout + 15) / 16, (hipStream_t)stream);
 }
 

@@ -28,15 +28,22 @@ extern "C" void atmvfi_debug_set_stamp_buffer(void* p) { g_stamp_buf = (unsigned
 
 namespace {
 
-template <int WN>
-__global__ __launch_bounds__(512) void conv3x3_f16x3_row_kernel(const Conv3Dev a) {
+// NWV wavefronts per workgroup (output tile 16 x 2*NWV pixels), TAPS k-steps per stage:
+//   <WN, 8, 3>  "row":  512 threads, 16x16 tile, one kernel row per stage, one workgroup per CU (LDS up to 140 KiB)
+//   <WN, 4, 1>  "half": 256 threads, 16x8 tile, one tap per stage, 55 KiB of LDS: two workgroups per CU, so one's DMA issue,
+//               barrier wait and halo conversion run under the other's MFMAs (at twice the weight traffic per pixel)
+template <int WN, int NWV, int TAPS>
+__global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void conv3x3_f16x3_row_kernel(const Conv3Dev a) {
     constexpr int BN = 16 * WN;
+    constexpr int NT = 64 * NWV;
+    constexpr int TH = 2 * NWV, NPIX = HW_ * (TH + 2), HALO_TASKS = NPIX * 4, HALO_TPT = (HALO_TASKS + NT - 1) / NT;
+    constexpr int SPC = 9 / TAPS;                       // stages per regular chunk
     extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
     _Float16* halo_hi = smem;                           // [NPIX][32]
     _Float16* halo_lo = halo_hi + NPIX * 32;
-    _Float16* b_hi = halo_lo + NPIX * 32;               // [2][3][BN][32]
-    _Float16* b_lo = b_hi + 2 * 3 * BN * 32;
-    float* cst = reinterpret_cast<float*>(b_lo + 2 * 3 * BN * 32);     // bias / PReLU slopes of this column block (common.h)
+    _Float16* b_hi = halo_lo + NPIX * 32;               // [2][TAPS][BN][32]
+    _Float16* b_lo = b_hi + 2 * TAPS * BN * 32;
+    float* cst = reinterpret_cast<float*>(b_lo + 2 * TAPS * BN * 32);  // bias / PReLU slopes of this column block (common.h)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -63,7 +70,7 @@ __global__ __launch_bounds__(512) void conv3x3_f16x3_row_kernel(const Conv3Dev a
     int txb = rem / rows_here;
     int tyb = 8 * grp + (rem - txb * rows_here);
     if (a.legacy_order) { txb = L % a.tiles_x; tyb = L / a.tiles_x; }
-    const int ox0 = txb * TW, oy0 = tyb * TH;
+    const int ox0 = txb * TW, oy0 = tyb * TH;      // TH = 2 * NWV rows per tile
     const int n0 = nblk * BN;
 
     // ---- halo tasks: T = tid + 512*k -> (halo pixel, 8-channel group) ----
@@ -72,7 +79,7 @@ __global__ __launch_bounds__(512) void conv3x3_f16x3_row_kernel(const Conv3Dev a
     bool hok[HALO_TPT], hact[HALO_TPT];
 #pragma unroll
     for (int k = 0; k < HALO_TPT; ++k) {
-        const int T = tid + 512 * k;
+        const int T = tid + NT * k;
         hact[k] = T < HALO_TASKS;
         const int hp = hact[k] ? (T >> 2) : 0;
         const int q = T & 3;
@@ -86,21 +93,21 @@ __global__ __launch_bounds__(512) void conv3x3_f16x3_row_kernel(const Conv3Dev a
     // ---- weights by LDS-DMA: the fp16 planes go global -> LDS without touching registers (no wr[] staging, no ds_write
     // phase).  One wave-instruction = 16 rows x 64 B of one (plane, tap): wave-piece q = wave + 8k -> plane = q / (3 WN),
     // tap t = (q / WN) % 3, row group q % WN; lane = (row in group, physical slot), the swizzle goes on the SOURCE slot. ----
-    constexpr int NWPIECE = 6 * WN;                       // wave-pieces per stage
-    constexpr int NWP = (NWPIECE + 7) / 8;                // per wave (the last one may be inactive: wave-uniform)
+    constexpr int NWPIECE = 2 * TAPS * WN;                // wave-pieces per stage
+    constexpr int NWP = (NWPIECE + NWV - 1) / NWV;        // per wave (the last one may be inactive: wave-uniform)
     const _Float16* wsrc[NWP];
     int wdst[NWP];
 #pragma unroll
     for (int k = 0; k < NWP; ++k) {
-        const int qq = wave + 8 * k;
+        const int qq = wave + NWV * k;
         const int qc = qq < NWPIECE ? qq : 0;
-        const int plane = qc / (3 * WN);
-        const int t = (qc / WN) % 3;
+        const int plane = qc / (TAPS * WN);
+        const int t = (qc / WN) % TAPS;
         const int row = 16 * (qc % WN) + (lane >> 2);
         const int ls = (lane & 3) ^ swz64(row);
         const int nrow = (n0 + row) < a.wrows ? n0 + row : a.wrows - 1;      // rows past the packed ones: columns never stored
         wsrc[k] = (plane ? a.w_lo : a.w_hi) + (long long)nrow * a.ktot + (long long)t * a.cs + ls * 8;
-        wdst[k] = plane * (2 * 3 * BN * 32) + (t * BN + 16 * (qc % WN)) * 32;      // halves from b_hi (b_lo = b_hi + 2*3*BN*32)
+        wdst[k] = plane * (2 * TAPS * BN * 32) + (t * BN + 16 * (qc % WN)) * 32;   // halves from b_hi (b_lo = b_hi + 2*TAPS*BN*32)
     }
 
     f32x4 acc[2][WN], cor[2][WN];
@@ -116,7 +123,7 @@ __global__ __launch_bounds__(512) void conv3x3_f16x3_row_kernel(const Conv3Dev a
     // (three k-steps of 4 taps x 8 channels, conv3x3_f16x3.hip) instead of three more
     const int nfull = a.cf >> 5;
     const int nchunks = nfull + (a.tail ? 1 : 0);
-    const int nstages = nfull * 3 + (a.tail ? 1 : 0);
+    const int nstages = nfull * SPC + (a.tail ? 3 / TAPS : 0);
 
     f32x4 hr[HALO_TPT][2];
     int hnv[HALO_TPT];
@@ -153,16 +160,22 @@ __global__ __launch_bounds__(512) void conv3x3_f16x3_row_kernel(const Conv3Dev a
             *reinterpret_cast<f16x8*>(halo_lo + hdst[k]) = lo;
         }
     };
+    // stage -> (chunk, first k-step q0): regular chunks have 9 k-steps (tap q), the tail chunk 3 (stored behind taps 0..2 of the
+    // weight row, so k-step q of either kind sits at q*cs + chunk*32)
+    auto stage_pos = [&](int stage, int& chunk, int& q0) {
+        const int full = nfull * SPC;
+        chunk = stage < full ? stage / SPC : nfull;
+        q0 = (stage < full ? stage - chunk * SPC : stage - full) * TAPS;
+    };
     auto w_dma = [&](int stage, int buf) {
-        const int chunk = stage / 3;
-        const int ky = stage - chunk * 3;
-        // the tail stage is (chunk nfull, ky 0) of the same formula: its three k-steps are stored behind taps 0..2
-        const long long koff = (long long)(ky * 3) * a.cs + chunk * 32;
+        int chunk, q0;
+        stage_pos(stage, chunk, q0);
+        const long long koff = (long long)q0 * a.cs + chunk * 32;
 #pragma unroll
         for (int k = 0; k < NWP; ++k)
-            if (wave + 8 * k < NWPIECE)
+            if (wave + NWV * k < NWPIECE)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[k] + koff),
-                                                 (__attribute__((address_space(3))) void*)(b_hi + buf * 3 * BN * 32 + wdst[k]), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(b_hi + buf * TAPS * BN * 32 + wdst[k]), 16, 0, 0);
     };
 
     int dtail = 0;                 // halo offsets of taps 4t+g, t = 0..2, one byte each (taps 9..11 carry zero weights: any
@@ -186,14 +199,14 @@ __global__ __launch_bounds__(512) void conv3x3_f16x3_row_kernel(const Conv3Dev a
     STAMP(0)
 
     for (int s = 0; s < nstages; ++s) {
-        const int chunk = s / 3;
-        const int ky = s - chunk * 3;
+        int chunk, q0;
+        stage_pos(s, chunk, q0);
         const int wb = s & 1;
         const bool tail_stage = chunk >= nfull;
         int dt = dtail;
         asm volatile("" : "+v"(dt));       // opaque: keeps hipcc from hoisting the six tail-stage offsets out of the loop (spills at WN = 8)
         const bool more_w = (s + 1) < nstages;
-        const bool next_halo = (ky == 2) && (chunk + 1 < nchunks);
+        const bool next_halo = !tail_stage && (q0 + TAPS == 9) && (chunk + 1 < nchunks);      // last stage of a regular chunk
         if (more_w) w_dma(s + 1, wb ^ 1);       // that buffer was last read in stage s-1: everyone has passed its barrier
         if (next_halo) {
 #pragma unroll
@@ -201,19 +214,20 @@ __global__ __launch_bounds__(512) void conv3x3_f16x3_row_kernel(const Conv3Dev a
         }
         STAMP(1)
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
+        for (int t = 0; t < TAPS; ++t) {
+            const int q = q0 + t;                        // k-step: tap q of a regular chunk, step q of the tail
             f16x8 xh[2], xl[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 // regular stage: tap (ky, t), lane group g reads channel slot g.  Tail stage: k = (tap 4t+g, tail channels
                 // 0..7), lane group g reads slot 0 of ITS tap's pixel (selects on a uniform flag: no branch in this loop)
-                const int p = (2 * wave + i) * HW_ + r + (tail_stage ? ((dt >> (8 * t)) & 0xff) : ky * HW_ + t);
+                const int p = (2 * wave + i) * HW_ + r + (tail_stage ? ((dt >> (8 * q)) & 0xff) : (q / 3) * HW_ + q % 3);
                 const int sl = tail_stage ? 0 : g;
                 const int off = p * 32 + ((sl ^ swz64(p)) << 3);
                 xh[i] = *reinterpret_cast<const f16x8*>(halo_hi + off);
                 xl[i] = *reinterpret_cast<const f16x8*>(halo_lo + off);
             }
-            const int wbase = (wb * 3 + t) * BN * 32 + r * 32 + ((g ^ swz64(r)) << 3);     // swz64(16j + r) == swz64(r)
+            const int wbase = (wb * TAPS + t) * BN * 32 + r * 32 + ((g ^ swz64(r)) << 3);  // swz64(16j + r) == swz64(r)
             // weight fragments ping-pong between two statically indexed register sets (j is a compile-time
             // constant after unrolling): the next n-tile is fetched before this tile's MFMAs, without copies
             // weight fragments run two n-tiles ahead of the MFMAs (3-slot ring, static indices) and the order is
@@ -300,11 +314,12 @@ __global__ __launch_bounds__(512) void conv3x3_f16x3_row_kernel(const Conv3Dev a
 #endif
 }
 
-template <int WN>
+template <int WN, int NWV, int TAPS>
 int launch_row(const Conv3Dev& d, int ntiles, hipStream_t s) {
     constexpr int BN = 16 * WN;
-    const size_t lds = (size_t)(2 * NPIX * 32 + 2 * 2 * 3 * BN * 32) * sizeof(_Float16) + epilogue_const_floats(BN) * sizeof(float);
-    auto kern = conv3x3_f16x3_row_kernel<WN>;
+    constexpr int TH = 2 * NWV, NPIX = HW_ * (TH + 2);
+    const size_t lds = (size_t)(2 * NPIX * 32 + 2 * 2 * TAPS * BN * 32) * sizeof(_Float16) + epilogue_const_floats(BN) * sizeof(float);
+    auto kern = conv3x3_f16x3_row_kernel<WN, NWV, TAPS>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -313,7 +328,8 @@ int launch_row(const Conv3Dev& d, int ntiles, hipStream_t s) {
     }
     Conv3Dev ds = d;
     ds.nblocks = (ntiles + WN - 1) / WN;
-    const long long sgroups = ((long long)d.N * d.tiles_x * d.tiles_y + 7) / 8;
+    ds.tiles_y = (d.H + TH - 1) / TH;
+    const long long sgroups = ((long long)d.N * d.tiles_x * ds.tiles_y + 7) / 8;
     ds.tchunk = (int)sgroups;
     static const int legacy = [] { const char* e = getenv("ATMVFI_LEGACY_ORDER"); return e ? atoi(e) : 0; }();
     ds.legacy_order = legacy;
@@ -322,7 +338,7 @@ int launch_row(const Conv3Dev& d, int ntiles, hipStream_t s) {
 #ifdef ATMVFI_STAMP
     ds.stamp = g_stamp_buf;
 #endif
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, ds);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * NWV), lds, s, ds);
     return atmvfi::check_launch("conv3x3_f16x3_row");
 }
 
@@ -336,14 +352,26 @@ int atmvfi::launch_conv3x3_row(const Conv3Dev& d, int ntiles, hipStream_t s) {
         const float cost = (float)padded * (1.0f + 1.0f / (float)wn);
         if (cost <= best_cost) { best_cost = cost; best = wn; }
     }
-    switch (best) {
-        case 1: return launch_row<1>(d, ntiles, s);
-        case 2: return launch_row<2>(d, ntiles, s);
-        case 3: return launch_row<3>(d, ntiles, s);
-        case 4: return launch_row<4>(d, ntiles, s);
-        case 5: return launch_row<5>(d, ntiles, s);
-        case 6: return launch_row<6>(d, ntiles, s);
-        case 7: return launch_row<7>(d, ntiles, s);
-        default: return launch_row<8>(d, ntiles, s);
+    // Schedule (ATMVFI_CONV3_SCHED=row|half forces one).  Two half-size workgroups per CU overlap each other's DMA issue, barrier
+    // waits and halo conversion, and quantise better on small images (8-row tiles, 2*CUs slots per round), but stream the
+    // weights twice per 256 pixels and pay a barrier per tap.  Rule: rounds of the launch x the measured time of a half-pair
+    // relative to a full tile at that width (1080p layers, same-box A/B: narrow tiles lose, 48..64 and 96-wide ones gain most).
+    static const int forced = [] { const char* e = getenv("ATMVFI_CONV3_SCHED"); return !e ? -1 : (e[0] == 'h' ? 1 : 0); }();
+    bool half = forced == 1;
+    if (forced < 0) {
+        static const float rel[9] = {1.f, 1.08f, 1.21f, 0.84f, 0.90f, 1.04f, 0.95f, 0.97f, 1.00f};
+        const int ncu = atmvfi::cu_count();
+        const int nb = (ntiles + best - 1) / best;
+        const long long t_row = (long long)d.N * d.tiles_x * ((d.H + 15) / 16) * nb;
+        const long long t_half = (long long)d.N * d.tiles_x * ((d.H + 7) / 8) * nb;
+        const float c_row = (float)((t_row + ncu - 1) / ncu);
+        const float c_half = (float)((t_half + 2 * ncu - 1) / (2 * ncu)) * rel[best];
+        half = c_half < c_row;
     }
+#define ATMVFI_C3_CASE(W) case W: return half ? launch_row<W, 4, 1>(d, ntiles, s) : launch_row<W, 8, 3>(d, ntiles, s);
+    switch (best) {
+        ATMVFI_C3_CASE(1) ATMVFI_C3_CASE(2) ATMVFI_C3_CASE(3) ATMVFI_C3_CASE(4) ATMVFI_C3_CASE(5) ATMVFI_C3_CASE(6) ATMVFI_C3_CASE(7)
+        default: return half ? launch_row<8, 4, 1>(d, ntiles, s) : launch_row<8, 8, 3>(d, ntiles, s);
+    }
+#undef ATMVFI_C3_CASE
 }
