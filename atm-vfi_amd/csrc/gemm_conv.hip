@@ -251,8 +251,8 @@ extern "C" int atmvfi_gemm(const atmvfi_gemm_params* p, void* stream) {
     const bool planes = p->in_hi || p->in_lo;
     ATMVFI_REQUIRE((p->in || planes) && p->weight && p->out, ATMVFI_EINVAL, "gemm: null tensor pointer");
     if (planes) {
-        ATMVFI_REQUIRE(p->in_hi && p->in_lo && p->precision == ATMVFI_PREC_F16X3 && p->mode == ATMVFI_GEMM_LINEAR && !p->in_prelu,
-                       ATMVFI_EINVAL, "gemm: split-plane input needs both planes, precision f16x3, LINEAR mode and no in_prelu");
+        ATMVFI_REQUIRE(p->in_hi && p->in_lo && p->precision == ATMVFI_PREC_F16X3 && p->mode != ATMVFI_GEMM_CONV && !p->in_prelu,
+                       ATMVFI_EINVAL, "gemm: split-plane input needs both planes, precision f16x3, LINEAR or DECONV mode and no in_prelu");
         ATMVFI_REQUIRE(p->in_ld % 8 == 0 && p->in_gstride % 8 == 0 && atmvfi::aligned16(p->in_hi) && atmvfi::aligned16(p->in_lo),
                        ATMVFI_EALIGN, "gemm: split planes need 16-byte aligned pointers, in_ld/in_gstride multiples of 8 halves");
         ATMVFI_REQUIRE(p->in_ld >= atmvfi::round_up(p->Cin, 32), ATMVFI_EALIGN, "gemm: split-plane rows must hold round_up(Cin,32)=%d halves (in_ld %d)",

@@ -271,20 +271,32 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_split_kernel(const Gem
 #endif
 }
 
-// fp32 rows -> (hi, lo') planes; one thread per 8 channels.  Pad channels (>= C, < ld_out) are written as zero.
-__global__ void split_planes_kernel(const float* __restrict__ in, int in_ld, long long M, int C, _Float16* hi, _Float16* lo, int ld) {
+// fp32 rows -> (hi, lo') planes; one thread per 8 channels.  Pad channels (>= C, < ld_out) are written as zero.  An optional
+// per-channel PReLU is applied first (the leading nn.PReLU of the decoder stages, network_base.py:209,215).
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ in, int in_ld, long long M, int C,
+                                                           const float* __restrict__ prelu, _Float16* hi, _Float16* lo, int ld) {
     const int groups = ld / 8;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= M * groups) return;
     const long long m = t / groups;
     const int c0 = (int)(t - m * groups) * 8;
+    float x[8];
+    const float* p = in + m * in_ld + c0;
+    if (c0 + 8 <= C && (in_ld & 3) == 0) {
+        const f32x4 va = *reinterpret_cast<const f32x4*>(p), vb = *reinterpret_cast<const f32x4*>(p + 4);
+        x[0] = va.x; x[1] = va.y; x[2] = va.z; x[3] = va.w; x[4] = vb.x; x[5] = vb.y; x[6] = vb.z; x[7] = vb.w;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = (c0 + e < C) ? p[e] : 0.f;
+    }
     f16x8 h, l;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const float x = (c0 + e < C) ? in[m * in_ld + c0 + e] : 0.f;
-        const _Float16 hh = (_Float16)fminf(fmaxf(x, -65504.0f), 65504.0f);
+        float v = x[e];
+        if (prelu && c0 + e < C) v = v > 0.f ? v : prelu[c0 + e] * v;
+        const _Float16 hh = (_Float16)fminf(fmaxf(v, -65504.0f), 65504.0f);
         h[e] = hh;
-        l[e] = (_Float16)fminf(fmaxf((x - (float)hh) * 1024.0f, -65504.0f), 65504.0f);
+        l[e] = (_Float16)fminf(fmaxf((v - (float)hh) * 1024.0f, -65504.0f), 65504.0f);
     }
     *reinterpret_cast<f16x8*>(hi + m * ld + c0) = h;
     *reinterpret_cast<f16x8*>(lo + m * ld + c0) = l;
@@ -320,12 +332,12 @@ int atmvfi::launch_gemm_split(const GemmDev& d, int ngemm, hipStream_t s) {
     return launch_split<4, 2>(d, ngemm, s);
 }
 
-extern "C" int atmvfi_split_planes(const float* in, int in_ld, int64_t M, int C, void* hi, void* lo, int ld, void* stream) {
+extern "C" int atmvfi_split_planes(const float* in, int in_ld, int64_t M, int C, const float* prelu, void* hi, void* lo, int ld, void* stream) {
     ATMVFI_REQUIRE(in && hi && lo && M > 0 && C > 0, ATMVFI_EINVAL, "split_planes: bad arguments");
     ATMVFI_REQUIRE(ld % 8 == 0 && ld >= C && in_ld >= C, ATMVFI_EALIGN, "split_planes: ld %d must be a multiple of 8 and >= C %d", ld, C);
     ATMVFI_REQUIRE(atmvfi::aligned16(hi) && atmvfi::aligned16(lo), ATMVFI_EALIGN, "split_planes: planes must be 16-byte aligned");
     const long long n = (long long)M * (ld / 8);
     hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, in_ld, (long long)M, C,
-                       (_Float16*)hi, (_Float16*)lo, ld);
+                       prelu, (_Float16*)hi, (_Float16*)lo, ld);
     return atmvfi::check_launch("split_planes");
 }

@@ -59,7 +59,7 @@ SIGNATURES = {
     "atmvfi_version": (c_i, []),
     "atmvfi_last_error": (ctypes.c_char_p, []),
     "atmvfi_gemm": (c_i, [ctypes.POINTER(GemmParams), c_f]),
-    "atmvfi_split_planes": (c_i, [c_f, c_i, c_l, c_i, c_f, c_f, c_i, c_f]),
+    "atmvfi_split_planes": (c_i, [c_f, c_i, c_l, c_i, c_f, c_f, c_f, c_i, c_f]),
     "atmvfi_conv2d": (c_i, [ctypes.POINTER(GemmParams), c_f]),
     "atmvfi_linear": (c_i, [ctypes.POINTER(GemmParams), c_f]),
     "atmvfi_deconv2x2": (c_i, [ctypes.POINTER(GemmParams), c_f]),
@@ -304,7 +304,9 @@ class HipOps:
         p.precision, p.weight_hi, p.weight_lo = self._prec(w)
         self._run("conv2d_f16x3" if p.precision else "conv2d", meta, self.lib.atmvfi_conv2d, ctypes.byref(p), self._stream())
 
-    def deconv(self, x, w: PackedWeight, out, bias=None, prelu=None, in_prelu=None):
+    def deconv(self, x, w: PackedWeight, out, bias=None, prelu=None, in_prelu=None, planes: Optional[Planes] = None):
+        """``planes``: the input rows [N*H*W, Cin] again in split-plane form (already through in_prelu): the LDS-DMA GEMM
+        then replaces the fp32-input engine."""
         ld, n, h, wd, cin = nhwc_view(x, "deconv.in")
         old, on, oh, ow, cout = nhwc_view(out, "deconv.out")
         if cin != w.cin or cout != w.cout or on != n or w.mode != GEMM_DECONV or oh != 2 * h or ow != 2 * wd:
@@ -314,19 +316,29 @@ class HipOps:
                        M=n * h * wd, out=out.data_ptr(), out_ld=old, out_gstride=0, out_rpg=0, out_row_map=None,
                        bias=_ptr(bias), prelu=_ptr(prelu), in_prelu=_ptr(in_prelu), residual=None, res_ld=0)
         p.precision, p.weight_hi, p.weight_lo = self._prec(w)
+        use_planes = planes is not None and p.precision == 1
+        if use_planes:
+            if planes.rows != n * h * wd or planes.c != cin:
+                raise ValueError("deconv: planes do not match the input rows")
+            p.in_, p.in_ld, p.in_prelu = None, planes.ld, None
+            p.in_hi, p.in_lo = planes.t[0].data_ptr(), planes.t[1].data_ptr()
         meta = {"flops": 2.0 * n * h * wd * 4 * cout * cin, "bytes": 4.0 * (n * h * wd * cin + n * oh * ow * cout + 4 * cout * cin),
                 "shape": f"M{n * h * wd} N{4 * cout} K{cin}"}
-        self._run("deconv2x2_f16x3" if p.precision else "deconv2x2", meta, self.lib.atmvfi_deconv2x2, ctypes.byref(p), self._stream())
+        self._run("deconv2x2_split" if use_planes else "deconv2x2_f16x3" if p.precision else "deconv2x2", meta, self.lib.atmvfi_deconv2x2,
+                  ctypes.byref(p), self._stream())
 
     split_planes_ok = True        # this backend has the split-plane sinks and the LDS-DMA GEMM
 
-    def split_planes(self, x, out: Planes):
+    def split_planes(self, x, out: Planes, prelu=None):
+        """fp32 rows -> split planes, optionally through a per-channel PReLU first."""
         ld, m, c, gs, _ = rows_view(x, "split_planes.in")
         if gs != 0 or m != out.rows or c != out.c:
             raise ValueError("split_planes: expected a plain [rows,C] view matching the planes")
+        if prelu is not None and prelu.numel() < c:
+            raise ValueError("split_planes: prelu needs one slope per channel")
         meta = {"bytes": 4.0 * m * c + 4.0 * m * out.ld}
-        self._run("split_planes", meta, self.lib.atmvfi_split_planes, _ptr(x), ld, m, c, out.t[0].data_ptr(), out.t[1].data_ptr(),
-                  out.ld, self._stream())
+        self._run("split_planes", meta, self.lib.atmvfi_split_planes, _ptr(x), ld, m, c, _ptr(prelu), out.t[0].data_ptr(),
+                  out.t[1].data_ptr(), out.ld, self._stream())
 
     def linear(self, x, w: PackedWeight, out, bias=None, residual=None, out_row_map=None):
         planes = x if isinstance(x, Planes) else None

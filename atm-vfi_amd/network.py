@@ -236,8 +236,18 @@ class Network(nn.Module):
     def _conv_plain(self, ops, P, p, x, out, stride=1, pad=1, dil=1):
         ops.conv(x, P[f"pk:{p}.weight"], out, stride=stride, pad=pad, dil=dil, bias=P[f"{p}.bias"])
 
-    def _deconv_act(self, ops, P, p, x, out, in_prelu=None):
-        ops.deconv(x, P[f"pk:{p}.0.weight"], out, bias=P[f"{p}.0.bias"], prelu=P[f"{p}.1.weight"], in_prelu=in_prelu)
+    def _deconv_act(self, ops, P, p, x, out, in_prelu=None, split: Optional[str] = None):
+        """``split``: workspace name -- split the input rows into fp16 planes first (one pass, through ``in_prelu``) and run the
+        deconv on the LDS-DMA GEMM: the fp32-input engine redoes that split once per column block (7x for 389 -> 4*197)."""
+        w = P[f"pk:{p}.0.weight"]
+        if split is not None and getattr(ops, "precision", None) == "f16x3" and getattr(ops, "split_planes_ok", False) \
+                and self.use_split_planes and w.hi is not None:
+            b, h, wd, cin = x.shape
+            xp = self.planes(split, b * h * wd, cin)
+            ops.split_planes(x.flatten(0, 2), xp, prelu=in_prelu)
+            ops.deconv(x, w, out, bias=P[f"{p}.0.bias"], prelu=P[f"{p}.1.weight"], planes=xp)
+            return
+        ops.deconv(x, w, out, bias=P[f"{p}.0.bias"], prelu=P[f"{p}.1.weight"], in_prelu=in_prelu)
 
     def _encoder(self, ops, P, x0, tag: str):
         """shared_feat_extraction + cross-scale fusion buffers.  x0: [F,H,W,4].  Returns (e1, e2, fuse_l)
@@ -530,6 +540,8 @@ class Network(nn.Module):
                 cout = dsts[st].shape[-1]
                 hs, wsz = H >> scale, W >> scale
                 t1 = self.buf(f"dec_t1_{st}", b, hs, wsz, _r4(cout))[..., :cout]
+                # (split=f"dec_xp_{st}" -- a split pass + the LDS-DMA GEMM -- measured 1.70 against 1.77 ms for the three stages: the
+                # pass costs what the faster GEMM saves; left on the fp32-input engine)
                 self._deconv_act(ops, P, f"{pfx}.{o}", x, t1, in_prelu=P[f"inprelu:{st}"] if st else None)
                 t2b = self.buf(f"dec_t2_{st}", b, hs, wsz, _r4(cout))[..., :cout]
                 self._conv_act(ops, P, f"{pfx}.{o + 1}", t1, t2b)

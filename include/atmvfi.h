@@ -84,7 +84,7 @@ typedef struct atmvfi_gemm_params {
     int32_t precision;
     const void* weight_hi;
     const void* weight_lo;
-    /* Split-plane input (F16X3 only): when in_hi/in_lo are set the activations are read from two fp16 planes
+    /* Split-plane input (F16X3, LINEAR and DECONV modes): when in_hi/in_lo are set the activations are read from two fp16 planes
        (written by a producer kernel or atmvfi_split_planes) by LDS-DMA instead of from `in`; in_ld / in_gstride
        then count halves (multiples of 8), the planes are 16-byte aligned and every row holds
        round_up(Cin, 32) readable, finite halves (pad channels meet zero weights).  `in` is ignored. */
@@ -99,8 +99,8 @@ int atmvfi_gemm(const atmvfi_gemm_params* p, void* stream);
 
 /* fp32 rows [M, C] (row stride in_ld floats) -> the two fp16 planes of the split-plane format,
    hi = fp16(x), lo = fp16((x - hi) * 1024), both saturating; plane rows are ld halves (multiple of 8),
-   channels C..ld-1 are written as zero. */
-int atmvfi_split_planes(const float* in, int in_ld, int64_t M, int C, void* hi, void* lo, int ld, void* stream);
+   channels C..ld-1 are written as zero.  `prelu` (optional, [C]) is applied to the values first. */
+int atmvfi_split_planes(const float* in, int in_ld, int64_t M, int C, const float* prelu, void* hi, void* lo, int ld, void* stream);
 
 /* Convenience wrappers with the reference-layer names (thin shims over atmvfi_gemm). */
 int atmvfi_conv2d(const atmvfi_gemm_params* p, void* stream);

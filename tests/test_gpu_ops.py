@@ -595,3 +595,26 @@ def test_frame_u8_f32_roundtrip_bit_exact(geom, bgr, hip, dev):
     assert np.array_equal(got.cpu().numpy(), want)
     with pytest.raises(RuntimeError):
         hip.frame_f32_to_u8(f.to(dev), got, t + 100, l, bgr)
+
+
+def test_deconv_from_split_planes(hip, cpu, dev):
+    """split_planes(+PReLU) -> deconv on the LDS-DMA GEMM == the fp32-input deconv with in_prelu, bit for bit."""
+    g = torch.Generator().manual_seed(77)
+    n, h, w, cin, cout = 1, 9, 14, 197, 101
+    xb = rnd(g, n, h, w, 200, scale=2.0).to(dev)
+    x = xb[..., :cin]
+    wt = rnd(g, cin, cout, 2, 2, scale=0.1).to(dev)
+    bias, slope, inp = rnd(g, cout, scale=0.3).to(dev), (0.25 + rnd(g, cout, scale=0.1)).to(dev), (0.25 + rnd(g, cin, scale=0.1)).to(dev)
+    pw = hip.pack_weight(GEMM_DECONV, wt)
+    y0 = torch.full((n, 2 * h, 2 * w, 104), 3.0, device=dev)
+    y1 = torch.full((n, 2 * h, 2 * w, 104), 3.0, device=dev)
+    hip.deconv(x, pw, y0[..., :cout], bias, slope, in_prelu=hip.pad_channels(inp))
+    p = hip_ops.Planes.alloc(n * h * w, cin, dev)
+    hip.split_planes(x.flatten(0, 2), p, prelu=inp)
+    hip.deconv(x, pw, y1[..., :cout], bias, slope, planes=p)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
+    xa = torch.where(x > 0, x, x * inp)
+    ref = torch.nn.functional.conv_transpose2d(xa.permute(0, 3, 1, 2).double(), wt.double(), bias.double(), stride=2)
+    ref = torch.where(ref > 0, ref, ref * slope.double()[None, :, None, None]).permute(0, 2, 3, 1)
+    assert (y1[..., :cout].double() - ref).abs().max().item() <= 2e-5
