@@ -355,7 +355,8 @@ int atmvfi::launch_conv3x3_row(const Conv3Dev& d, int ntiles, hipStream_t s) {
     // Schedule (ATMVFI_CONV3_SCHED=row|half forces one).  Two half-size workgroups per CU overlap each other's DMA issue, barrier
     // waits and halo conversion, and quantise better on small images (8-row tiles, 2*CUs slots per round), but stream the
     // weights twice per 256 pixels and pay a barrier per tap.  Rule: rounds of the launch x the measured time of a half-pair
-    // relative to a full tile at that width (1080p layers, same-box A/B: narrow tiles lose, 48..64 and 96-wide ones gain most).
+    // relative to a full tile at that width (1080p layers, same-box A/B: narrow tiles lose, 48..64 and 96-wide ones gain most;
+    // three taps per stage on the half tiles, fewer barriers at 72 KiB of LDS, measured no better for the narrow layers).
     static const int forced = [] { const char* e = getenv("ATMVFI_CONV3_SCHED"); return !e ? -1 : (e[0] == 'h' ? 1 : 0); }();
     bool half = forced == 1;
     if (forced < 0) {
