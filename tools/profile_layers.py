@@ -5,6 +5,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import pairs
 pkg = importlib.import_module("atm-vfi_amd")
+if os.environ.get("ATMVFI_LIB"):          # A/B of two builds on one box: ATMVFI_LIB=atm-vfi_amd/libatmvfi_hip_base.so
+    _h = importlib.import_module("atm-vfi_amd.hip_ops")
+    _h.LIB_PATH = os.path.join(ROOT, os.environ["ATMVFI_LIB"])
+    _h.load_library.__defaults__ = (_h.LIB_PATH,)
 torch.set_grad_enabled(False)
 dev = torch.device("cuda:0")
 H, W = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1088, 1920)
