@@ -345,29 +345,31 @@ int launch_row(const Conv3Dev& d, int ntiles, hipStream_t s) {
 }  // namespace
 
 int atmvfi::launch_conv3x3_row(const Conv3Dev& d, int ntiles, hipStream_t s) {
-    int best = 1;
-    float best_cost = 1e30f;
-    for (int wn = 1; wn <= 8; ++wn) {
-        const int padded = (ntiles + wn - 1) / wn * wn;
-        const float cost = (float)padded * (1.0f + 1.0f / (float)wn);
-        if (cost <= best_cost) { best_cost = cost; best = wn; }
-    }
-    // Schedule (ATMVFI_CONV3_SCHED=row|half forces one).  Two half-size workgroups per CU overlap each other's DMA issue, barrier
-    // waits and halo conversion, and quantise better on small images (8-row tiles, 2*CUs slots per round), but stream the
-    // weights twice per 256 pixels and pay a barrier per tap.  Rule: rounds of the launch x the measured time of a half-pair
-    // relative to a full tile at that width (1080p layers, same-box A/B: narrow tiles lose, 48..64 and 96-wide ones gain most;
-    // three taps per stage on the half tiles, fewer barriers at 72 KiB of LDS, measured no better for the narrow layers).
+    // Tile width WN (n-tiles per workgroup) and schedule, chosen together by one cost model:
+    //   time ~ rounds(launch) x tile time,  tile time ~ WN * (1 + 1/WN) [MFMA work ~ WN, operand staging per tile ~ const]
+    //   rounds = ceil(workgroups / resident slots): one slot per CU for the 512-thread schedule, two for the half-size one.
+    // The half-size schedule overlaps two workgroups' DMA issue, barrier waits and halo conversion and quantises better on small
+    // images (8-row tiles), but streams the weights twice per 256 pixels and pays a barrier per tap: `rel` is its measured tile-pair
+    // time relative to a full tile at that width (1080p layers, same-box A/B: narrow tiles lose, 48..64 and 96-wide ones gain
+    // most; three taps per stage on the half tiles measured no better).  Counting rounds is what keeps small images busy: a
+    // 36x60 map with 768 channels is 72 workgroups at WN = 8 on 256 CUs, 192 at WN = 3.
+    // ATMVFI_CONV3_SCHED=row|half forces a schedule.
     static const int forced = [] { const char* e = getenv("ATMVFI_CONV3_SCHED"); return !e ? -1 : (e[0] == 'h' ? 1 : 0); }();
-    bool half = forced == 1;
-    if (forced < 0) {
-        static const float rel[9] = {1.f, 1.08f, 1.21f, 0.84f, 0.90f, 1.04f, 0.95f, 0.97f, 1.00f};
-        const int ncu = atmvfi::cu_count();
-        const int nb = (ntiles + best - 1) / best;
-        const long long t_row = (long long)d.N * d.tiles_x * ((d.H + 15) / 16) * nb;
-        const long long t_half = (long long)d.N * d.tiles_x * ((d.H + 7) / 8) * nb;
-        const float c_row = (float)((t_row + ncu - 1) / ncu);
-        const float c_half = (float)((t_half + 2 * ncu - 1) / (2 * ncu)) * rel[best];
-        half = c_half < c_row;
+    static const float rel[9] = {1.f, 1.08f, 1.21f, 0.84f, 0.90f, 1.04f, 0.95f, 0.97f, 1.00f};
+    const int ncu = atmvfi::cu_count();
+    int best = 1;
+    bool half = false;
+    float best_cost = 1e30f;
+    for (int sched = 0; sched < 2; ++sched) {
+        if (forced >= 0 && sched != forced) continue;
+        const long long spatial = (long long)d.N * d.tiles_x * ((d.H + (sched ? 7 : 15)) / (sched ? 8 : 16));
+        const int slots = sched ? 2 * ncu : ncu;
+        for (int wn = 1; wn <= 8; ++wn) {
+            const long long wgs = spatial * ((ntiles + wn - 1) / wn);
+            const float rounds = (float)((wgs + slots - 1) / slots);
+            const float cost = rounds * (float)wn * (1.0f + 1.0f / (float)wn) * (sched ? rel[wn] : 1.0f);
+            if (cost <= best_cost) { best_cost = cost; best = wn; half = sched == 1; }
+        }
     }
 #define ATMVFI_C3_CASE(W) case W: return half ? launch_row<W, 4, 1>(d, ntiles, s) : launch_row<W, 8, 3>(d, ntiles, s);
     switch (best) {

@@ -373,14 +373,18 @@ int launch(const GemmDev& d, int ntiles, hipStream_t s) {
 
 int atmvfi::launch_gemm_f16x3(const GemmDev& d, int ngemm, hipStream_t s) {
     const int ntiles = (ngemm + 15) / 16;
-    // tile width: MFMA work ~ padded tiles, operand staging (incl. the fp32 -> fp16-pair split, redone per column block) ~ 1/WN;
-    // the split makes narrow tiles dearer here than in the exact-fp32 engine: weight 2 measured best (deconv 788x389: -12 %)
+    // tile width: time ~ rounds x tile time; tile time ~ WN * (1 + cfac/WN) (MFMA work ~ WN; operand staging incl. the fp32 ->
+    // fp16-pair split, redone per column block, ~ const: weight 2 measured best, deconv 788x389 -12 %); rounds = ceil(tiles / CUs)
+    // of the persistent grid, which is what keeps small maps busy (M = 8 640, N = 256: 68 tiles at WN = 8, 204 at WN = 3)
     static const float cfac = [] { const char* e = getenv("ATMVFI_WN_COST"); return e ? (float)atof(e) : 2.0f; }();
+    const int ncu = atmvfi::cu_count();
+    const long long mtiles = atmvfi::ceil_div64(d.M, 256);
     int best = 1;
     float best_cost = 1e30f;
     for (int wn = 1; wn <= 8; ++wn) {
-        const int padded = (ntiles + wn - 1) / wn * wn;
-        const float cost = (float)padded * (1.0f + cfac / (float)wn);
+        const long long tiles = mtiles * ((ntiles + wn - 1) / wn);
+        const float rounds = (float)((tiles + ncu - 1) / ncu);
+        const float cost = rounds * (float)wn * (1.0f + cfac / (float)wn);
         if (cost <= best_cost) { best_cost = cost; best = wn; }
     }
     switch (best) {
