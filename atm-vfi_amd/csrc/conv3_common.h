@@ -14,8 +14,7 @@ struct Conv3Dev {
     int wrows;      // packed weight rows (multiple of 16)
     int cf;         // channels covered by full 32-channel chunks
     int tail;       // 1..8 channels in the tap-packed tail steps, 0 = none
-    int cs;         // per-tap stride of a weight row, halves: cf (+ 32 with a tail)
-    int ktot;       // halves per weight row = 9*cs
+    int cs, ktot;   // unused (row-major layout of an earlier revision)
     int Cout;
     float* out;
     int out_ld;

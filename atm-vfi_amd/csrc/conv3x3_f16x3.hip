@@ -10,12 +10,12 @@
 //     epilogue) on v_mfma_f32_16x16x32_f16: 3 MFMAs at 16x the fp32-MFMA rate, ~22 significand bits at any operand
 //     magnitude (the dropped lo*lo term is 2^-22 relative).  Weights are split once at pack time.
 //
-// Weight layout (atmvfi_pack_weight_conv3x3), per output-channel row (rows padded to 16), fp16 hi and lo' planes:
-//   [9 taps][CS]; CF = 32*floor(Cin/32) and tail = Cin - CF if 1 <= tail <= 8, else CF = round_up(Cin, 32), tail = 0.
-//   Without a tail CS = CF and entry [tap][c] is w[row][c][tap].  With one CS = CF + 32: the extra 32 entries behind
-//   taps 0, 1, 2 hold the tap-packed tail steps t = 0, 1, 2, each [4 taps 4t..4t+3][8 channels CF..CF+7] (taps >= 9 and
-//   channels >= Cin are zero); the extra entries behind taps 3..8 are unused zeros.  The tail then looks to the kernel
-//   like one more (chunk, kernel row 0) stage.
+// Weight layout (atmvfi_pack_weight_conv3x3), fp16 hi and lo' planes, K-STEP MAJOR: [k-step][row (padded to 16)][32 halves].
+//   CF = 32*floor(Cin/32) and tail = Cin - CF if 1 <= tail <= 8, else CF = round_up(Cin, 32), tail = 0.
+//   k-step (chunk c < CF/32, tap q < 9) has index 9c + q and holds w[row][32c .. 32c+31][tap q]; with a tail, three more k-steps
+//   9*CF/32 + t (t = 0..2) hold the tap-packed tail: entry [4 taps 4t..4t+3][8 channels CF..CF+7] (taps >= 9, channels >= Cin: 0).
+//   The 16 rows x 64 bytes one LDS-DMA instruction moves are therefore ONE contiguous KiB (8 full cache lines); in a row-major
+//   layout they were 16 half-used lines, and issuing those was a third of the half-tile schedule's time (tools/stamp_conv.py).
 // The decoder widths are 32k+5 (101, 197, 389: features + two flows + mask), so a plain 32-channel last chunk would
 // spend 9 k-steps (one per tap) on 5 live channels; the tail steps spend 3 (k = 4 taps x 8 channels each), which removes
 // 6 of 36 / 63 / 117 k-steps of those layers.
@@ -53,21 +53,23 @@ __global__ void pack_split_kernel(int mode, const float* __restrict__ src, _Floa
     }
 }
 
-// conv3x3 layout with the tap-packed tail (see the file header)
+// conv3x3 layout: k-step major, tap-packed tail (see the file header)
 __global__ void pack_conv3x3_kernel(const float* __restrict__ src, _Float16* __restrict__ hi, _Float16* __restrict__ lo, int Cout, int Cin,
                                     int rows, int cf, int tail) {
-    const int cs = cf + (tail ? 32 : 0);
-    const int ktot = 9 * cs;
-    const long long total = (long long)rows * ktot;
+    const int nsteps = 9 * (cf >> 5) + (tail ? 3 : 0);
+    const long long total = (long long)nsteps * rows * 32;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-        const int row = (int)(idx / ktot);
-        const int k = (int)(idx - (long long)row * ktot);
-        int tap = k / cs;
-        int c = k - tap * cs;
-        if (c >= cf) {                          // tail segment behind tap t: step t = [4 taps][8 channels]
-            const int kt = c - cf;
-            c = (kt & 7) < tail ? cf + (kt & 7) : Cin;
-            tap = tap < 3 ? 4 * tap + (kt >> 3) : 9;
+        const int e = (int)(idx & 31);
+        const int row = (int)((idx >> 5) % rows);
+        const int step = (int)((idx >> 5) / rows);
+        int tap, c;
+        if (step < 9 * (cf >> 5)) {
+            tap = step % 9;
+            c = (step / 9) * 32 + e;
+        } else {                                // tail step t: [4 taps][8 channels]
+            const int t = step - 9 * (cf >> 5);
+            tap = 4 * t + (e >> 3);
+            c = (e & 7) < tail ? cf + (e & 7) : Cin;
         }
         float v = 0.f;
         if (row < Cout && tap < 9 && c < Cin) v = src[((long long)row * Cin + c) * 9 + tap];     // OIHW, tap = ky*3 + kx
@@ -122,8 +124,8 @@ extern "C" int atmvfi_conv3x3_f16x3(const float* in, int in_ld, int N, int H, in
     d.w_hi = (const _Float16*)w_hi; d.w_lo = (const _Float16*)w_lo;
     d.wrows = atmvfi::round_up(Cout, 16);
     conv3_layout(Cin, d.cf, d.tail);
-    d.cs = d.cf + (d.tail ? 32 : 0);
-    d.ktot = 9 * d.cs;
+    d.cs = 0;
+    d.ktot = 0;
     d.Cout = Cout; d.out = out; d.out_ld = out_ld; d.bias = bias; d.prelu = prelu;
     d.stamp = nullptr;
     d.nblocks = 0;
@@ -138,7 +140,7 @@ extern "C" int atmvfi_conv3x3_f16x3(const float* in, int in_ld, int N, int H, in
 extern "C" int64_t atmvfi_conv3x3_weight_halves(int Cout, int Cin) {
     int cf, tail;
     conv3_layout(Cin, cf, tail);
-    return (int64_t)atmvfi::round_up(Cout, 16) * 9 * (cf + (tail ? 32 : 0));
+    return (int64_t)atmvfi::round_up(Cout, 16) * 32 * (9 * (cf >> 5) + (tail ? 3 : 0));
 }
 
 extern "C" int atmvfi_pack_weight_conv3x3(const float* src, void* dst_hi, void* dst_lo, int Cout, int Cin, void* stream) {

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void conv3x3_f16x3_row_
     const int nblk = slot - sgrp * a.nblocks;
     int L = (blockIdx.x & 7) * a.tchunk + sgrp;                  // position in the tile order
     const int per_img = a.tiles_x * a.tiles_y;
-    if (a.legacy_order) L = sgrp * 8 + (blockIdx.x & 7);
+    if (a.legacy_order & 1) L = sgrp * 8 + (blockIdx.x & 7);
     if (L >= a.N * per_img) return;
     const int img = L / per_img;
     L -= img * per_img;
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void conv3x3_f16x3_row_
     const int rows_here = (a.tiles_y - 8 * grp) < 8 ? a.tiles_y - 8 * grp : 8;
     int txb = rem / rows_here;
     int tyb = 8 * grp + (rem - txb * rows_here);
-    if (a.legacy_order) { txb = L % a.tiles_x; tyb = L / a.tiles_x; }
+    if (a.legacy_order & 1) { txb = L % a.tiles_x; tyb = L / a.tiles_x; }
     const int ox0 = txb * TW, oy0 = tyb * TH;      // TH = 2 * NWV rows per tile
     const int n0 = nblk * BN;
 
@@ -90,23 +90,26 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void conv3x3_f16x3_row_
         hdst[k] = hp * 32 + ((q ^ swz64(hp)) << 3);
         hq[k] = q;
     }
-    // ---- weights by LDS-DMA: the fp16 planes go global -> LDS without touching registers (no wr[] staging, no ds_write
-    // phase).  One wave-instruction = 16 rows x 64 B of one (plane, tap): wave-piece q = wave + 8k -> plane = q / (3 WN),
-    // tap t = (q / WN) % 3, row group q % WN; lane = (row in group, physical slot), the swizzle goes on the SOURCE slot. ----
+    // ---- weights by LDS-DMA: the fp16 planes go global -> LDS without touching registers.  The planes are k-step major
+    // ([k-step][row][32 halves], conv3x3_f16x3.hip), so one wave-instruction = 16 rows x 64 B = one contiguous KiB: wave-piece
+    // q = wave + NWV*k -> plane = q / (TAPS*WN), tap-in-stage t = (q / WN) % TAPS, row group q % WN; lane = (row in group,
+    // physical slot), the swizzle goes on the SOURCE slot. ----
     constexpr int NWPIECE = 2 * TAPS * WN;                // wave-pieces per stage
     constexpr int NWP = (NWPIECE + NWV - 1) / NWV;        // per wave (the last one may be inactive: wave-uniform)
     const _Float16* wsrc[NWP];
     int wdst[NWP];
+    const long long step_halves = (long long)a.wrows * 32;                    // one k-step of one plane
 #pragma unroll
     for (int k = 0; k < NWP; ++k) {
         const int qq = wave + NWV * k;
         const int qc = qq < NWPIECE ? qq : 0;
         const int plane = qc / (TAPS * WN);
         const int t = (qc / WN) % TAPS;
-        const int row = 16 * (qc % WN) + (lane >> 2);
-        const int ls = (lane & 3) ^ swz64(row);
-        const int nrow = (n0 + row) < a.wrows ? n0 + row : a.wrows - 1;      // rows past the packed ones: columns never stored
-        wsrc[k] = (plane ? a.w_lo : a.w_hi) + (long long)nrow * a.ktot + (long long)t * a.cs + ls * 8;
+        int rg = n0 + 16 * (qc % WN);                                         // first row of the group
+        if (rg >= a.wrows) rg = a.wrows - 16;                                 // groups past the packed rows: columns never stored
+        const int row = lane >> 2;
+        const int ls = (lane & 3) ^ swz64(row);                               // swz64(16j + row) == swz64(row)
+        wsrc[k] = (plane ? a.w_lo : a.w_hi) + t * step_halves + (long long)(rg + row) * 32 + ls * 8;
         wdst[k] = plane * (2 * TAPS * BN * 32) + (t * BN + 16 * (qc % WN)) * 32;   // halves from b_hi (b_lo = b_hi + 2*TAPS*BN*32)
     }
 
@@ -160,8 +163,8 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void conv3x3_f16x3_row_
             *reinterpret_cast<f16x8*>(halo_lo + hdst[k]) = lo;
         }
     };
-    // stage -> (chunk, first k-step q0): regular chunks have 9 k-steps (tap q), the tail chunk 3 (stored behind taps 0..2 of the
-    // weight row, so k-step q of either kind sits at q*cs + chunk*32)
+    // stage -> (chunk, first k-step q0): regular chunks have 9 k-steps (tap q), the tail chunk 3; k-step q of chunk c is the
+    // (9c + q)-th block of the k-step-major weight planes
     auto stage_pos = [&](int stage, int& chunk, int& q0) {
         const int full = nfull * SPC;
         chunk = stage < full ? stage / SPC : nfull;
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void conv3x3_f16x3_row_
     auto w_dma = [&](int stage, int buf) {
         int chunk, q0;
         stage_pos(stage, chunk, q0);
-        const long long koff = (long long)q0 * a.cs + chunk * 32;
+        const long long koff = (long long)(9 * chunk + q0) * step_halves;
 #pragma unroll
         for (int k = 0; k < NWP; ++k)
             if (wave + NWV * k < NWPIECE)

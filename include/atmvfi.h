@@ -128,10 +128,10 @@ int atmvfi_pack_weight(int mode, const float* src, float* dst, int Cout, int Cin
 int64_t atmvfi_split_weight_halves(int mode, int Cout, int Cin, int kh, int kw);
 int atmvfi_pack_weight_split(int mode, const float* src, void* dst_hi, void* dst_lo, int Cout, int Cin, int kh, int kw,
                              void* stream);   /* same source layouts and row order as atmvfi_pack_weight, CinPad32 */
-/* Weights of atmvfi_conv3x3_f16x3 (OIHW [Cout,Cin,3,3] -> two fp16 planes of atmvfi_conv3x3_weight_halves halves each):
- * per output row [9 taps][CS]; when 1 <= Cin % 32 <= 8 the channel tail is tap-packed (three k-steps of 4 taps x 8
- * channels stored behind taps 0..2, CS = Cin - tail + 32), so that e.g. the 32k+5-wide decoder maps do not pay nine
- * 32-wide k-steps for five channels; otherwise CS = round_up(Cin, 32).  Layout details: csrc/conv3x3_f16x3.hip. */
+/* Weights of atmvfi_conv3x3_f16x3 (OIHW [Cout,Cin,3,3] -> two fp16 planes of atmvfi_conv3x3_weight_halves halves each), k-step
+ * major: [k-step][row padded to 16][32 halves], k-step = (32-channel chunk, tap); when 1 <= Cin % 32 <= 8 the channel tail is
+ * tap-packed into three more k-steps of 4 taps x 8 channels, so that e.g. the 32k+5-wide decoder maps do not pay nine 32-wide
+ * k-steps for five channels.  Layout details: csrc/conv3x3_f16x3.hip. */
 int64_t atmvfi_conv3x3_weight_halves(int Cout, int Cin);
 int atmvfi_pack_weight_conv3x3(const float* src, void* dst_hi, void* dst_lo, int Cout, int Cin, void* stream);
 int atmvfi_conv3x3_f16x3(const float* in, int in_ld, int N, int H, int W, int Cin, const void* w_hi, const void* w_lo,
