@@ -207,8 +207,8 @@ extern "C" int atmvfi_window_attention(const float* qkv, float* out, float* moti
                                         int nW, int ws, int heads, int hd, int kv_shift, void* out_hi, void* out_lo,
                                         int plane_ld, void* stream) {
     ATMVFI_REQUIRE(qkv, ATMVFI_EINVAL, "window_attention: null pointer");
-    ATMVFI_REQUIRE(sink_ok(out, heads * hd, heads * hd, out_hi, out_lo, plane_ld), ATMVFI_EALIGN,
-                   "window_attention: output needs fp32 rows and/or both fp16 planes (ld %% 8 == 0, >= C), 16-byte aligned");
+    ATMVFI_REQUIRE(sink_ok(out, heads * hd, heads * hd, out_hi, out_lo, plane_ld, (long long)Bw * ws * ws), ATMVFI_EALIGN,
+                   "window_attention: output needs fp32 rows and/or both fp16 planes (plane rows >= Bw*ws*ws), 16-byte aligned");
     const RowSink sink{out, heads * hd, (_Float16*)out_hi, (_Float16*)out_lo, plane_ld};
     ATMVFI_REQUIRE(Bw > 0 && nW > 0 && Bw % nW == 0, ATMVFI_EINVAL, "window_attention: Bw %d must be a positive multiple of nW %d", Bw, nW);
     ATMVFI_REQUIRE(ws >= 1 && ws <= 16, ATMVFI_EINVAL, "window_attention: window size %d outside 1..16", ws);

@@ -42,12 +42,15 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 // Output of a row-producing kernel: fp32 rows, and/or the split-plane pair (hi = fp16(x), lo = fp16((x - hi) * 1024), both
 // saturating) that the split GEMM (gemm_split.hip) reads by LDS-DMA.  Either side may be null.
+// Plane layout, CHUNK MAJOR: element (row, c) lives at ((c / 32) * plane_rows + row) * 32 + c % 32, i.e. [32-channel chunk][row][32].
+// The 16 rows x 64 bytes that one LDS-DMA instruction of the GEMM moves are then one contiguous KiB; with row-major planes they
+// were 16 pieces a row pitch apart, 2.6x dearer to issue (tools/probes/dma_probe.hip).
 struct RowSink {
     float* f32;
     long long ld;
     _Float16* hi;
     _Float16* lo;
-    long long pl_ld;
+    long long plane_rows;
 };
 __device__ __forceinline__ void sink_store4(const RowSink& s, long long row, int c, const f32x4 v) {
     if (s.f32) *reinterpret_cast<f32x4*>(s.f32 + row * s.ld + c) = v;
@@ -60,15 +63,16 @@ __device__ __forceinline__ void sink_store4(const RowSink& s, long long row, int
             h[e] = hh;
             l[e] = (_Float16)fminf(fmaxf((x[e] - (float)hh) * 1024.0f, -65504.0f), 65504.0f);
         }
-        *reinterpret_cast<f16x4*>(s.hi + row * s.pl_ld + c) = h;
-        *reinterpret_cast<f16x4*>(s.lo + row * s.pl_ld + c) = l;
+        const long long off = ((long long)(c >> 5) * s.plane_rows + row) * 32 + (c & 31);
+        *reinterpret_cast<f16x4*>(s.hi + off) = h;
+        *reinterpret_cast<f16x4*>(s.lo + off) = l;
     }
 }
-static inline bool sink_ok(const void* f32, int ld, int C, const void* hi, const void* lo, int pl_ld) {
+static inline bool sink_ok(const void* f32, int ld, int C, const void* hi, const void* lo, long long plane_rows, long long rows) {
     if (!f32 && !hi) return false;
     if (f32 && (ld % 4 != 0 || ld < C || (reinterpret_cast<uintptr_t>(f32) & 15u))) return false;
     if ((hi == nullptr) != (lo == nullptr)) return false;
-    if (hi && (pl_ld % 8 != 0 || pl_ld < C || (reinterpret_cast<uintptr_t>(hi) & 15u) || (reinterpret_cast<uintptr_t>(lo) & 15u))) return false;
+    if (hi && (plane_rows < rows || (reinterpret_cast<uintptr_t>(hi) & 15u) || (reinterpret_cast<uintptr_t>(lo) & 15u))) return false;
     return true;
 }
 

@@ -253,10 +253,11 @@ extern "C" int atmvfi_gemm(const atmvfi_gemm_params* p, void* stream) {
     if (planes) {
         ATMVFI_REQUIRE(p->in_hi && p->in_lo && p->precision == ATMVFI_PREC_F16X3 && p->mode != ATMVFI_GEMM_CONV && !p->in_prelu,
                        ATMVFI_EINVAL, "gemm: split-plane input needs both planes, precision f16x3, LINEAR or DECONV mode and no in_prelu");
-        ATMVFI_REQUIRE(p->in_ld % 8 == 0 && p->in_gstride % 8 == 0 && atmvfi::aligned16(p->in_hi) && atmvfi::aligned16(p->in_lo),
-                       ATMVFI_EALIGN, "gemm: split planes need 16-byte aligned pointers, in_ld/in_gstride multiples of 8 halves");
-        ATMVFI_REQUIRE(p->in_ld >= atmvfi::round_up(p->Cin, 32), ATMVFI_EALIGN, "gemm: split-plane rows must hold round_up(Cin,32)=%d halves (in_ld %d)",
-                       atmvfi::round_up(p->Cin, 32), p->in_ld);
+        ATMVFI_REQUIRE(atmvfi::aligned16(p->in_hi) && atmvfi::aligned16(p->in_lo) && p->in_rpg == 0, ATMVFI_EALIGN,
+                       "gemm: split planes need 16-byte aligned pointers and plain rows");
+        const long long mrows = p->mode == ATMVFI_GEMM_LINEAR ? (long long)p->M : (long long)p->N * p->H * p->W;
+        ATMVFI_REQUIRE(p->in_ld >= mrows, ATMVFI_EALIGN, "gemm: with split planes in_ld is the plane row count and must cover M (%lld > %d)",
+                       mrows, p->in_ld);
     }
     ATMVFI_REQUIRE(p->mode >= 0 && p->mode <= 2, ATMVFI_EINVAL, "gemm: bad mode %d", p->mode);
     ATMVFI_REQUIRE(p->Cin > 0 && p->Cout > 0, ATMVFI_EINVAL, "gemm: bad channel counts");

@@ -10,6 +10,8 @@
 // One LDS stage = A_hi[256][32] A_lo[256][32] W_hi[128][32] W_lo[128][32] halves = 48 KiB; three stages.
 // LDS rows are 64 B; the slot swizzle ((row>>2)&1)<<1 is applied on the SOURCE address of the DMA (its
 // destination is lane-linear) and again on the fragment read.
+// Both operands are stored K-STEP MAJOR in global memory -- activations [32-channel chunk][row][32] (RowSink, common.h), weights
+// [k-step][row][32] (atmvfi_pack_weight_split_kmajor) -- so the 16 rows x 64 B of one DMA instruction are one contiguous KiB.
 // Per k-step: s_waitcnt vmcnt(6) (own pieces of this stage landed) -> s_barrier (everyone's landed, everyone is
 // done with the previous stage) -> DMA stage k+2 into the buffer of stage k-1 -> 16 ds_read_b128 + 48 MFMA.
 #include "common.h"
@@ -95,8 +97,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_split_kernel(const Gem
         const int ls = (lane & 3) ^ swz64(row);
         long long m = m0 + row;
         if (m >= a.M) m = a.M - 1;                                  // tail rows: valid address, result never stored
-        const long long off = (a.in_rpg > 0) ? (m / a.in_rpg) * a.in_gstride + (m % a.in_rpg) * (long long)a.in_ld : m * (long long)a.in_ld;
-        asrc[i] = (plane ? a.a_lo : a.a_hi) + off + ls * 8;
+        asrc[i] = (plane ? a.a_lo : a.a_hi) + m * 32 + ls * 8;      // chunk kc adds kc * plane_rows * 32
         adst[i] = (i * NW + wave) * 64 * 8;
     }
     const _Float16* wsrc[WPT];
@@ -109,22 +110,23 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_split_kernel(const Gem
         const int ls = (lane & 3) ^ swz64(row);
         int n = n0 + row;
         if (n >= a.wrows) n = a.wrows - 1;                          // columns past the packed rows: never stored
-        wsrc[i] = (plane ? a.w_lo : a.w_hi) + (long long)n * a.ktot32 + ls * 8;
+        wsrc[i] = (plane ? a.w_lo : a.w_hi) + (long long)n * 32 + ls * 8;       // k-step kc adds kc * wrows * 32
         wdst[i] = W_HI_OFF + (i * NW + wave) * 64 * 8;
     }
+    const long long astep = (long long)a.in_ld * 32, wstep = (long long)a.wrows * 32;      // halves per k-step of a plane (in_ld = plane rows)
     auto issue = [&](int kc, int buf) {
         _Float16* st = smem + buf * STAGE_HALVES;
 #pragma unroll
-        for (int i = 0; i < APT; ++i) dma16(asrc[i] + kc * 32, st + adst[i]);
+        for (int i = 0; i < APT; ++i) dma16(asrc[i] + kc * astep, st + adst[i]);
 #pragma unroll
-        for (int i = 0; i < WPT; ++i) dma16(wsrc[i] + kc * 32, st + wdst[i]);
+        for (int i = 0; i < WPT; ++i) dma16(wsrc[i] + kc * wstep, st + wdst[i]);
     };
     // one third of a stage's pieces (PIECES == 6: A pieces 0-3, W pieces 0-1)
     auto issue_pair = [&](int kc, int buf, int p) {
         _Float16* st = smem + buf * STAGE_HALVES;
-        if (p == 0) { dma16(asrc[0] + kc * 32, st + adst[0]); dma16(asrc[1] + kc * 32, st + adst[1]); }
-        if (p == 1) { dma16(asrc[2] + kc * 32, st + adst[2]); dma16(asrc[3] + kc * 32, st + adst[3]); }
-        if (p == 2) { dma16(wsrc[0] + kc * 32, st + wdst[0]); dma16(wsrc[1] + kc * 32, st + wdst[1]); }
+        if (p == 0) { dma16(asrc[0] + kc * astep, st + adst[0]); dma16(asrc[1] + kc * astep, st + adst[1]); }
+        if (p == 1) { dma16(asrc[2] + kc * astep, st + adst[2]); dma16(asrc[3] + kc * astep, st + adst[3]); }
+        if (p == 2) { dma16(wsrc[0] + kc * wstep, st + wdst[0]); dma16(wsrc[1] + kc * wstep, st + wdst[1]); }
     };
     // The DMA of one stage is spread over three items (an LDS-DMA instruction holds the wave's issue for 60-180 cycles)
     // and the two wave groups of a SIMD (waves 0-3 / 4-7) take different items, so one group's MFMAs cover the other's
@@ -271,11 +273,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_split_kernel(const Gem
 #endif
 }
 
-// fp32 rows -> (hi, lo') planes; one thread per 8 channels.  Pad channels (>= C, < ld_out) are written as zero.  An optional
-// per-channel PReLU is applied first (the leading nn.PReLU of the decoder stages, network_base.py:209,215).
+// fp32 rows -> (hi, lo') planes in the chunk-major layout; one thread per 8 channels, pad channels of the last chunk written as
+// zero.  An optional per-channel PReLU is applied first (the leading nn.PReLU of the decoder stages, network_base.py:209,215).
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ in, int in_ld, long long M, int C,
-                                                           const float* __restrict__ prelu, _Float16* hi, _Float16* lo, int ld) {
-    const int groups = ld / 8;
+                                                           const float* __restrict__ prelu, _Float16* hi, _Float16* lo, long long plane_rows) {
+    const int groups = (C + 31) / 32 * 4;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= M * groups) return;
     const long long m = t / groups;
@@ -298,8 +300,20 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
         h[e] = hh;
         l[e] = (_Float16)fminf(fmaxf((v - (float)hh) * 1024.0f, -65504.0f), 65504.0f);
     }
-    *reinterpret_cast<f16x8*>(hi + m * ld + c0) = h;
-    *reinterpret_cast<f16x8*>(lo + m * ld + c0) = l;
+    const long long off = ((long long)(c0 >> 5) * plane_rows + m) * 32 + (c0 & 31);
+    *reinterpret_cast<f16x8*>(hi + off) = h;
+    *reinterpret_cast<f16x8*>(lo + off) = l;
+}
+
+// [rows16][taps = 1][CinPad32] row-major split planes -> k-step major [k-step][rows16][32] (LINEAR and DECONV weights)
+__global__ void kmajor_kernel(const _Float16* __restrict__ src, _Float16* __restrict__ dst, int rows, int ksteps) {
+    const long long total = (long long)rows * ksteps * 32;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int e = (int)(idx & 31);
+        const int row = (int)((idx >> 5) % rows);
+        const int kc = (int)((idx >> 5) / rows);
+        dst[idx] = src[((long long)row * ksteps + kc) * 32 + e];
+    }
 }
 
 template <int WGM, int WGN>
@@ -332,12 +346,27 @@ int atmvfi::launch_gemm_split(const GemmDev& d, int ngemm, hipStream_t s) {
     return launch_split<4, 2>(d, ngemm, s);
 }
 
-extern "C" int atmvfi_split_planes(const float* in, int in_ld, int64_t M, int C, const float* prelu, void* hi, void* lo, int ld, void* stream) {
+extern "C" int atmvfi_split_planes(const float* in, int in_ld, int64_t M, int C, const float* prelu, void* hi, void* lo, int plane_rows,
+                                   void* stream) {
     ATMVFI_REQUIRE(in && hi && lo && M > 0 && C > 0, ATMVFI_EINVAL, "split_planes: bad arguments");
-    ATMVFI_REQUIRE(ld % 8 == 0 && ld >= C && in_ld >= C, ATMVFI_EALIGN, "split_planes: ld %d must be a multiple of 8 and >= C %d", ld, C);
+    ATMVFI_REQUIRE(plane_rows >= M && in_ld >= C, ATMVFI_EALIGN, "split_planes: plane rows %d must cover M and in_ld %d must cover C %d", plane_rows, in_ld, C);
     ATMVFI_REQUIRE(atmvfi::aligned16(hi) && atmvfi::aligned16(lo), ATMVFI_EALIGN, "split_planes: planes must be 16-byte aligned");
-    const long long n = (long long)M * (ld / 8);
+    const long long n = (long long)M * ((C + 31) / 32 * 4);
     hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, in_ld, (long long)M, C,
-                       prelu, (_Float16*)hi, (_Float16*)lo, ld);
+                       prelu, (_Float16*)hi, (_Float16*)lo, (long long)plane_rows);
     return atmvfi::check_launch("split_planes");
+}
+
+// Re-lays the two planes written by atmvfi_pack_weight_split (LINEAR or DECONV) k-step major for the LDS-DMA GEMM; same size.
+extern "C" int atmvfi_weight_planes_kmajor(int mode, const void* src_hi, const void* src_lo, void* dst_hi, void* dst_lo, int Cout, int Cin,
+                                           void* stream) {
+    ATMVFI_REQUIRE(src_hi && src_lo && dst_hi && dst_lo && Cout > 0 && Cin > 0 && (mode == ATMVFI_GEMM_LINEAR || mode == ATMVFI_GEMM_DECONV),
+                   ATMVFI_EINVAL, "weight_planes_kmajor: bad arguments (LINEAR and DECONV weights only)");
+    const int rows = (mode == ATMVFI_GEMM_DECONV) ? atmvfi::round_up(4 * atmvfi::round_up(Cout, 4), 16) : atmvfi::round_up(Cout, 16);
+    const int ksteps = atmvfi::round_up(Cin, 32) / 32;
+    const long long total = (long long)rows * ksteps * 32;
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(kmajor_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)src_hi, (_Float16*)dst_hi, rows, ksteps);
+    hipLaunchKernelGGL(kmajor_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)src_lo, (_Float16*)dst_lo, rows, ksteps);
+    return atmvfi::check_launch("weight_planes_kmajor");
 }

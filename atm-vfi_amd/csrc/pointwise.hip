@@ -455,8 +455,8 @@ extern "C" int atmvfi_layernorm(const float* in, int in_ld, int64_t in_gstride, 
     ATMVFI_REQUIRE(rows > 0 && C > 0 && C % 4 == 0, ATMVFI_EINVAL, "layernorm: C %d must be a positive multiple of 4", C);
     ATMVFI_REQUIRE(in_ld % 4 == 0 && in_ld >= C && in_gstride % 4 == 0, ATMVFI_EALIGN,
                    "layernorm: leading dimensions must be multiples of 4 and >= C");
-    ATMVFI_REQUIRE(sink_ok(out, out_ld, C, out_hi, out_lo, plane_ld), ATMVFI_EALIGN,
-                   "layernorm: output needs fp32 rows (ld %% 4 == 0) and/or both fp16 planes (ld %% 8 == 0), 16-byte aligned, ld >= C");
+    ATMVFI_REQUIRE(sink_ok(out, out_ld, C, out_hi, out_lo, plane_ld, rows), ATMVFI_EALIGN,
+                   "layernorm: output needs fp32 rows (ld %% 4 == 0, >= C) and/or both fp16 planes (plane rows >= rows), 16-byte aligned");
     ATMVFI_REQUIRE(atmvfi::aligned16(in) && atmvfi::aligned16(gamma) && atmvfi::aligned16(beta),
                    ATMVFI_EALIGN, "layernorm: pointers must be 16-byte aligned");
     const unsigned blocks = (unsigned)((rows + 3) / 4);
@@ -472,8 +472,8 @@ extern "C" int atmvfi_dwconv3x3_gelu(const float* in, int in_ld, float* out, int
     ATMVFI_REQUIRE(in && weight9 && bias, ATMVFI_EINVAL, "dwconv3x3_gelu: null pointer");
     ATMVFI_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, ATMVFI_EINVAL, "dwconv3x3_gelu: bad shape");
     ATMVFI_REQUIRE(in_ld % 4 == 0 && in_ld >= C, ATMVFI_EALIGN, "dwconv3x3_gelu: bad ld");
-    ATMVFI_REQUIRE(sink_ok(out, out_ld, C, out_hi, out_lo, plane_ld), ATMVFI_EALIGN,
-                   "dwconv3x3_gelu: output needs fp32 rows (ld %% 4 == 0) and/or both fp16 planes (ld %% 8 == 0), 16-byte aligned, ld >= C");
+    ATMVFI_REQUIRE(sink_ok(out, out_ld, C, out_hi, out_lo, plane_ld, (long long)N * H * W), ATMVFI_EALIGN,
+                   "dwconv3x3_gelu: output needs fp32 rows (ld %% 4 == 0, >= C) and/or both fp16 planes (plane rows >= N*H*W), 16-byte aligned");
     const RowSink sink{out, out_ld, (_Float16*)out_hi, (_Float16*)out_lo, plane_ld};
     ATMVFI_REQUIRE(atmvfi::aligned16(in) && atmvfi::aligned16(out) && atmvfi::aligned16(weight9) && atmvfi::aligned16(bias),
                    ATMVFI_EALIGN, "dwconv3x3_gelu: pointers must be 16-byte aligned");

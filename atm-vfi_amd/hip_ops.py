@@ -60,6 +60,7 @@ SIGNATURES = {
     "atmvfi_last_error": (ctypes.c_char_p, []),
     "atmvfi_gemm": (c_i, [ctypes.POINTER(GemmParams), c_f]),
     "atmvfi_split_planes": (c_i, [c_f, c_i, c_l, c_i, c_f, c_f, c_f, c_i, c_f]),
+    "atmvfi_weight_planes_kmajor": (c_i, [c_i, c_f, c_f, c_f, c_f, c_i, c_i, c_f]),
     "atmvfi_conv2d": (c_i, [ctypes.POINTER(GemmParams), c_f]),
     "atmvfi_linear": (c_i, [ctypes.POINTER(GemmParams), c_f]),
     "atmvfi_deconv2x2": (c_i, [ctypes.POINTER(GemmParams), c_f]),
@@ -114,33 +115,41 @@ class PackedWeight:
     packed: Optional[torch.Tensor]     # GEMM layout on the device (None only for test doubles)
     hi: Optional[torch.Tensor] = None  # split-precision planes (fp16) in the generic GEMM layout (gemm_f16x3 / gemm_split)
     lo: Optional[torch.Tensor] = None
-    hi3: Optional[torch.Tensor] = None  # 3x3 weights again in the conv3x3_f16x3 layout (tap-packed channel tail)
+    hi3: Optional[torch.Tensor] = None  # 3x3 weights again in the conv3x3_f16x3 layout (k-step major, tap-packed channel tail)
     lo3: Optional[torch.Tensor] = None
+    hik: Optional[torch.Tensor] = None  # LINEAR / DECONV planes again k-step major, for the split-plane (LDS-DMA) GEMM
+    lok: Optional[torch.Tensor] = None
 
 
 class Planes:
-    """Split-plane activation rows: one fp16 tensor [2, rows, ld] (plane 0 = hi, plane 1 = lo' = (x - hi) * 1024) holding
-    `c` real channels per row; ld is a multiple of 32 and the pad channels are finite (zero).  Producers write it in
-    their epilogue; the split GEMM reads it by LDS-DMA."""
+    """Split-plane activation rows: one fp16 tensor [2, chunks, rows, 32] -- plane 0 = hi, plane 1 = lo' = (x - hi) * 1024, CHUNK
+    MAJOR (channel c of row r at [c // 32, r, c % 32]) -- holding ``c`` real channels per row; the pad channels of the last chunk
+    are finite (zero).  Producers write it in their epilogue; the split GEMM reads it by LDS-DMA, 16 rows x 64 bytes = one
+    contiguous KiB per instruction."""
 
     def __init__(self, t: torch.Tensor, c: int):
-        if t.dtype != torch.float16 or t.dim() != 3 or t.shape[0] != 2 or not t.is_contiguous() or t.shape[2] % 32 or c > t.shape[2]:
-            raise ValueError(f"Planes: expected contiguous fp16 [2, rows, ld%32==0] with ld >= C, got {tuple(t.shape)} {t.dtype} C={c}")
+        if t.dtype != torch.float16 or t.dim() != 4 or t.shape[0] != 2 or t.shape[3] != 32 or not t.is_contiguous() or c > t.shape[1] * 32 \
+                or c <= (t.shape[1] - 1) * 32:
+            raise ValueError(f"Planes: expected contiguous fp16 [2, ceil(C/32), rows, 32], got {tuple(t.shape)} {t.dtype} C={c}")
         if not t.is_cuda:
             raise TypeError("Planes: tensor must live on the GPU")
         self.t, self.c = t, c
 
     @property
     def rows(self):
-        return self.t.shape[1]
+        return self.t.shape[2]
 
     @property
-    def ld(self):
-        return self.t.shape[2]
+    def chunks(self):
+        return self.t.shape[1]
+
+    def to_rows(self) -> torch.Tensor:
+        """[2, rows, chunks*32] row-major copy (tests / debugging)."""
+        return self.t.permute(0, 2, 1, 3).reshape(2, self.rows, self.chunks * 32)
 
     @staticmethod
     def alloc(rows: int, c: int, device) -> "Planes":
-        return Planes(torch.zeros(2, rows, (c + 31) // 32 * 32, dtype=torch.float16, device=device), c)
+        return Planes(torch.zeros(2, (c + 31) // 32, rows, 32, dtype=torch.float16, device=device), c)
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -254,6 +263,10 @@ class HipOps:
             pw.lo = torch.empty(nh, dtype=torch.float16, device=self.device)
             self._check(self.lib.atmvfi_pack_weight_split(mode, _ptr(w), _ptr(pw.hi), _ptr(pw.lo), cout, cin, kh, kw, self._stream()),
                         "pack_weight_split")
+            if mode in (GEMM_LINEAR, GEMM_DECONV):
+                pw.hik, pw.lok = torch.empty_like(pw.hi), torch.empty_like(pw.lo)
+                self._check(self.lib.atmvfi_weight_planes_kmajor(mode, _ptr(pw.hi), _ptr(pw.lo), _ptr(pw.hik), _ptr(pw.lok), cout, cin,
+                                                                 self._stream()), "weight_planes_kmajor")
             if mode == GEMM_CONV and kh == 3 and kw == 3:
                 n3 = self.lib.atmvfi_conv3x3_weight_halves(cout, cin)
                 pw.hi3 = torch.empty(n3, dtype=torch.float16, device=self.device)
@@ -316,12 +329,13 @@ class HipOps:
                        M=n * h * wd, out=out.data_ptr(), out_ld=old, out_gstride=0, out_rpg=0, out_row_map=None,
                        bias=_ptr(bias), prelu=_ptr(prelu), in_prelu=_ptr(in_prelu), residual=None, res_ld=0)
         p.precision, p.weight_hi, p.weight_lo = self._prec(w)
-        use_planes = planes is not None and p.precision == 1
+        use_planes = planes is not None and p.precision == 1 and w.hik is not None
         if use_planes:
             if planes.rows != n * h * wd or planes.c != cin:
                 raise ValueError("deconv: planes do not match the input rows")
-            p.in_, p.in_ld, p.in_prelu = None, planes.ld, None
+            p.in_, p.in_ld, p.in_prelu = None, planes.rows, None
             p.in_hi, p.in_lo = planes.t[0].data_ptr(), planes.t[1].data_ptr()
+            p.weight_hi, p.weight_lo = w.hik.data_ptr(), w.lok.data_ptr()
         meta = {"flops": 2.0 * n * h * wd * 4 * cout * cin, "bytes": 4.0 * (n * h * wd * cin + n * oh * ow * cout + 4 * cout * cin),
                 "shape": f"M{n * h * wd} N{4 * cout} K{cin}"}
         self._run("deconv2x2_split" if use_planes else "deconv2x2_f16x3" if p.precision else "deconv2x2", meta, self.lib.atmvfi_deconv2x2,
@@ -336,16 +350,16 @@ class HipOps:
             raise ValueError("split_planes: expected a plain [rows,C] view matching the planes")
         if prelu is not None and prelu.numel() < c:
             raise ValueError("split_planes: prelu needs one slope per channel")
-        meta = {"bytes": 4.0 * m * c + 4.0 * m * out.ld}
+        meta = {"bytes": 4.0 * m * c + 4.0 * m * out.chunks * 32}
         self._run("split_planes", meta, self.lib.atmvfi_split_planes, _ptr(x), ld, m, c, _ptr(prelu), out.t[0].data_ptr(),
-                  out.t[1].data_ptr(), out.ld, self._stream())
+                  out.t[1].data_ptr(), out.rows, self._stream())
 
     def linear(self, x, w: PackedWeight, out, bias=None, residual=None, out_row_map=None):
         planes = x if isinstance(x, Planes) else None
         if planes is not None:
-            if self.precision != "f16x3" or w.hi is None:
+            if self.precision != "f16x3" or w.hik is None:
                 raise ValueError("linear: split-plane input needs the f16x3 engine and split weights")
-            ld, m, cin, gs, rpg = planes.ld, planes.rows, planes.c, 0, 0
+            ld, m, cin, gs, rpg = planes.rows, planes.rows, planes.c, 0, 0
         else:
             ld, m, cin, gs, rpg = rows_view(x, "linear.in")
         old, mo, cout, ogs, orpg = rows_view(out, "linear.out")
@@ -367,6 +381,7 @@ class HipOps:
         p.precision, p.weight_hi, p.weight_lo = self._prec(w)
         if planes is not None:
             p.in_hi, p.in_lo = planes.t[0].data_ptr(), planes.t[1].data_ptr()
+            p.weight_hi, p.weight_lo = w.hik.data_ptr(), w.lok.data_ptr()
         meta = {"flops": 2.0 * m * cout * cin, "bytes": 4.0 * (m * cin + m * cout + cout * cin), "shape": f"M{m} N{cout} K{cin}"}
         self._run("linear_split" if planes is not None else "linear_f16x3" if p.precision else "linear", meta, self.lib.atmvfi_linear, ctypes.byref(p), self._stream())
 
@@ -378,7 +393,7 @@ class HipOps:
             return None, None, 0
         if planes.rows != rows or planes.c != c:
             raise ValueError(f"{what}: planes hold {planes.rows} x {planes.c}, kernel writes {rows} x {c}")
-        return planes.t[0].data_ptr(), planes.t[1].data_ptr(), planes.ld
+        return planes.t[0].data_ptr(), planes.t[1].data_ptr(), planes.rows
 
     def layernorm(self, x, out, gamma, beta, src_row_map=None, planes: Optional[Planes] = None):
         """``out`` (fp32 rows) may be None when only the split planes are wanted."""

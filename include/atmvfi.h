@@ -84,10 +84,10 @@ typedef struct atmvfi_gemm_params {
     int32_t precision;
     const void* weight_hi;
     const void* weight_lo;
-    /* Split-plane input (F16X3, LINEAR and DECONV modes): when in_hi/in_lo are set the activations are read from two fp16 planes
-       (written by a producer kernel or atmvfi_split_planes) by LDS-DMA instead of from `in`; in_ld / in_gstride
-       then count halves (multiples of 8), the planes are 16-byte aligned and every row holds
-       round_up(Cin, 32) readable, finite halves (pad channels meet zero weights).  `in` is ignored. */
+    /* Split-plane input (F16X3, LINEAR and DECONV modes): when in_hi/in_lo are set the activations are read by LDS-DMA from two
+       fp16 planes in the chunk-major layout [Cin/32 chunks][plane rows][32] written by a producer kernel's sink or by
+       atmvfi_split_planes; `in_ld` is then the plane row count (>= M), `in` is ignored, the pad channels of the last chunk must be
+       finite (they meet zero weights), and weight_hi / weight_lo must be k-step major (atmvfi_weight_planes_kmajor). */
     const void* in_hi;
     const void* in_lo;
 } atmvfi_gemm_params;
@@ -97,10 +97,13 @@ typedef struct atmvfi_gemm_params {
 
 int atmvfi_gemm(const atmvfi_gemm_params* p, void* stream);
 
-/* fp32 rows [M, C] (row stride in_ld floats) -> the two fp16 planes of the split-plane format,
-   hi = fp16(x), lo = fp16((x - hi) * 1024), both saturating; plane rows are ld halves (multiple of 8),
-   channels C..ld-1 are written as zero.  `prelu` (optional, [C]) is applied to the values first. */
-int atmvfi_split_planes(const float* in, int in_ld, int64_t M, int C, const float* prelu, void* hi, void* lo, int ld, void* stream);
+/* fp32 rows [M, C] (row stride in_ld floats) -> the two fp16 planes of the split-plane format, hi = fp16(x),
+   lo = fp16((x - hi) * 1024), both saturating, chunk major: element (row, c) at ((c / 32) * plane_rows + row) * 32 + c % 32
+   (each plane holds ceil(C / 32) * plane_rows * 32 halves; the pad channels of the last chunk are written as zero).
+   `prelu` (optional, [C]) is applied to the values first. */
+int atmvfi_split_planes(const float* in, int in_ld, int64_t M, int C, const float* prelu, void* hi, void* lo, int plane_rows, void* stream);
+/* The planes of atmvfi_pack_weight_split (LINEAR / DECONV) re-laid k-step major, [k-step][row][32], for the split-plane GEMM. */
+int atmvfi_weight_planes_kmajor(int mode, const void* src_hi, const void* src_lo, void* dst_hi, void* dst_lo, int Cout, int Cin, void* stream);
 
 /* Convenience wrappers with the reference-layer names (thin shims over atmvfi_gemm). */
 int atmvfi_conv2d(const atmvfi_gemm_params* p, void* stream);
@@ -145,19 +148,19 @@ int atmvfi_conv3x3_f16x3(const float* in, int in_ld, int N, int H, int W, int Ci
  * LayerNorm is exactly `beta` (attention.py:58-61 pads with zeros BEFORE norm1).
  * The map fuses pad_if_needed + torch.roll + window_partition (attention.py:273-313).
  * Output sinks (also of atmvfi_dwconv3x3_gelu and atmvfi_window_attention): fp32 rows `out`, and/or the split-plane
- * pair `out_hi`/`out_lo` (fp16, row stride plane_ld halves, a multiple of 8) that feeds atmvfi_gemm's in_hi/in_lo
+ * pair `out_hi`/`out_lo` (fp16, chunk major with `plane_rows` rows per 32-channel chunk) that feeds atmvfi_gemm's in_hi/in_lo
  * directly -- the consumer GEMM then skips its fp32 -> fp16-pair conversion.  Either side may be NULL, not both.
  * ---------------------------------------------------------------------------------- */
 int atmvfi_layernorm(const float* in, int in_ld, int64_t in_gstride, int in_rpg,
                      const int32_t* src_row_map, float* out, int out_ld,
                      const float* gamma, const float* beta, int64_t rows, int C,
-                     void* out_hi, void* out_lo, int plane_ld, void* stream);
+                     void* out_hi, void* out_lo, int plane_rows, void* stream);
 
 /* Depth-wise 3x3 conv (pad 1, bias) + exact GELU on NHWC tokens: DWConv + act of
  * attention.py:74-85,118-119.  weight9 is [9][C] (tap-major), see atmvfi_pack_dw_weight. */
 int atmvfi_dwconv3x3_gelu(const float* in, int in_ld, float* out, int out_ld,
                           const float* weight9, const float* bias,
-                          int N, int H, int W, int C, void* out_hi, void* out_lo, int plane_ld, void* stream);
+                          int N, int H, int W, int C, void* out_hi, void* out_lo, int plane_rows, void* stream);
 int atmvfi_pack_dw_weight(const float* src /*[C,1,3,3]*/, float* dst /*[9][C]*/, int C, void* stream);
 
 /* ------------------------------------------------------------------------------------
@@ -176,7 +179,7 @@ int atmvfi_pack_dw_weight(const float* src /*[C,1,3,3]*/, float* dst /*[9][C]*/,
  * ---------------------------------------------------------------------------------- */
 int atmvfi_window_attention(const float* qkv, float* out /*[Bw*N, C]*/, float* motion,
                             const int32_t* labels, int Bw, int nW, int ws, int heads, int hd,
-                            int kv_shift, void* out_hi, void* out_lo, int plane_ld, void* stream);
+                            int kv_shift, void* out_hi, void* out_lo, int plane_rows, void* stream);
 /* Named entry points of SURVEY.md section 8b (shims over atmvfi_window_attention). */
 int atmvfi_window_attn_cross_motion(const float* qkv, float* out, float* motion, const int32_t* labels,
                                     int Bw, int nW, int ws, int heads, int hd, void* stream);

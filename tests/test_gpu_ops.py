@@ -440,7 +440,7 @@ def test_gemm_modes_both_precisions(precision, hip, cpu, dev):
 # ------------------------------------------------------------------ split-plane activations (LDS-DMA GEMM)
 def planes_to_f32(p):
     """hi + lo'/1024: the value the split GEMM sees (fp64 so that the reconstruction itself adds nothing)."""
-    t = p.t.double().cpu()
+    t = p.to_rows().double().cpu()
     return (t[0] + t[1] / 1024.0)[:, :p.c]
 
 
@@ -451,13 +451,15 @@ def test_split_planes_format(hip, dev):
     buf = torch.zeros(150, 72)
     buf[:, :70] = x
     p = hip_ops.Planes.alloc(150, 70, dev)
-    assert p.ld == 96
+    assert p.chunks == 3 and tuple(p.t.shape) == (2, 3, 150, 32)          # chunk major: [plane, chunk, row, 32]
     hip.split_planes(buf.to(dev)[:, :70], p)
     torch.cuda.synchronize()
     hi = x.clamp(-65504, 65504).half()
     lo = ((x.clamp(-3e38, 3e38) - hi.float()) * 1024).clamp(-65504, 65504).half()
-    assert torch.equal(p.t[0, :, :70].cpu(), hi) and torch.equal(p.t[1, :, :70].cpu(), lo)
-    assert (p.t[:, :, 70:] == 0).all()                                    # pad channels are written as zero
+    pr = p.to_rows()
+    assert torch.equal(pr[0, :, :70].cpu(), hi) and torch.equal(pr[1, :, :70].cpu(), lo)
+    assert torch.equal(p.t[0, 2, :, 5].cpu(), hi[:, 69])                  # channel 69 = chunk 2, element 5
+    assert (pr[:, :, 70:] == 0).all()                                     # pad channels are written as zero
     err = (planes_to_f32(p) - x.double()).abs()
     normal = (x.abs() <= 65504) & (x.abs() >= 2.0 ** -14)
     assert (err / x.double().abs().clamp_min(1e-30))[normal].max().item() <= 2.0 ** -21    # ~22 significant bits in fp16's normal range
@@ -531,7 +533,7 @@ def test_split_plane_sinks(hip, cpu, dev):
         hip.layernorm(src, o2, gamma, beta, geo.row_map.to(dev), planes=p)
         torch.cuda.synchronize()
         hi, lo = split_of(of)
-        assert torch.equal(p.t[0, :, :C], hi) and torch.equal(p.t[1, :, :C], lo)
+        assert torch.equal(p.to_rows()[0, :, :C], hi) and torch.equal(p.to_rows()[1, :, :C], lo)
         if keep:
             assert torch.equal(o2, of)
     # dwconv + GELU (both kernels: C % 64 == 0 and not)
@@ -545,7 +547,7 @@ def test_split_plane_sinks(hip, cpu, dev):
         hip.dwconv_gelu(x, None, wt, b, planes=p)
         torch.cuda.synchronize()
         hi, lo = split_of(of.reshape(-1, c))
-        assert torch.equal(p.t[0, :, :c], hi) and torch.equal(p.t[1, :, :c], lo)
+        assert torch.equal(p.to_rows()[0, :, :c], hi) and torch.equal(p.to_rows()[1, :, :c], lo)
     # window attention
     ws, hd, heads = 8, 28, 8
     geo = windows.build_window_geometry(2, 12, 20, ws, 4)
@@ -558,7 +560,7 @@ def test_split_plane_sinks(hip, cpu, dev):
     hip.window_attention(qkv, None, None, lab, bw, geo.n_windows, ws, heads, hd, bw // 2, planes=p)
     torch.cuda.synchronize()
     hi, lo = split_of(of)
-    assert torch.equal(p.t[0, :, :C], hi) and torch.equal(p.t[1, :, :C], lo)
+    assert torch.equal(p.to_rows()[0, :, :C], hi) and torch.equal(p.to_rows()[1, :, :C], lo)
     with pytest.raises(ValueError):
         hip.layernorm(src, None, gamma, beta)                              # no output at all
 
