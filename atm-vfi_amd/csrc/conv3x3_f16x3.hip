@@ -27,15 +27,20 @@
 
 namespace {
 
+// generic split planes, K-STEP MAJOR: [k-step = tap * (CinPad32 / 32) + chunk][row][32 halves] -- the 16 rows x 64 B that one
+// load / LDS-DMA instruction of the GEMM engines moves are one contiguous KiB (gemm_f16x3.hip, gemm_split.hip)
 __global__ void pack_split_kernel(int mode, const float* __restrict__ src, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
                                   int Cout, int Cin, int kh, int kw, int rows, int cin_pad, int coutp) {
     const int taps = (mode == ATMVFI_GEMM_DECONV) ? 1 : kh * kw;
+    const int cpt = cin_pad >> 5;
     const long long total = (long long)rows * taps * cin_pad;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % cin_pad);
-        const int tap = (int)((idx / cin_pad) % taps);
-        const int row = (int)(idx / ((long long)cin_pad * taps));
+        const int e = (int)(idx & 31);
+        const int row = (int)((idx >> 5) % rows);
+        const int kstep = (int)((idx >> 5) / rows);
+        const int tap = kstep / cpt;
+        const int c = (kstep - tap * cpt) * 32 + e;
         float v = 0.f;
         if (c < Cin) {
             if (mode == ATMVFI_GEMM_DECONV) {

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(512) void gemm_f16x3_kernel(const GemmDev a) {
             const int rem = P - plane * BN * 4;
             const int row = wact[k] ? (rem >> 2) : 0;
             wok[k] = wact[k] && (n0 + row) < a.wrows;
-            wsrc[k] = (plane ? a.w_lo : a.w_hi) + (long long)(wok[k] ? n0 + row : 0) * a.ktot32 + (rem & 3) * 8;
+            wsrc[k] = (plane ? a.w_lo : a.w_hi) + (long long)(wok[k] ? n0 + row : 0) * 32 + (rem & 3) * 8;      // k-step major: + kc * wrows * 32
         }
     };
 
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(512) void gemm_f16x3_kernel(const GemmDev a) {
                 rp[i][1] = *reinterpret_cast<const f32x4*>(a.in_prelu + pc + 4);
             }
         }
-        const long long koff = (long long)kc * 32;
+        const long long koff = (long long)kc * a.wrows * 32;
 #pragma unroll
         for (int k = 0; k < B_PPT; ++k) {
             wr[k] = *reinterpret_cast<const f16x8*>(wsrc[k] + koff);         // row-clamped address: always valid; masked at store

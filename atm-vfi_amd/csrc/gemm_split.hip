@@ -11,7 +11,7 @@
 // LDS rows are 64 B; the slot swizzle ((row>>2)&1)<<1 is applied on the SOURCE address of the DMA (its
 // destination is lane-linear) and again on the fragment read.
 // Both operands are stored K-STEP MAJOR in global memory -- activations [32-channel chunk][row][32] (RowSink, common.h), weights
-// [k-step][row][32] (atmvfi_pack_weight_split_kmajor) -- so the 16 rows x 64 B of one DMA instruction are one contiguous KiB.
+// [k-step][row][32] (atmvfi_pack_weight_split) -- so the 16 rows x 64 B of one DMA instruction are one contiguous KiB.
 // Per k-step: s_waitcnt vmcnt(6) (own pieces of this stage landed) -> s_barrier (everyone's landed, everyone is
 // done with the previous stage) -> DMA stage k+2 into the buffer of stage k-1 -> 16 ds_read_b128 + 48 MFMA.
 #include "common.h"
@@ -305,17 +305,6 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
     *reinterpret_cast<f16x8*>(lo + off) = l;
 }
 
-// [rows16][taps = 1][CinPad32] row-major split planes -> k-step major [k-step][rows16][32] (LINEAR and DECONV weights)
-__global__ void kmajor_kernel(const _Float16* __restrict__ src, _Float16* __restrict__ dst, int rows, int ksteps) {
-    const long long total = (long long)rows * ksteps * 32;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-        const int e = (int)(idx & 31);
-        const int row = (int)((idx >> 5) % rows);
-        const int kc = (int)((idx >> 5) / rows);
-        dst[idx] = src[((long long)row * ksteps + kc) * 32 + e];
-    }
-}
-
 template <int WGM, int WGN>
 int launch_split(const GemmDev& d, int ngemm, hipStream_t s) {
     constexpr int BM = 64 * WGM, BN = 64 * WGN;
@@ -355,18 +344,4 @@ extern "C" int atmvfi_split_planes(const float* in, int in_ld, int64_t M, int C,
     hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, in_ld, (long long)M, C,
                        prelu, (_Float16*)hi, (_Float16*)lo, (long long)plane_rows);
     return atmvfi::check_launch("split_planes");
-}
-
-// Re-lays the two planes written by atmvfi_pack_weight_split (LINEAR or DECONV) k-step major for the LDS-DMA GEMM; same size.
-extern "C" int atmvfi_weight_planes_kmajor(int mode, const void* src_hi, const void* src_lo, void* dst_hi, void* dst_lo, int Cout, int Cin,
-                                           void* stream) {
-    ATMVFI_REQUIRE(src_hi && src_lo && dst_hi && dst_lo && Cout > 0 && Cin > 0 && (mode == ATMVFI_GEMM_LINEAR || mode == ATMVFI_GEMM_DECONV),
-                   ATMVFI_EINVAL, "weight_planes_kmajor: bad arguments (LINEAR and DECONV weights only)");
-    const int rows = (mode == ATMVFI_GEMM_DECONV) ? atmvfi::round_up(4 * atmvfi::round_up(Cout, 4), 16) : atmvfi::round_up(Cout, 16);
-    const int ksteps = atmvfi::round_up(Cin, 32) / 32;
-    const long long total = (long long)rows * ksteps * 32;
-    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-    hipLaunchKernelGGL(kmajor_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)src_hi, (_Float16*)dst_hi, rows, ksteps);
-    hipLaunchKernelGGL(kmajor_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)src_lo, (_Float16*)dst_lo, rows, ksteps);
-    return atmvfi::check_launch("weight_planes_kmajor");
 }

@@ -60,7 +60,6 @@ SIGNATURES = {
     "atmvfi_last_error": (ctypes.c_char_p, []),
     "atmvfi_gemm": (c_i, [ctypes.POINTER(GemmParams), c_f]),
     "atmvfi_split_planes": (c_i, [c_f, c_i, c_l, c_i, c_f, c_f, c_f, c_i, c_f]),
-    "atmvfi_weight_planes_kmajor": (c_i, [c_i, c_f, c_f, c_f, c_f, c_i, c_i, c_f]),
     "atmvfi_conv2d": (c_i, [ctypes.POINTER(GemmParams), c_f]),
     "atmvfi_linear": (c_i, [ctypes.POINTER(GemmParams), c_f]),
     "atmvfi_deconv2x2": (c_i, [ctypes.POINTER(GemmParams), c_f]),
@@ -113,12 +112,10 @@ class PackedWeight:
     kw: int
     orig: torch.Tensor                 # the parameter (OIHW / [out,in] / IOHW)
     packed: Optional[torch.Tensor]     # GEMM layout on the device (None only for test doubles)
-    hi: Optional[torch.Tensor] = None  # split-precision planes (fp16) in the generic GEMM layout (gemm_f16x3 / gemm_split)
+    hi: Optional[torch.Tensor] = None  # split-precision planes (fp16), k-step major, of the two GEMM engines (gemm_f16x3 / gemm_split)
     lo: Optional[torch.Tensor] = None
     hi3: Optional[torch.Tensor] = None  # 3x3 weights again in the conv3x3_f16x3 layout (k-step major, tap-packed channel tail)
     lo3: Optional[torch.Tensor] = None
-    hik: Optional[torch.Tensor] = None  # LINEAR / DECONV planes again k-step major, for the split-plane (LDS-DMA) GEMM
-    lok: Optional[torch.Tensor] = None
 
 
 class Planes:
@@ -263,10 +260,6 @@ class HipOps:
             pw.lo = torch.empty(nh, dtype=torch.float16, device=self.device)
             self._check(self.lib.atmvfi_pack_weight_split(mode, _ptr(w), _ptr(pw.hi), _ptr(pw.lo), cout, cin, kh, kw, self._stream()),
                         "pack_weight_split")
-            if mode in (GEMM_LINEAR, GEMM_DECONV):
-                pw.hik, pw.lok = torch.empty_like(pw.hi), torch.empty_like(pw.lo)
-                self._check(self.lib.atmvfi_weight_planes_kmajor(mode, _ptr(pw.hi), _ptr(pw.lo), _ptr(pw.hik), _ptr(pw.lok), cout, cin,
-                                                                 self._stream()), "weight_planes_kmajor")
             if mode == GEMM_CONV and kh == 3 and kw == 3:
                 n3 = self.lib.atmvfi_conv3x3_weight_halves(cout, cin)
                 pw.hi3 = torch.empty(n3, dtype=torch.float16, device=self.device)
@@ -329,13 +322,12 @@ class HipOps:
                        M=n * h * wd, out=out.data_ptr(), out_ld=old, out_gstride=0, out_rpg=0, out_row_map=None,
                        bias=_ptr(bias), prelu=_ptr(prelu), in_prelu=_ptr(in_prelu), residual=None, res_ld=0)
         p.precision, p.weight_hi, p.weight_lo = self._prec(w)
-        use_planes = planes is not None and p.precision == 1 and w.hik is not None
+        use_planes = planes is not None and p.precision == 1
         if use_planes:
             if planes.rows != n * h * wd or planes.c != cin:
                 raise ValueError("deconv: planes do not match the input rows")
             p.in_, p.in_ld, p.in_prelu = None, planes.rows, None
             p.in_hi, p.in_lo = planes.t[0].data_ptr(), planes.t[1].data_ptr()
-            p.weight_hi, p.weight_lo = w.hik.data_ptr(), w.lok.data_ptr()
         meta = {"flops": 2.0 * n * h * wd * 4 * cout * cin, "bytes": 4.0 * (n * h * wd * cin + n * oh * ow * cout + 4 * cout * cin),
                 "shape": f"M{n * h * wd} N{4 * cout} K{cin}"}
         self._run("deconv2x2_split" if use_planes else "deconv2x2_f16x3" if p.precision else "deconv2x2", meta, self.lib.atmvfi_deconv2x2,
@@ -357,7 +349,7 @@ class HipOps:
     def linear(self, x, w: PackedWeight, out, bias=None, residual=None, out_row_map=None):
         planes = x if isinstance(x, Planes) else None
         if planes is not None:
-            if self.precision != "f16x3" or w.hik is None:
+            if self.precision != "f16x3" or w.hi is None:
                 raise ValueError("linear: split-plane input needs the f16x3 engine and split weights")
             ld, m, cin, gs, rpg = planes.rows, planes.rows, planes.c, 0, 0
         else:
@@ -381,7 +373,6 @@ class HipOps:
         p.precision, p.weight_hi, p.weight_lo = self._prec(w)
         if planes is not None:
             p.in_hi, p.in_lo = planes.t[0].data_ptr(), planes.t[1].data_ptr()
-            p.weight_hi, p.weight_lo = w.hik.data_ptr(), w.lok.data_ptr()
         meta = {"flops": 2.0 * m * cout * cin, "bytes": 4.0 * (m * cin + m * cout + cout * cin), "shape": f"M{m} N{cout} K{cin}"}
         self._run("linear_split" if planes is not None else "linear_f16x3" if p.precision else "linear", meta, self.lib.atmvfi_linear, ctypes.byref(p), self._stream())
 

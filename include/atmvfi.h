@@ -87,7 +87,7 @@ typedef struct atmvfi_gemm_params {
     /* Split-plane input (F16X3, LINEAR and DECONV modes): when in_hi/in_lo are set the activations are read by LDS-DMA from two
        fp16 planes in the chunk-major layout [Cin/32 chunks][plane rows][32] written by a producer kernel's sink or by
        atmvfi_split_planes; `in_ld` is then the plane row count (>= M), `in` is ignored, the pad channels of the last chunk must be
-       finite (they meet zero weights), and weight_hi / weight_lo must be k-step major (atmvfi_weight_planes_kmajor). */
+       finite (they meet zero weights). */
     const void* in_hi;
     const void* in_lo;
 } atmvfi_gemm_params;
@@ -102,8 +102,6 @@ int atmvfi_gemm(const atmvfi_gemm_params* p, void* stream);
    (each plane holds ceil(C / 32) * plane_rows * 32 halves; the pad channels of the last chunk are written as zero).
    `prelu` (optional, [C]) is applied to the values first. */
 int atmvfi_split_planes(const float* in, int in_ld, int64_t M, int C, const float* prelu, void* hi, void* lo, int plane_rows, void* stream);
-/* The planes of atmvfi_pack_weight_split (LINEAR / DECONV) re-laid k-step major, [k-step][row][32], for the split-plane GEMM. */
-int atmvfi_weight_planes_kmajor(int mode, const void* src_hi, const void* src_lo, void* dst_hi, void* dst_lo, int Cout, int Cin, void* stream);
 
 /* Convenience wrappers with the reference-layer names (thin shims over atmvfi_gemm). */
 int atmvfi_conv2d(const atmvfi_gemm_params* p, void* stream);
@@ -124,13 +122,14 @@ int atmvfi_pack_weight(int mode, const float* src, float* dst, int Cout, int Cin
  * Every fp32 operand is split as x = hi + lo (fp16 each) and hi*hi + hi*lo + lo*hi is accumulated
  * in fp32 on v_mfma_f32_16x16x32_f16 (3 MFMAs at 16x the fp32-MFMA rate; ~22 significand bits,
  * finite for |x| < 1.3e5).  The input halo of a 16x16 output tile is staged in LDS once per
- * 32-channel chunk and reused by all nine taps.  Weights are split once by
- * atmvfi_pack_weight_split into two fp16 planes [rows16(Cout)][kh*kw][CinPad32]
- * (atmvfi_split_weight_halves() halves each).  Epilogue: + bias[co]; PReLU(slope[co]).
+ * 32-channel chunk and reused by all nine taps.  Epilogue: + bias[co]; PReLU(slope[co]).
+ * Split weights of the two GEMM engines (atmvfi_gemm with precision F16X3): atmvfi_pack_weight_split writes two fp16 planes
+ * (atmvfi_split_weight_halves() halves each), K-STEP MAJOR: [k-step = tap * CinPad32/32 + chunk][row16][32 halves], same source
+ * layouts and row order as atmvfi_pack_weight -- the 16 rows x 64 bytes one load / LDS-DMA instruction moves are one contiguous KiB.
  * ---------------------------------------------------------------------------------- */
 int64_t atmvfi_split_weight_halves(int mode, int Cout, int Cin, int kh, int kw);
 int atmvfi_pack_weight_split(int mode, const float* src, void* dst_hi, void* dst_lo, int Cout, int Cin, int kh, int kw,
-                             void* stream);   /* same source layouts and row order as atmvfi_pack_weight, CinPad32 */
+                             void* stream);
 /* Weights of atmvfi_conv3x3_f16x3 (OIHW [Cout,Cin,3,3] -> two fp16 planes of atmvfi_conv3x3_weight_halves halves each), k-step
  * major: [k-step][row padded to 16][32 halves], k-step = (32-channel chunk, tap); when 1 <= Cin % 32 <= 8 the channel tail is
  * tap-packed into three more k-steps of 4 taps x 8 channels, so that e.g. the 32k+5-wide decoder maps do not pay nine 32-wide
