@@ -49,8 +49,6 @@ template <int WN>
 __global__ __launch_bounds__(512) void gemm_f16x3_kernel(const GemmDev a) {
     constexpr int BM = 256;
     constexpr int BN = 16 * WN;
-    constexpr int BP = BN * 8;                       // 16-byte weight pieces per chunk (hi + lo planes)
-    constexpr int B_PPT = (BP + 511) / 512;
     extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
     _Float16* a_hi = smem;                           // [2][BM][32]
     _Float16* a_lo = a_hi + 2 * BM * 32;
@@ -69,23 +67,22 @@ __global__ __launch_bounds__(512) void gemm_f16x3_kernel(const GemmDev a) {
     const float* rbase[2];
     int iy0[2], ix0[2], adst[2];
     bool rok[2];
-    const _Float16* wsrc[B_PPT];
-    int wdst[B_PPT];
-    bool wok[B_PPT], wact[B_PPT], wlo[B_PPT];
+    // weights by LDS-DMA (k-step-major planes: one wave-instruction = 16 rows x 64 B = one contiguous KiB; no register staging,
+    // no ds_write): wave-piece qq = wave + 8k -> plane = qq / WN, row group qq % WN; lane = (row in group, physical slot)
+    constexpr int NWPIECE = 2 * WN;
+    constexpr int NWP = (NWPIECE + 7) / 8;
+    const _Float16* wsrc[NWP];
+    int wdst[NWP];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int row = (tid >> 2) + 128 * i;
         adst[i] = row * 32 + ((q ^ swz64(row)) << 3);
     }
 #pragma unroll
-    for (int k = 0; k < B_PPT; ++k) {
-        const int P = tid + 512 * k;
-        wact[k] = P < BP;
-        const int plane = (P >= BN * 4) ? 1 : 0;
-        const int rem = P - plane * BN * 4;
-        const int row = wact[k] ? (rem >> 2) : 0;
-        wlo[k] = plane == 1;
-        wdst[k] = row * 32 + (((rem & 3) ^ swz64(row)) << 3);
+    for (int k = 0; k < NWP; ++k) {
+        const int qq = wave + 8 * k;
+        const int qc = qq < NWPIECE ? qq : 0;
+        wdst[k] = (qc / WN) * (2 * BN * 32) + 16 * (qc % WN) * 32;        // halves from b_hi (b_lo = b_hi + 2*BN*32)
     }
     // XCD-aware tile order.  Virtual blocks b and b+8 share an XCD (and its 4 MiB L2), so the NB column blocks that
     // re-read one 256-row activation tile are dealt to ONE XCD back to back: the tile comes from HBM once and
@@ -126,13 +123,13 @@ __global__ __launch_bounds__(512) void gemm_f16x3_kernel(const GemmDev a) {
             }
         }
 #pragma unroll
-        for (int k = 0; k < B_PPT; ++k) {
-            const int P = tid + 512 * k;
-            const int plane = (P >= BN * 4) ? 1 : 0;
-            const int rem = P - plane * BN * 4;
-            const int row = wact[k] ? (rem >> 2) : 0;
-            wok[k] = wact[k] && (n0 + row) < a.wrows;
-            wsrc[k] = (plane ? a.w_lo : a.w_hi) + (long long)(wok[k] ? n0 + row : 0) * 32 + (rem & 3) * 8;      // k-step major: + kc * wrows * 32
+        for (int k = 0; k < NWP; ++k) {
+            const int qq = wave + 8 * k;
+            const int qc = qq < NWPIECE ? qq : 0;
+            int rg = n0 + 16 * (qc % WN);
+            if (rg >= a.wrows) rg = a.wrows - 16;                          // groups past the packed rows: columns never stored
+            const int row = lane >> 2;
+            wsrc[k] = ((qc / WN) ? a.w_lo : a.w_hi) + (long long)(rg + row) * 32 + (((lane & 3) ^ swz64(row)) << 3);   // + kc * wrows * 32
         }
     };
 
@@ -147,7 +144,6 @@ __global__ __launch_bounds__(512) void gemm_f16x3_kernel(const GemmDev a) {
 
     f32x4 ra[2][2], rp[2][2];              // rp: in_prelu slopes of the same 8 channels, fetched WITH the activations
     int anv[2];
-    f16x8 wr[B_PPT];
 
     auto load_chunk = [&](int kc) {
         const int tap = kc / a.cpt32;
@@ -176,11 +172,14 @@ __global__ __launch_bounds__(512) void gemm_f16x3_kernel(const GemmDev a) {
                 rp[i][1] = *reinterpret_cast<const f32x4*>(a.in_prelu + pc + 4);
             }
         }
+        // this chunk's weights straight into the LDS buffer it will be read from (free: everyone passed the barrier behind its last
+        // reader); waited for with the activation loads, before the barrier that publishes the chunk
         const long long koff = (long long)kc * a.wrows * 32;
 #pragma unroll
-        for (int k = 0; k < B_PPT; ++k) {
-            wr[k] = *reinterpret_cast<const f16x8*>(wsrc[k] + koff);         // row-clamped address: always valid; masked at store
-        }
+        for (int k = 0; k < NWP; ++k)
+            if (wave + 8 * k < NWPIECE)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[k] + koff),
+                                                 (__attribute__((address_space(3))) void*)(b_hi + (kc & 1) * BN * 32 + wdst[k]), 16, 0, 0);
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
@@ -211,11 +210,7 @@ __global__ __launch_bounds__(512) void gemm_f16x3_kernel(const GemmDev a) {
             *reinterpret_cast<f16x8*>(a_hi + buf * BM * 32 + adst[i]) = hi;
             *reinterpret_cast<f16x8*>(a_lo + buf * BM * 32 + adst[i]) = lo;
         }
-#pragma unroll
-        for (int k = 0; k < B_PPT; ++k)
-            if (wact[k])
-                *reinterpret_cast<f16x8*>((wlo[k] ? b_lo : b_hi) + buf * BN * 32 + wdst[k]) =
-                    wok[k] ? wr[k] : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // own weight DMA pieces of this chunk have landed (the barrier publishes them)
     };
 
     // Persistent tile loop.  The first chunk of the NEXT tile is fetched (registers) before the epilogue of the current
