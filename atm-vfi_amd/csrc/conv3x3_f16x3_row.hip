@@ -210,6 +210,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void conv3x3_f16x3_row_
         asm volatile("" : "+v"(dt));       // opaque: keeps hipcc from hoisting the six tail-stage offsets out of the loop (spills at WN = 8)
         const bool more_w = (s + 1) < nstages;
         const bool next_halo = !tail_stage && (q0 + TAPS == 9) && (chunk + 1 < nchunks);      // last stage of a regular chunk
+        STAMP(7)
         if (more_w) w_dma(s + 1, wb ^ 1);       // that buffer was last read in stage s-1: everyone has passed its barrier
         if (next_halo) {
 #pragma unroll

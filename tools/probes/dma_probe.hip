@@ -8,11 +8,12 @@ __device__ __forceinline__ void dma16(const h16* src, h16* lds) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
 }
 template <int MODE, int CONTIG>
-__global__ __launch_bounds__(512) void probe(const h16* src, long long stride_rows, unsigned long long* out, int iters) {
+__global__ __launch_bounds__(512) void probe(const h16* src, long long stride_rows, unsigned long long* out, int iters, int shared_src) {
     extern __shared__ __attribute__((aligned(16))) h16 smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long acc = 0;
-    const h16* base = src + ((long long)blockIdx.x * 8 + wave) * 6 * 16 * (CONTIG ? 32 : stride_rows);
+    // shared_src: every workgroup streams the SAME addresses (weights of a convolution), else each wave its own
+    const h16* base = src + ((long long)(shared_src ? 0 : blockIdx.x) * 8 + wave) * 6 * 16 * (CONTIG ? 32 : stride_rows);
     for (int it = 0; it < iters; ++it) {
         __builtin_amdgcn_s_barrier();
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();
@@ -20,7 +21,7 @@ __global__ __launch_bounds__(512) void probe(const h16* src, long long stride_ro
         for (int k = 0; k < 6; ++k) {
             const h16* p = CONTIG ? base + (k * 16 + (lane >> 2)) * 32 + (lane & 3) * 8
                                   : base + (long long)(k * 16 + (lane >> 2)) * stride_rows + (lane & 3) * 8;
-            dma16(p + (long long)it * 64 * 4096, smem + (wave * 6 + k) * 512);
+            dma16(p + (long long)it * (shared_src ? 8 * 6 * 16 * 32 : 64 * 4096), smem + (wave * 6 + k) * 512);
         }
         if (MODE == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (MODE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -35,17 +36,18 @@ int main() {
     const size_t n = (size_t)1 << 30;           // 2 GiB of halves
     hipMalloc(&src, n * 2); hipMemset(src, 0, n * 2); hipMalloc(&out, 2048 * 8);
     const int iters = 50;
+    for (int shared = 0; shared < 2; ++shared)
     for (int contig = 0; contig < 2; ++contig)
-        for (int mode = 0; mode < 3; ++mode) {
+        for (int mode = 0; mode < 3; mode += 2) {
             for (int rep = 0; rep < 2; ++rep) {
-#define L(M, C) hipLaunchKernelGGL((probe<M, C>), dim3(256), dim3(512), 8 * 6 * 1024, 0, src, 4096LL, out, iters)
+#define L(M, C) hipLaunchKernelGGL((probe<M, C>), dim3(256), dim3(512), 8 * 6 * 1024, 0, src, 4096LL, out, iters, shared)
                 if (contig == 0) { if (mode == 0) L(0, 0); else if (mode == 1) L(1, 0); else L(2, 0); }
                 else { if (mode == 0) L(0, 1); else if (mode == 1) L(1, 1); else L(2, 1); }
                 hipDeviceSynchronize();
             }
             unsigned long long h[2048]; hipMemcpy(h, out, sizeof(h), hipMemcpyDeviceToHost);
             double m = 0; for (auto v : h) m += v; m /= 2048 * iters;
-            printf("%s source, %s: %.0f ticks per 6 DMA instructions per wave\n", contig ? "contiguous-KiB" : "16-row-scattered",
+            printf("%s%s source, %s: %.0f ticks per 6 DMA instructions per wave\n", shared ? "SHARED " : "", contig ? "contiguous-KiB" : "16-row-scattered",
                    mode == 0 ? "issue only" : mode == 1 ? "issue + lgkmcnt(0)" : "issue + vmcnt(0)", m);
         }
     return 0;

@@ -25,8 +25,8 @@ for _ in range(3):
 torch.cuda.synchronize()
 t = buf.reshape(-1, 8).double()
 t = t[t.sum(1) > 0]
-names = ["prologue", "issue loads", "LDS reads + MFMA", "weight ds_write", "stage barrier", "halo convert+write+barrier", "epilogue", "-"]
+names = ["prologue", "issue loads (DMA + halo loads)", "LDS reads + MFMA", "vmcnt(0) wait", "stage barrier", "halo convert+write+barrier", "epilogue", "loop top (stage decode)"]
 tot = t.sum(1).mean().item()
 print(f"{H}x{W} {cin}->{cout}: waves {t.shape[0]}, mean cycles per wave {tot:.0f} (s_memtime ticks)")
-for k in range(7):
+for k in range(8):
     print(f"  {names[k]:28s} {t[:, k].mean().item():10.0f}  {100 * t[:, k].mean().item() / tot:5.1f} %")
