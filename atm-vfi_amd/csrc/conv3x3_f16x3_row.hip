@@ -349,32 +349,45 @@ int launch_row(const Conv3Dev& d, int ntiles, hipStream_t s) {
 }  // namespace
 
 int atmvfi::launch_conv3x3_row(const Conv3Dev& d, int ntiles, hipStream_t s) {
-    // Tile width WN (n-tiles per workgroup) and schedule, chosen together by one cost model:
-    //   time ~ rounds(launch) x tile time,  tile time ~ WN * (1 + 1/WN) [MFMA work ~ WN, operand staging per tile ~ const]
+    // Tile width WN (n-tiles per workgroup), then the schedule:
+    //   work ~ padded tiles * (1 + 1/WN) [MFMA work ~ WN, operand staging per tile ~ const]; an under-filled launch is charged the
+    //   idle CUs, which is what keeps small maps busy (a 36x60 map with 768 channels is 72 workgroups at WN = 8, 192 at WN = 3);
     //   rounds = ceil(workgroups / resident slots): one slot per CU for the 512-thread schedule, two for the half-size one.
+    //   (A joint search over (WN, schedule) on rounds x tile time picked 3-tile half workgroups for 389- and 576-wide layers and
+    //   lost 10 % at 576x960: the halo staging repeated per column block is dearer than the model's constant.)
     // The half-size schedule overlaps two workgroups' DMA issue, barrier waits and halo conversion and quantises better on small
     // images (8-row tiles), but streams the weights twice per 256 pixels and pays a barrier per tap: `rel` is its measured tile-pair
-    // time relative to a full tile at that width (1080p layers, same-box A/B: narrow tiles lose, 48..64 and 96-wide ones gain
-    // most; three taps per stage on the half tiles measured no better).  Counting rounds is what keeps small images busy: a
+    // time relative to a full tile at that width (1080p layers, same-box A/B, rounds factored out: 48- and 64-wide layers gain
+    // 10-13 %, 24-wide and 80-wide (5 n-tiles) ones lose 18-50 %, 112-wide ones are even; three taps per stage on the half tiles
+    // measured no better).  Counting rounds is what keeps small images busy: a
     // 36x60 map with 768 channels is 72 workgroups at WN = 8 on 256 CUs, 192 at WN = 3.
     // ATMVFI_CONV3_SCHED=row|half forces a schedule.
     static const int forced = [] { const char* e = getenv("ATMVFI_CONV3_SCHED"); return !e ? -1 : (e[0] == 'h' ? 1 : 0); }();
-    static const float rel[9] = {1.f, 1.08f, 1.21f, 0.84f, 0.90f, 1.04f, 0.95f, 0.97f, 1.00f};
+    static const float rel[9] = {1.f, 1.10f, 1.50f, 0.87f, 0.90f, 1.18f, 1.07f, 1.01f, 1.02f};     // re-measured with the k-step-major weights
     const int ncu = atmvfi::cu_count();
+    // (1) tile width from the padding rule; narrower only if that is what it takes to put a workgroup on every CU
     int best = 1;
-    bool half = false;
     float best_cost = 1e30f;
-    for (int sched = 0; sched < 2; ++sched) {
-        if (forced >= 0 && sched != forced) continue;
-        const long long spatial = (long long)d.N * d.tiles_x * ((d.H + (sched ? 7 : 15)) / (sched ? 8 : 16));
-        const int slots = sched ? 2 * ncu : ncu;
-        for (int wn = 1; wn <= 8; ++wn) {
-            const long long wgs = spatial * ((ntiles + wn - 1) / wn);
-            const float rounds = (float)((wgs + slots - 1) / slots);
-            const float cost = rounds * (float)wn * (1.0f + 1.0f / (float)wn) * (sched ? rel[wn] : 1.0f);
-            if (cost <= best_cost) { best_cost = cost; best = wn; half = sched == 1; }
-        }
+    const long long spatial_row = (long long)d.N * d.tiles_x * ((d.H + 15) / 16);
+    for (int wn = 1; wn <= 8; ++wn) {
+        const int nb = (ntiles + wn - 1) / wn;
+        float cost = (float)(nb * wn) * (1.0f + 1.0f / (float)wn);
+        const long long wgs = spatial_row * nb;
+        if (wgs < ncu) cost *= (float)ncu / (float)wgs;              // under-filled launch: time ~ tile time, not total work
+        if (cost <= best_cost) { best_cost = cost; best = wn; }
     }
+    // (2) schedule at that width: rounds of the launch x measured relative tile time
+    bool half = forced == 1;
+    if (forced < 0) {
+        const int nb = (ntiles + best - 1) / best;
+        const long long t_row = spatial_row * nb;
+        const long long t_half = (long long)d.N * d.tiles_x * ((d.H + 7) / 8) * nb;
+        const float c_row = (float)((t_row + ncu - 1) / ncu);
+        const float c_half = (float)((t_half + 2 * ncu - 1) / (2 * ncu)) * rel[best];
+        half = c_half < c_row;
+    }
+    static const bool verbose = getenv("ATMVFI_CONV3_VERBOSE") != nullptr;
+    if (verbose) fprintf(stderr, "conv3x3 N%d H%d W%d Cin%d Cout%d -> WN %d %s (cost %.2f)\n", d.N, d.H, d.W, d.Cin, d.Cout, best, half ? "half" : "row", best_cost);
 #define ATMVFI_C3_CASE(W) case W: return half ? launch_row<W, 4, 1>(d, ntiles, s) : launch_row<W, 8, 3>(d, ntiles, s);
     switch (best) {
         ATMVFI_C3_CASE(1) ATMVFI_C3_CASE(2) ATMVFI_C3_CASE(3) ATMVFI_C3_CASE(4) ATMVFI_C3_CASE(5) ATMVFI_C3_CASE(6) ATMVFI_C3_CASE(7)

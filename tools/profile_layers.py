@@ -35,7 +35,7 @@ for rep in range(3):
 tot = sum(t for _, _, t in best)
 print(f"total {tot:.2f} ms over {len(best)} launches")
 for n, m, t in best:
-    if t < 0.15: continue
+    if t < float(os.environ.get("ATMVFI_PROFILE_MIN_MS", "0.15")): continue
     tf = m.get("flops", 0) / (t * 1e-3) / 1e12
     gb = m.get("bytes", 0) / (t * 1e-3) / 1e9
     print(f"{n:18s} {m.get('shape', ''):28s} {t:8.3f} ms {tf:7.1f} TF/s {gb:8.1f} GB/s")
