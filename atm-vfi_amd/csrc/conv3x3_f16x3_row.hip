@@ -36,7 +36,7 @@ template <int WN, int NWV, int TAPS>
 __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void conv3x3_f16x3_row_kernel(const Conv3Dev a) {
     constexpr int BN = 16 * WN;
     constexpr int NT = 64 * NWV;
-    constexpr int TH = 2 * NWV, NPIX = HW_ * (TH + 2), HALO_TASKS = NPIX * 4, HALO_TPT = (HALO_TASKS + NT - 1) / NT;
+    constexpr int TH = 2 * NWV, NPIX = HW_ * (TH + 2), HALO_TASKS = NPIX * 8, HALO_TPT = (HALO_TASKS + NT - 1) / NT;
     constexpr int SPC = 9 / TAPS;                       // stages per regular chunk
     extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
     _Float16* halo_hi = smem;                           // [NPIX][32]
@@ -73,7 +73,9 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void conv3x3_f16x3_row_
     const int ox0 = txb * TW, oy0 = tyb * TH;      // TH = 2 * NWV rows per tile
     const int n0 = nblk * BN;
 
-    // ---- halo tasks: T = tid + 512*k -> (halo pixel, 8-channel group) ----
+    // ---- halo tasks: T = tid + NT*k -> (halo pixel T >> 3, 4-channel group T & 7).  Eight lanes cover the 128 contiguous bytes of
+    // one pixel's 32-channel chunk, so a load instruction touches 8 full cache lines (with 4 lanes x 8 channels per pixel and two
+    // loads per task it touched 16 half lines each, which costs about twice as much to issue: tools/probes/dma_probe.hip) ----
     const float* hsrc[HALO_TPT];
     int hdst[HALO_TPT], hq[HALO_TPT];
     bool hok[HALO_TPT], hact[HALO_TPT];
@@ -81,13 +83,13 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void conv3x3_f16x3_row_
     for (int k = 0; k < HALO_TPT; ++k) {
         const int T = tid + NT * k;
         hact[k] = T < HALO_TASKS;
-        const int hp = hact[k] ? (T >> 2) : 0;
-        const int q = T & 3;
+        const int hp = hact[k] ? (T >> 3) : 0;
+        const int q = T & 7;
         const int hy = hp / HW_, hx = hp - hy * HW_;
         const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
         hok[k] = hact[k] && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-        hsrc[k] = a.in + (((long long)img * a.H + (hok[k] ? iy : 0)) * a.W + (hok[k] ? ix : 0)) * a.in_ld + q * 8;
-        hdst[k] = hp * 32 + ((q ^ swz64(hp)) << 3);
+        hsrc[k] = a.in + (((long long)img * a.H + (hok[k] ? iy : 0)) * a.W + (hok[k] ? ix : 0)) * a.in_ld + q * 4;
+        hdst[k] = hp * 32 + (((q >> 1) ^ swz64(hp)) << 3) + (q & 1) * 4;
         hq[k] = q;
     }
     // ---- weights by LDS-DMA: the fp16 planes go global -> LDS without touching registers.  The planes are k-step major
@@ -128,39 +130,37 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void conv3x3_f16x3_row_
     const int nchunks = nfull + (a.tail ? 1 : 0);
     const int nstages = nfull * SPC + (a.tail ? 3 / TAPS : 0);
 
-    f32x4 hr[HALO_TPT][2];
+    f32x4 hr[HALO_TPT];
     int hnv[HALO_TPT];
 
     auto halo_load = [&](int k, int chunk) {
         // Unconditional loads from a clamped, always-valid address, zeroed afterwards by selects: a
         // predicated load makes hipcc branch around it and wait vmcnt(0) on the spot, which serialises
         // the whole prefetch (seen in the ISA; cdna_hip_programming.md "Three .s-level traps" (c)).
-        const int c = chunk * 32 + hq[k] * 8;
+        const int c = chunk * 32 + hq[k] * 4;
         const bool ok = hok[k] && c < a.Cin;
-        const int nv = ok ? a.Cin - c : 0;                       // valid channels in this group of 8
-        const float* p = ok ? hsrc[k] + chunk * 32 : a.in;       // masked lanes read the tensor base: hsrc[k] + q*8 may lie past a narrow last pixel
-        const f32x4 va = *reinterpret_cast<const f32x4*>(p);
-        const f32x4 vb = *reinterpret_cast<const f32x4*>(p + (nv > 4 ? 4 : 0));
-        hnv[k] = nv;                                             // masking happens at store time: no early consumer
-        hr[k][0] = va;
-        hr[k][1] = vb;
+        hnv[k] = ok ? a.Cin - c : 0;                             // valid channels in this group of 4; masking happens at store time
+        const float* p = ok ? hsrc[k] + chunk * 32 : a.in;       // masked lanes read the tensor base
+        hr[k] = *reinterpret_cast<const f32x4*>(p);
     };
     auto halo_store = [&](int k) {
         if (hact[k]) {
-            f16x8 hi, lo;
-            f32x4 va = hr[k][0], vb = hr[k][1];
+            f32x4 v = hr[k];
             const int nv = hnv[k];
-            va.x = nv > 0 ? va.x : 0.f;
-            va.y = nv > 1 ? va.y : 0.f;
-            va.z = nv > 2 ? va.z : 0.f;
-            va.w = nv > 3 ? va.w : 0.f;
-            vb.x = nv > 4 ? vb.x : 0.f;
-            vb.y = nv > 5 ? vb.y : 0.f;
-            vb.z = nv > 6 ? vb.z : 0.f;
-            vb.w = nv > 7 ? vb.w : 0.f;
-            split8(va, vb, hi, lo);
-            *reinterpret_cast<f16x8*>(halo_hi + hdst[k]) = hi;
-            *reinterpret_cast<f16x8*>(halo_lo + hdst[k]) = lo;
+            v.x = nv > 0 ? v.x : 0.f;
+            v.y = nv > 1 ? v.y : 0.f;
+            v.z = nv > 2 ? v.z : 0.f;
+            v.w = nv > 3 ? v.w : 0.f;
+            const float x[4] = {v.x, v.y, v.z, v.w};
+            f16x4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const _Float16 h = sat_half(x[e]);
+                hi[e] = h;
+                lo[e] = sat_half((x[e] - (float)h) * LO_SCALE);
+            }
+            *reinterpret_cast<f16x4*>(halo_hi + hdst[k]) = hi;
+            *reinterpret_cast<f16x4*>(halo_lo + hdst[k]) = lo;
         }
     };
     // stage -> (chunk, first k-step q0): regular chunks have 9 k-steps (tap q), the tail chunk 3; k-step q of chunk c is the
