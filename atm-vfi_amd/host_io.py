@@ -75,8 +75,9 @@ class FramePipeline:
     ``depth`` slots of pinned host buffers and device staging; slot i+1's host->device copy and slot i-1's device->host copy run
     on their own streams under slot i's forward.  Per pair over PCIe: 2 * H*W*3 bytes in, H*W*3 bytes out (uint8, 4x less than the
     fp32 tensors the reference moves).  ``run`` yields frames in order; a yielded array is a fresh copy.  Measured at 1080p on one
-    MI355X (tools/bench_hostio.py): 26.0 ms resident, 35.4 / 31.8 / 28.4 ms per frame at depth 1 / 2 / 3 -- the pieces themselves are
-    small (H2D 0.7 ms, enqueue 2.2 ms, pre/post kernels < 0.1 ms); what depth buys is a GPU queue that never runs dry."""
+    MI355X (tools/bench_hostio.py, tools/diag_hostio.py): 25.0 ms resident, 26.9 ms per frame at depth 1 and 25.2 ms at depth 3 -- the
+    pieces are small (H2D 1.0 ms, enqueue 2.8 ms of CPU, pre/post kernels < 0.1 ms) and at depth 3 the GPU queue never runs dry
+    (gap between consecutive forwards 0.03 ms)."""
 
     def __init__(self, model, height: int, width: int, isBGR: bool = True, divisor: int = 64, depth: int = 3):
         ops, dev = _hip_ops_of(model)
@@ -95,14 +96,18 @@ class FramePipeline:
             "f0": mk(1, 3, self.hp, self.wp, dt=torch.float32), "f1": mk(1, 3, self.hp, self.wp, dt=torch.float32),
             "in_ready": torch.cuda.Event(), "done": torch.cuda.Event(), "out_ready": torch.cuda.Event(),
         } for _ in range(self.depth)]
+        for slot in self.slots:
+            slot["h_in_np"] = slot["h_in"].numpy()
         self.copy_in, self.copy_out = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
 
     def _upload(self, slot, pair):
         a, b = pair
         if a.shape != (self.h, self.w, 3) or b.shape != (self.h, self.w, 3) or a.dtype != np.uint8 or b.dtype != np.uint8:
             raise ValueError(f"FramePipeline: expected two uint8 [{self.h},{self.w},3] frames")
-        slot["h_in"][0].copy_(torch.from_numpy(np.ascontiguousarray(a)))
-        slot["h_in"][1].copy_(torch.from_numpy(np.ascontiguousarray(b)))
+        # numpy's single-threaded memcpy, not Tensor.copy_: ATen spreads a 6 MB copy over every core it sees (128 threads on the
+        # GPU box), which trips the container's CPU quota and stalls the enqueueing thread for tens of ms (tools/diag_hostio.py)
+        np.copyto(slot["h_in_np"][0], a)
+        np.copyto(slot["h_in_np"][1], b)
         with torch.cuda.stream(self.copy_in):
             slot["d_in"].copy_(slot["h_in"], non_blocking=True)
             slot["in_ready"].record(self.copy_in)
