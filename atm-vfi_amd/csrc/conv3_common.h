@@ -43,12 +43,64 @@ constexpr float LO_UNSCALE = 1.0f / 1024.0f;
 __device__ __forceinline__ _Float16 sat_half(float v) { return (_Float16)fminf(fmaxf(v, -65504.0f), 65504.0f); }
 
 __device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, f16x8& hi, f16x8& lo) {
-    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    const f32x2 x[4] = {{a.x, a.y}, {a.z, a.w}, {b.x, b.y}, {b.z, b.w}};
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const _Float16 h = sat_half(x[e]);
-        hi[e] = h;
-        lo[e] = sat_half((x[e] - (float)h) * LO_SCALE);
+    for (int e = 0; e < 4; ++e) {
+        f16x2 h, l;
+        split_pair(x[e], h, l);
+        hi[2 * e] = h.x;
+        hi[2 * e + 1] = h.y;
+        lo[2 * e] = l.x;
+        lo[2 * e + 1] = l.y;
     }
 }
 
+// ---- fragment reads under manual wait counts (conv3x3_f16x3_row.hip explains why) ----
+#include <type_traits>
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+// 32-bit LDS offset of a pointer into __shared__ memory (the low half of the flat address)
+__device__ __forceinline__ unsigned lds_offset(const void* p) { return (unsigned)(unsigned long long)p; }
+template <int OFF>
+__device__ __forceinline__ void lds_read16(f16x8& d, unsigned addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field is 16 bits");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");     // "memory": stays behind the barrier / ds_writes that publish the data
+}
+// s_waitcnt lgkmcnt(N), tied to the registers it makes valid so that their consumers cannot be scheduled above it
+template <int N>
+__device__ __forceinline__ void lds_wait2(f16x8& a, f16x8& b) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void lds_wait4(f16x8& a, f16x8& b, f16x8& c, f16x8& d) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
+// Issue order of one stage's fragment reads and the wait each group needs.  Groups n = 0 .. NG-1 = (k-step n / WN, n-tile n % WN).
+// Stage start: X(0) [4 reads], W(0) [2], W(1) [2].  Group n, before its MFMAs: W(n+2) [2], then (DX: two activation register sets)
+// X(t+1) [4] if n % WN == JX; with one set (the 8-tile kernel has no 16 registers to spare) X(t+1) goes out right AFTER the MFMAs
+// of the k-step's last group.  LDS returns in order, so wait(n) = number of reads issued after the youngest one group n consumes.
+template <int WN, int TAPS, bool DX>
+struct FragPipe {
+    static constexpr int NG = TAPS * WN;
+    static constexpr int JX = !DX ? WN - 1 : (WN >= 3 ? WN - 3 : 0);
+    static constexpr int w_off(int n, int BN) { return ((n / WN) * BN + (n % WN) * 16) * 32 * 2; }      // bytes from the stage's hi plane
+    static constexpr int wait(int n) {
+        int issued = 4, seq_x[TAPS + 1] = {}, seq_w[NG + 3] = {};
+        seq_x[0] = issued;
+        for (int k = 0; k < 2 && k < NG; ++k) { issued += 2; seq_w[k] = issued; }
+        for (int m = 0; m <= n; ++m) {
+            if (m + 2 < NG) { issued += 2; seq_w[m + 2] = issued; }
+            const bool x_here = m % WN == JX && m / WN + 1 < TAPS;
+            if (x_here && DX) { issued += 4; seq_x[m / WN + 1] = issued; }
+            if (m == n) break;
+            if (x_here && !DX) { issued += 4; seq_x[m / WN + 1] = issued; }
+        }
+        const int need = seq_w[n] > seq_x[n / WN] ? seq_w[n] : seq_x[n / WN];
+        return issued - need;
+    }
+};

@@ -26,6 +26,14 @@ extern "C" void atmvfi_debug_set_stamp_buffer(void* p) { g_stamp_buf = (unsigned
 #define STAMP(k)
 #endif
 
+// Diagnostic build only (`make ablate`, never the product): ATMVFI_LEGACY_ORDER bits switch pieces of the kernel off (results are
+// then wrong) to price them: 2 weight DMA after the prologue, 4 halo reloads, 8 halo convert + write, 16 epilogue stores.
+#ifdef ATMVFI_ABLATE
+#define ABL(bit) ((a.legacy_order & (bit)) != 0)
+#else
+#define ABL(bit) false
+#endif
+
 namespace {
 
 // NWV wavefronts per workgroup (output tile 16 x 2*NWV pixels), TAPS k-steps per stage:
@@ -44,6 +52,8 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void conv3x3_f16x3_row_
     _Float16* b_hi = halo_lo + NPIX * 32;               // [2][TAPS][BN][32]
     _Float16* b_lo = b_hi + 2 * TAPS * BN * 32;
     float* cst = reinterpret_cast<float*>(b_lo + 2 * TAPS * BN * 32);  // bias / PReLU slopes of this column block (common.h)
+
+    const unsigned halo_base = lds_offset(halo_hi), w_base = lds_offset(b_hi);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -147,18 +157,14 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void conv3x3_f16x3_row_
         if (hact[k]) {
             f32x4 v = hr[k];
             const int nv = hnv[k];
-            v.x = nv > 0 ? v.x : 0.f;
-            v.y = nv > 1 ? v.y : 0.f;
-            v.z = nv > 2 ? v.z : 0.f;
+            v.x = nv > 0 ? v.x : 0.f;          // (a wave-uniform branch around the selects makes hipcc wait vmcnt(0) before the
+            v.y = nv > 1 ? v.y : 0.f;          //  first task instead of converting each task as its load arrives: +55 % on the
+            v.z = nv > 2 ? v.z : 0.f;          //  24-channel full-resolution layer)
             v.w = nv > 3 ? v.w : 0.f;
-            const float x[4] = {v.x, v.y, v.z, v.w};
-            f16x4 hi, lo;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const _Float16 h = sat_half(x[e]);
-                hi[e] = h;
-                lo[e] = sat_half((x[e] - (float)h) * LO_SCALE);
-            }
+            f16x2 h0, l0, h1, l1;
+            split_pair((f32x2){v.x, v.y}, h0, l0);
+            split_pair((f32x2){v.z, v.w}, h1, l1);
+            const f16x4 hi = {h0.x, h0.y, h1.x, h1.y}, lo = {l0.x, l0.y, l1.x, l1.y};
             *reinterpret_cast<f16x4*>(halo_hi + hdst[k]) = hi;
             *reinterpret_cast<f16x4*>(halo_lo + hdst[k]) = lo;
         }
@@ -211,54 +217,97 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void conv3x3_f16x3_row_
         const bool more_w = (s + 1) < nstages;
         const bool next_halo = !tail_stage && (q0 + TAPS == 9) && (chunk + 1 < nchunks);      // last stage of a regular chunk
         STAMP(7)
-        if (more_w) w_dma(s + 1, wb ^ 1);       // that buffer was last read in stage s-1: everyone has passed its barrier
-        if (next_halo) {
+        if (more_w && !ABL(2)) w_dma(s + 1, wb ^ 1);       // that buffer was last read in stage s-1: everyone has passed its barrier
+        if (next_halo && !ABL(4)) {
 #pragma unroll
             for (int k = 0; k < HALO_TPT; ++k) halo_load(k, chunk + 1);
         }
         STAMP(1)
-#pragma unroll
-        for (int t = 0; t < TAPS; ++t) {
-            const int q = q0 + t;                        // k-step: tap q of a regular chunk, step q of the tail
-            f16x8 xh[2], xl[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                // regular stage: tap (ky, t), lane group g reads channel slot g.  Tail stage: k = (tap 4t+g, tail channels
-                // 0..7), lane group g reads slot 0 of ITS tap's pixel (selects on a uniform flag: no branch in this loop)
-                const int p = (2 * wave + i) * HW_ + r + (tail_stage ? ((dt >> (8 * q)) & 0xff) : (q / 3) * HW_ + q % 3);
-                const int sl = tail_stage ? 0 : g;
-                const int off = p * 32 + ((sl ^ swz64(p)) << 3);
-                xh[i] = *reinterpret_cast<const f16x8*>(halo_hi + off);
-                xl[i] = *reinterpret_cast<const f16x8*>(halo_lo + off);
-            }
-            const int wbase = (wb * TAPS + t) * BN * 32 + r * 32 + ((g ^ swz64(r)) << 3);  // swz64(16j + r) == swz64(r)
-            // weight fragments ping-pong between two statically indexed register sets (j is a compile-time
-            // constant after unrolling): the next n-tile is fetched before this tile's MFMAs, without copies
-            // weight fragments run two n-tiles ahead of the MFMAs (3-slot ring, static indices) and the order is
-            // pinned per tile: left alone, the scheduler folds the ring into one register, hoists the next tile's
-            // MFMAs behind its just-issued ds_read and stalls on it (lgkmcnt(1)) every 6 MFMAs
-            f16x8 wh[3], wl[3];
-            wh[0] = *reinterpret_cast<const f16x8*>(b_hi + wbase);
-            wl[0] = *reinterpret_cast<const f16x8*>(b_lo + wbase);
-            if (WN > 1) {
-                wh[1] = *reinterpret_cast<const f16x8*>(b_hi + wbase + 16 * 32);
-                wl[1] = *reinterpret_cast<const f16x8*>(b_lo + wbase + 16 * 32);
-            }
-#pragma unroll
-            for (int j = 0; j < WN; ++j) {
-                if (j + 2 < WN) {
-                    wh[(j + 2) % 3] = *reinterpret_cast<const f16x8*>(b_hi + wbase + (j + 2) * 16 * 32);
-                    wl[(j + 2) % 3] = *reinterpret_cast<const f16x8*>(b_lo + wbase + (j + 2) * 16 * 32);
+        // One stage = TAPS k-steps x WN n-tiles = NG groups of six MFMAs, run as ONE software pipeline: the weight fragments of
+        // group n+2 (3-slot ring) and the activation fragments of the next k-step (second register set) are requested before
+        // the MFMAs of group n, and the wait in front of a group leaves the younger reads in flight (lgkmcnt(2..8), FragPipe).
+        // hipcc cannot be brought to do this: whatever the source order, it puts s_waitcnt lgkmcnt(0) in front of the first MFMA
+        // that needs a fragment, so every k-step drained the LDS queue ~3 times with all 8 waves asking at once, and the kernel
+        // ran at LDS time PLUS MFMA time (ablation build: 0.75 ms of a 1.08 ms layer with the MFMAs removed).  The reads and
+        // waits are therefore inline asm, invisible to the compiler's counter model; every read is waited for inside the stage.
+        if constexpr (WN >= 3) {
+            constexpr bool DX = !(WN == 8 && NWV == 8);        // two activation-fragment sets wherever the registers allow
+            using P = FragPipe<WN, TAPS, DX>;
+            f16x8 xh[DX ? 2 : 1][2], xl[DX ? 2 : 1][2], wh[3], wl[3];
+            auto load_x = [&](int t, int set) {
+                const int q = q0 + t;                        // k-step: tap q of a regular chunk, step q of the tail
+    #pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    // regular stage: tap (ky, t), lane group g reads channel slot g.  Tail stage: k = (tap 4t+g, tail channels
+                    // 0..7), lane group g reads slot 0 of ITS tap's pixel (selects on a uniform flag: no branch in this loop)
+                    const int p = (2 * wave + i) * HW_ + r + (tail_stage ? ((dt >> (8 * q)) & 0xff) : (q / 3) * HW_ + q % 3);
+                    const int sl = tail_stage ? 0 : g;
+                    const unsigned addr = halo_base + 2u * (unsigned)(p * 32 + ((sl ^ swz64(p)) << 3));
+                    lds_read16<0>(xh[set][i], addr);
+                    lds_read16<NPIX * 32 * 2>(xl[set][i], addr);
                 }
-                const f16x8 ch = wh[j % 3], cl = wl[j % 3];
+            };
+            const unsigned waddr = w_base + 2u * (unsigned)(wb * TAPS * BN * 32 + r * 32 + ((g ^ swz64(r)) << 3));   // swz64(16j + r) == swz64(r)
+            const unsigned waddr_lo = waddr + 2u * (2 * TAPS * BN * 32);      // the lo planes (the 16-bit offset field does not reach them)
+            load_x(0, 0);
+            static_for<0, (P::NG < 2 ? P::NG : 2)>([&](auto nc) {
+                constexpr int n = decltype(nc)::value;
+                lds_read16<P::w_off(n, BN)>(wh[n % 3], waddr);
+                lds_read16<P::w_off(n, BN)>(wl[n % 3], waddr_lo);
+            });
+            static_for<0, P::NG>([&](auto nc) {
+                constexpr int n = decltype(nc)::value;
+                constexpr int t = n / WN, j = n % WN;
+                if constexpr (n + 2 < P::NG) {
+                    lds_read16<P::w_off(n + 2, BN)>(wh[(n + 2) % 3], waddr);
+                    lds_read16<P::w_off(n + 2, BN)>(wl[(n + 2) % 3], waddr_lo);
+                }
+                constexpr int xs = DX ? (t & 1) : 0;
+                if constexpr (DX && j == P::JX && t + 1 < TAPS) load_x(t + 1, (t + 1) & 1);
+                if constexpr (j == 0) lds_wait4<P::wait(n)>(xh[xs][0], xh[xs][1], xl[xs][0], xl[xs][1]);
+                lds_wait2<P::wait(n)>(wh[n % 3], wl[n % 3]);
+                const f16x8 ch = wh[n % 3], cl = wl[n % 3];
+                const f16x8 h0 = xh[xs][0], h1 = xh[xs][1], l0 = xl[xs][0], l1 = xl[xs][1];
                 // dependent MFMAs (same accumulator) are kept 4 issues apart
-                cor[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cl, xh[0], cor[0][j], 0, 0, 0);
-                cor[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cl, xh[1], cor[1][j], 0, 0, 0);
-                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, xh[0], acc[0][j], 0, 0, 0);
-                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, xh[1], acc[1][j], 0, 0, 0);
-                cor[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, xl[0], cor[0][j], 0, 0, 0);
-                cor[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, xl[1], cor[1][j], 0, 0, 0);
+                cor[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cl, h0, cor[0][j], 0, 0, 0);
+                cor[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cl, h1, cor[1][j], 0, 0, 0);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, h0, acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, h1, acc[1][j], 0, 0, 0);
+                cor[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, l0, cor[0][j], 0, 0, 0);
+                cor[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, l1, cor[1][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (!DX && j == P::JX && t + 1 < TAPS) {
+                    load_x(t + 1, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+        } else {
+            // narrow tiles (1-2 n-tiles: 3- to 48-channel layers, bound by HBM and the halo staging, not by the MFMA loop): the
+            // compiler-scheduled form, which measured 35 % faster there than the pinned pipeline
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) {
+                const int q = q0 + t;
+                f16x8 xh[2], xl[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int p = (2 * wave + i) * HW_ + r + (tail_stage ? ((dt >> (8 * q)) & 0xff) : (q / 3) * HW_ + q % 3);
+                    const int sl = tail_stage ? 0 : g;
+                    const int off = p * 32 + ((sl ^ swz64(p)) << 3);
+                    xh[i] = *reinterpret_cast<const f16x8*>(halo_hi + off);
+                    xl[i] = *reinterpret_cast<const f16x8*>(halo_lo + off);
+                }
+                const int wbase = (wb * TAPS + t) * BN * 32 + r * 32 + ((g ^ swz64(r)) << 3);
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    const f16x8 ch = *reinterpret_cast<const f16x8*>(b_hi + wbase + j * 16 * 32);
+                    const f16x8 cl = *reinterpret_cast<const f16x8*>(b_lo + wbase + j * 16 * 32);
+                    cor[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cl, xh[0], cor[0][j], 0, 0, 0);
+                    cor[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cl, xh[1], cor[1][j], 0, 0, 0);
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, xh[0], acc[0][j], 0, 0, 0);
+                    acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, xh[1], acc[1][j], 0, 0, 0);
+                    cor[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, xl[0], cor[0][j], 0, 0, 0);
+                    cor[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, xl[1], cor[1][j], 0, 0, 0);
+                }
             }
         }
         STAMP(2)
@@ -266,7 +315,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void conv3x3_f16x3_row_
         STAMP(3)
         __syncthreads();
         STAMP(4)
-        if (next_halo) {        // every wave has finished reading the old halo
+        if (next_halo && !ABL(8)) {        // every wave has finished reading the old halo
 #pragma unroll
             for (int k = 0; k < HALO_TPT; ++k) halo_store(k);
             __syncthreads();
@@ -298,7 +347,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void conv3x3_f16x3_row_
             v.y = v.y > 0.f ? v.y : pv.y * v.y;
             v.z = v.z > 0.f ? v.z : pv.z * v.z;
             v.w = v.w > 0.f ? v.w : pv.w * v.w;
-            if (live[i]) {
+            if (live[i] && !ABL(16)) {
                 if (nvalid >= 4) {
                     *reinterpret_cast<f32x4*>(orow[i] + co) = v;
                 } else if (nvalid > 0) {

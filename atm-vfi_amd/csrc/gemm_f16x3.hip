@@ -30,18 +30,19 @@ namespace {
 
 using atmvfi::GemmDev;
 
-constexpr float LO_SCALE = 1024.0f;
 constexpr float LO_UNSCALE = 1.0f / 1024.0f;
-__device__ __forceinline__ _Float16 sat_half(float v) { return (_Float16)fminf(fmaxf(v, -65504.0f), 65504.0f); }
 __device__ __forceinline__ int swz64(int row) { return ((row >> 2) & 1) << 1; }
 
 __device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, f16x8& hi, f16x8& lo) {
-    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    const f32x2 x[4] = {{a.x, a.y}, {a.z, a.w}, {b.x, b.y}, {b.z, b.w}};
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const _Float16 h = sat_half(x[e]);
-        hi[e] = h;
-        lo[e] = sat_half((x[e] - (float)h) * LO_SCALE);
+    for (int e = 0; e < 4; ++e) {
+        f16x2 h, l;
+        split_pair(x[e], h, l);
+        hi[2 * e] = h.x;
+        hi[2 * e + 1] = h.y;
+        lo[2 * e] = l.x;
+        lo[2 * e + 1] = l.y;
     }
 }
 
@@ -187,14 +188,16 @@ __global__ __launch_bounds__(512) void gemm_f16x3_kernel(const GemmDev a) {
             f16x8 hi, lo;
             f32x4 va = ra[i][0], vb = ra[i][1];
             const int nv = anv[i];
-            va.x = nv > 0 ? va.x : 0.f;
-            va.y = nv > 1 ? va.y : 0.f;
-            va.z = nv > 2 ? va.z : 0.f;
-            va.w = nv > 3 ? va.w : 0.f;
-            vb.x = nv > 4 ? vb.x : 0.f;
-            vb.y = nv > 5 ? vb.y : 0.f;
-            vb.z = nv > 6 ? vb.z : 0.f;
-            vb.w = nv > 7 ? vb.w : 0.f;
+            if (__builtin_amdgcn_ballot_w64(nv < 8)) {          // K tail, rows past M, padding taps: most waves skip the selects
+                va.x = nv > 0 ? va.x : 0.f;
+                va.y = nv > 1 ? va.y : 0.f;
+                va.z = nv > 2 ? va.z : 0.f;
+                va.w = nv > 3 ? va.w : 0.f;
+                vb.x = nv > 4 ? vb.x : 0.f;
+                vb.y = nv > 5 ? vb.y : 0.f;
+                vb.z = nv > 6 ? vb.z : 0.f;
+                vb.w = nv > 7 ? vb.w : 0.f;
+            }
             if (a.in_prelu) {
                 const f32x4 al = rp[i][0], bl = rp[i][1];
                 va.x = va.x > 0.f ? va.x : al.x * va.x;

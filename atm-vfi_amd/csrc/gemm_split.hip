@@ -292,13 +292,19 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
         for (int e = 0; e < 8; ++e) x[e] = (c0 + e < C) ? p[e] : 0.f;
     }
     f16x8 h, l;
+    if (prelu) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        float v = x[e];
-        if (prelu && c0 + e < C) v = v > 0.f ? v : prelu[c0 + e] * v;
-        const _Float16 hh = (_Float16)fminf(fmaxf(v, -65504.0f), 65504.0f);
-        h[e] = hh;
-        l[e] = (_Float16)fminf(fmaxf((v - (float)hh) * 1024.0f, -65504.0f), 65504.0f);
+        for (int e = 0; e < 8; ++e)
+            if (c0 + e < C) x[e] = x[e] > 0.f ? x[e] : prelu[c0 + e] * x[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        f16x2 hh, ll;
+        split_pair((f32x2){x[2 * e], x[2 * e + 1]}, hh, ll);
+        h[2 * e] = hh.x;
+        h[2 * e + 1] = hh.y;
+        l[2 * e] = ll.x;
+        l[2 * e + 1] = ll.y;
     }
     const long long off = ((long long)(c0 >> 5) * plane_rows + m) * 32 + (c0 & 31);
     *reinterpret_cast<f16x8*>(hi + off) = h;
