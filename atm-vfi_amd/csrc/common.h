@@ -4,6 +4,7 @@
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <type_traits>
 
 #include "atmvfi.h"
 
@@ -105,6 +106,32 @@ __device__ __forceinline__ void dma_epilogue_consts(const float* bias, const flo
     const float* p = (src && co >= 0) ? src + co : &kEpilogueDefaults[sl ? 1 : 0];
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
                                      (__attribute__((address_space(3))) void*)(cst + piece * 64), 4, 0, 0);
+}
+
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+// ---- fragment reads under manual wait counts (conv3x3_f16x3_row.hip explains why; also gemm_split.hip) ----
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+// 32-bit LDS offset of a pointer into __shared__ memory (the low half of the flat address)
+__device__ __forceinline__ unsigned lds_offset(const void* p) { return (unsigned)(unsigned long long)p; }
+template <int OFF>
+__device__ __forceinline__ void lds_read16(f16x8_t& d, unsigned addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field is 16 bits");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");     // "memory": stays behind the barrier / ds_writes that publish the data
+}
+// s_waitcnt lgkmcnt(N), tied to the registers it makes valid so that their consumers cannot be scheduled above it
+template <int N>
+__device__ __forceinline__ void lds_wait2(f16x8_t& a, f16x8_t& b) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void lds_wait4(f16x8_t& a, f16x8_t& b, f16x8_t& c, f16x8_t& d) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
 }
 
 // exact GELU (erf form), as nn.GELU() default

@@ -55,31 +55,6 @@ __device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, f16x8& hi, 
     }
 }
 
-// ---- fragment reads under manual wait counts (conv3x3_f16x3_row.hip explains why) ----
-#include <type_traits>
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-// 32-bit LDS offset of a pointer into __shared__ memory (the low half of the flat address)
-__device__ __forceinline__ unsigned lds_offset(const void* p) { return (unsigned)(unsigned long long)p; }
-template <int OFF>
-__device__ __forceinline__ void lds_read16(f16x8& d, unsigned addr) {
-    static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field is 16 bits");
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");     // "memory": stays behind the barrier / ds_writes that publish the data
-}
-// s_waitcnt lgkmcnt(N), tied to the registers it makes valid so that their consumers cannot be scheduled above it
-template <int N>
-__device__ __forceinline__ void lds_wait2(f16x8& a, f16x8& b) {
-    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
-}
-template <int N>
-__device__ __forceinline__ void lds_wait4(f16x8& a, f16x8& b, f16x8& c, f16x8& d) {
-    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
-}
 // Issue order of one stage's fragment reads and the wait each group needs.  Groups n = 0 .. NG-1 = (k-step n / WN, n-tile n % WN).
 // Stage start: X(0) [4 reads], W(0) [2], W(1) [2].  Group n, before its MFMAs: W(n+2) [2], then (DX: two activation register sets)
 // X(t+1) [4] if n % WN == JX; with one set (the 8-tile kernel has no 16 registers to spare) X(t+1) goes out right AFTER the MFMAs

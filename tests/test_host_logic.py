@@ -210,3 +210,17 @@ def test_checkpoint_wire_format_and_tta_helpers(tmp_path, nets):
     assert host_io.psnr(torch.zeros(4), torch.zeros(4)) == float("inf")
     assert abs(host_io.psnr(torch.zeros(100), torch.full((100,), 0.1)) - 20.0) < 1e-5      # 0.1 is a float32 here
     m.global_motion = True
+
+
+def test_isa_of_counted_lds_waits():
+    """The 3x3 kernel reads its MFMA fragments by inline asm under hand-counted s_waitcnt lgkmcnt(N): that is only sound while no
+    scalar memory load (same counter, out-of-order return) sits inside a stage's MFMA stream and the stage drains to lgkmcnt(0).
+    tools/check_isa.py compiles the kernel to gfx950 assembly and checks exactly that (hipcc cross-compiles without a GPU)."""
+    import shutil
+    import subprocess
+    import sys
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_isa.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
