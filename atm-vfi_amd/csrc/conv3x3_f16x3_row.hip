@@ -34,6 +34,17 @@ extern "C" void atmvfi_debug_set_stamp_buffer(void* p) { g_stamp_buf = (unsigned
 #define ABL(bit) false
 #endif
 
+// Override for tests and A/B runs (atmvfi_conv3x3_set_schedule): schedule -1 = cost model (default), 0 = row, 1 = half;
+// wn 0 = cost model, 1..8 = n-tiles per workgroup.
+static int g_conv3_schedule = -1, g_conv3_wn = 0;
+extern "C" int atmvfi_conv3x3_set_schedule(int schedule, int wn) {
+    ATMVFI_REQUIRE(schedule >= -1 && schedule <= 1, ATMVFI_EINVAL, "conv3x3_set_schedule: schedule -1 (auto), 0 (row) or 1 (half), got %d", schedule);
+    ATMVFI_REQUIRE(wn >= 0 && wn <= 8, ATMVFI_EINVAL, "conv3x3_set_schedule: wn 0 (auto) or 1..8, got %d", wn);
+    g_conv3_schedule = schedule;
+    g_conv3_wn = wn;
+    return 0;
+}
+
 namespace {
 
 // NWV wavefronts per workgroup (output tile 16 x 2*NWV pixels), TAPS k-steps per stage:
@@ -411,7 +422,8 @@ int atmvfi::launch_conv3x3_row(const Conv3Dev& d, int ntiles, hipStream_t s) {
     // measured no better).  Counting rounds is what keeps small images busy: a
     // 36x60 map with 768 channels is 72 workgroups at WN = 8 on 256 CUs, 192 at WN = 3.
     // ATMVFI_CONV3_SCHED=row|half forces a schedule.
-    static const int forced = [] { const char* e = getenv("ATMVFI_CONV3_SCHED"); return !e ? -1 : (e[0] == 'h' ? 1 : 0); }();
+    static const int env_forced = [] { const char* e = getenv("ATMVFI_CONV3_SCHED"); return !e ? -1 : (e[0] == 'h' ? 1 : 0); }();
+    const int forced = g_conv3_schedule >= 0 ? g_conv3_schedule : env_forced;
     static const float rel[9] = {1.f, 1.10f, 1.50f, 0.87f, 0.90f, 1.18f, 1.07f, 1.01f, 1.02f};     // re-measured with the k-step-major weights
     const int ncu = atmvfi::cu_count();
     // (1) tile width from the padding rule; narrower only if that is what it takes to put a workgroup on every CU
@@ -425,6 +437,7 @@ int atmvfi::launch_conv3x3_row(const Conv3Dev& d, int ntiles, hipStream_t s) {
         if (wgs < ncu) cost *= (float)ncu / (float)wgs;              // under-filled launch: time ~ tile time, not total work
         if (cost <= best_cost) { best_cost = cost; best = wn; }
     }
+    if (g_conv3_wn > 0) best = g_conv3_wn;
     // (2) schedule at that width: rounds of the launch x measured relative tile time
     bool half = forced == 1;
     if (forced < 0) {

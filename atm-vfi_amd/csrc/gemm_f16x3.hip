@@ -108,7 +108,7 @@ __global__ __launch_bounds__(512) void gemm_f16x3_kernel(const GemmDev a) {
             const long long mm = rok[i] ? m : 0;
             if (a.mode == ATMVFI_GEMM_CONV) {
                 const int hw = a.Ho * a.Wo;
-                const int n = (int)(mm / hw);
+                const int n = (mm >> 31) ? (int)(mm / hw) : (int)((unsigned)mm / (unsigned)hw);
                 const int rem = (int)(mm - (long long)n * hw);
                 const int oy = rem / a.Wo;
                 const int ox = rem - oy * a.Wo;

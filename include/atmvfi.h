@@ -138,6 +138,12 @@ int64_t atmvfi_conv3x3_weight_halves(int Cout, int Cin);
 int atmvfi_pack_weight_conv3x3(const float* src, void* dst_hi, void* dst_lo, int Cout, int Cin, void* stream);
 int atmvfi_conv3x3_f16x3(const float* in, int in_ld, int N, int H, int W, int Cin, const void* w_hi, const void* w_lo,
                          int Cout, float* out, int out_ld, const float* bias, const float* prelu, void* stream);
+/* The 3x3 kernel has two schedules (512-thread 16x16 tiles, one workgroup per CU; 256-thread 16x8 tiles, two per CU) and 1..8
+ * n-tiles of 16 output channels per workgroup, picked per layer from a cost model.  This process-wide override exists for the
+ * parity tests, which must reach every instance of the kernel, and for same-box A/B timing: schedule -1 = cost model (default),
+ * 0 = row, 1 = half; wn 0 = cost model, 1..8 = n-tiles per workgroup.  Not thread-safe against concurrent launches; results do
+ * not depend on either choice. */
+int atmvfi_conv3x3_set_schedule(int schedule, int wn);
 
 /* ------------------------------------------------------------------------------------
  * LayerNorm over the channel axis of token rows (eps 1e-5, affine), optional gather.

@@ -620,3 +620,34 @@ def test_deconv_from_split_planes(hip, cpu, dev):
     ref = torch.nn.functional.conv_transpose2d(xa.permute(0, 3, 1, 2).double(), wt.double(), bias.double(), stride=2)
     ref = torch.where(ref > 0, ref, ref * slope.double()[None, :, None, None]).permute(0, 2, 3, 1)
     assert (y1[..., :cout].double() - ref).abs().max().item() <= 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("schedule", [0, 1], ids=["row", "half"])
+def test_conv3x3_every_kernel_instance(schedule, hip, cpu, dev):
+    """All 16 instances of the 3x3 kernel (1..8 n-tiles x row / half schedule; from 3 n-tiles on the fragment reads run under
+    hand-counted LDS waits, 7-8 tiles of the row schedule with a single activation register set): ragged image, two images,
+    a channel count with a tap-packed tail and one without, against the CPU restatement."""
+    g = torch.Generator().manual_seed(4242 + schedule)
+    r4 = lambda c: (c + 3) // 4 * 4
+    try:
+        for wn in range(1, 9):
+            assert hip.lib.atmvfi_conv3x3_set_schedule(schedule, wn) == 0
+            for cin in (37, 64):
+                cout = 2 * 16 * wn - (5 if wn % 2 else 0)            # two column blocks, the second one partial for odd wn
+                N, H, W = 2, 21, 35
+                x = rnd(g, N, H, W, r4(cin))[..., :cin]
+                w = rnd(g, cout, cin, 3, 3, scale=1.0 / np.sqrt(9 * cin))
+                bias = rnd(g, cout, scale=0.2)
+                slope = torch.rand(cout, generator=g) * 0.4
+                oc = torch.empty(N, H, W, r4(cout))[..., :cout]
+                cpu.conv(x, cpu.pack_weight(GEMM_CONV, w), oc, 1, 1, 1, bias, slope)
+                xg = torch.zeros(N, H, W, r4(cin), device=dev)
+                xg[..., :cin] = x.to(dev)
+                og = torch.full((N, H, W, r4(cout)), 7.0, device=dev)
+                hip.conv(xg[..., :cin], hip.pack_weight(GEMM_CONV, w.to(dev)), og[..., :cout], 1, 1, 1, bias.to(dev), slope.to(dev))
+                torch.cuda.synchronize()
+                assert maxdiff(og[..., :cout], oc) <= 1e-4, (schedule, wn, cin)
+                assert (og[..., cout:] == 7.0).all()
+    finally:
+        hip.lib.atmvfi_conv3x3_set_schedule(-1, 0)
