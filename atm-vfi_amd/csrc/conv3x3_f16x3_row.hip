@@ -409,44 +409,37 @@ int launch_row(const Conv3Dev& d, int ntiles, hipStream_t s) {
 }  // namespace
 
 int atmvfi::launch_conv3x3_row(const Conv3Dev& d, int ntiles, hipStream_t s) {
-    // Tile width WN (n-tiles per workgroup), then the schedule:
-    //   work ~ padded tiles * (1 + 1/WN) [MFMA work ~ WN, operand staging per tile ~ const]; an under-filled launch is charged the
-    //   idle CUs, which is what keeps small maps busy (a 36x60 map with 768 channels is 72 workgroups at WN = 8, 192 at WN = 3);
-    //   rounds = ceil(workgroups / resident slots): one slot per CU for the 512-thread schedule, two for the half-size one.
-    //   (A joint search over (WN, schedule) on rounds x tile time picked 3-tile half workgroups for 389- and 576-wide layers and
-    //   lost 10 % at 576x960: the halo staging repeated per column block is dearer than the model's constant.)
-    // The half-size schedule overlaps two workgroups' DMA issue, barrier waits and halo conversion and quantises better on small
-    // images (8-row tiles), but streams the weights twice per 256 pixels and pays a barrier per tap: `rel` is its measured tile-pair
-    // time relative to a full tile at that width (1080p layers, same-box A/B, rounds factored out: 48- and 64-wide layers gain
-    // 10-13 %, 24-wide and 80-wide (5 n-tiles) ones lose 18-50 %, 112-wide ones are even; three taps per stage on the half tiles
-    // measured no better).  Counting rounds is what keeps small images busy: a
-    // 36x60 map with 768 channels is 72 workgroups at WN = 8 on 256 CUs, 192 at WN = 3.
-    // ATMVFI_CONV3_SCHED=row|half forces a schedule.
+    // Tile width WN (n-tiles per workgroup) and schedule, chosen together: time ~ rounds x tile time.
+    //   rounds    = ceil(workgroups / resident slots): one slot per CU for the 512-thread schedule, two for the half-size one.
+    //               Counting rounds is what keeps small maps busy and whole: a 68x120 map with 768 channels is 240 workgroups at
+    //               WN = 8 (one round on 256 CUs) but 320 at WN = 6 -- two rounds, the second a quarter full (0.65 against 0.42 ms).
+    //   tile time ~ (WN + c0) [MFMA work ~ WN; halo staging, prologue and epilogue per tile ~ c0 = 2 n-tiles' worth, fitted to
+    //               same-box sweeps of all (schedule, WN) pairs on the 1080p layers, tools/tune_conv3.py; with c0 = 1 the search
+    //               picked 3-tile half workgroups for 389- and 576-wide layers and lost 10 %], x rel[WN] for the half schedule.
+    //   rel[WN]   = measured time of a half-tile pair relative to a full tile at that width (1080p layers, same-box A/B, rounds
+    //               factored out: 48- and 64-wide layers gain 10-13 %, 24-wide and 80-wide (5 n-tiles) ones lose 18-50 %,
+    //               112-wide ones are even).  The half schedule overlaps two workgroups' DMA issue, barrier waits and halo
+    //               conversion and quantises better on small images (8-row tiles), but streams the weights twice per 256 pixels
+    //               and pays a barrier per tap; three taps per stage on the half tiles measured no better.
+    // ATMVFI_CONV3_SCHED=row|half or atmvfi_conv3x3_set_schedule() force a schedule / width.
     static const int env_forced = [] { const char* e = getenv("ATMVFI_CONV3_SCHED"); return !e ? -1 : (e[0] == 'h' ? 1 : 0); }();
     const int forced = g_conv3_schedule >= 0 ? g_conv3_schedule : env_forced;
-    static const float rel[9] = {1.f, 1.10f, 1.50f, 0.87f, 0.90f, 1.18f, 1.07f, 1.01f, 1.02f};     // re-measured with the k-step-major weights
+    static const float rel[9] = {1.f, 1.10f, 1.20f, 0.88f, 0.95f, 1.15f, 1.07f, 1.06f, 1.02f};     // re-measured with the pipelined fragment reads (tools/tune_conv3.py)
+    static const float c0 = [] { const char* e = getenv("ATMVFI_CONV3_C0"); return e ? (float)atof(e) : 2.0f; }();
     const int ncu = atmvfi::cu_count();
-    // (1) tile width from the padding rule; narrower only if that is what it takes to put a workgroup on every CU
-    int best = 1;
-    float best_cost = 1e30f;
     const long long spatial_row = (long long)d.N * d.tiles_x * ((d.H + 15) / 16);
+    const long long spatial_half = (long long)d.N * d.tiles_x * ((d.H + 7) / 8);
+    int best = 1;
+    bool half = false;
+    float best_cost = 1e30f;
     for (int wn = 1; wn <= 8; ++wn) {
+        if (g_conv3_wn > 0 && wn != g_conv3_wn) continue;
         const int nb = (ntiles + wn - 1) / wn;
-        float cost = (float)(nb * wn) * (1.0f + 1.0f / (float)wn);
-        const long long wgs = spatial_row * nb;
-        if (wgs < ncu) cost *= (float)ncu / (float)wgs;              // under-filled launch: time ~ tile time, not total work
-        if (cost <= best_cost) { best_cost = cost; best = wn; }
-    }
-    if (g_conv3_wn > 0) best = g_conv3_wn;
-    // (2) schedule at that width: rounds of the launch x measured relative tile time
-    bool half = forced == 1;
-    if (forced < 0) {
-        const int nb = (ntiles + best - 1) / best;
-        const long long t_row = spatial_row * nb;
-        const long long t_half = (long long)d.N * d.tiles_x * ((d.H + 7) / 8) * nb;
-        const float c_row = (float)((t_row + ncu - 1) / ncu);
-        const float c_half = (float)((t_half + 2 * ncu - 1) / (2 * ncu)) * rel[best];
-        half = c_half < c_row;
+        const float tile = (float)wn + c0;
+        const float c_row = (float)((spatial_row * nb + ncu - 1) / ncu) * tile;
+        const float c_half = (float)((spatial_half * nb + 2 * ncu - 1) / (2 * ncu)) * tile * rel[wn];
+        if (forced != 1 && c_row <= best_cost) { best_cost = c_row; best = wn; half = false; }
+        if (forced != 0 && c_half <= best_cost) { best_cost = c_half; best = wn; half = true; }
     }
     static const bool verbose = getenv("ATMVFI_CONV3_VERBOSE") != nullptr;
     if (verbose) fprintf(stderr, "conv3x3 N%d H%d W%d Cin%d Cout%d -> WN %d %s (cost %.2f)\n", d.N, d.H, d.W, d.Cin, d.Cout, best, half ? "half" : "row", best_cost);
