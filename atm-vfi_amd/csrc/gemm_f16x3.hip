@@ -369,6 +369,14 @@ int launch(const GemmDev& d, int ntiles, hipStream_t s) {
 
 }  // namespace
 
+// Tile-width override for A/B sweeps (tools/tune_gemm.py): 0 = cost model (default), 1..8 = n-tiles per workgroup.
+static int g_gemm_wn = 0;
+extern "C" int atmvfi_gemm_f16x3_set_tile_width(int wn) {
+    ATMVFI_REQUIRE(wn >= 0 && wn <= 8, ATMVFI_EINVAL, "gemm_f16x3_set_tile_width: 0 (auto) or 1..8, got %d", wn);
+    g_gemm_wn = wn;
+    return 0;
+}
+
 int atmvfi::launch_gemm_f16x3(const GemmDev& d, int ngemm, hipStream_t s) {
     const int ntiles = (ngemm + 15) / 16;
     // tile width: time ~ rounds x tile time; tile time ~ WN * (1 + cfac/WN) (MFMA work ~ WN; operand staging incl. the fp32 ->
@@ -385,6 +393,7 @@ int atmvfi::launch_gemm_f16x3(const GemmDev& d, int ngemm, hipStream_t s) {
         const float cost = rounds * (float)wn * (1.0f + cfac / (float)wn);
         if (cost <= best_cost) { best_cost = cost; best = wn; }
     }
+    if (g_gemm_wn > 0) best = g_gemm_wn;
     switch (best) {
         case 1: return launch<1>(d, ntiles, s);
         case 2: return launch<2>(d, ntiles, s);

@@ -71,6 +71,7 @@ SIGNATURES = {
     "atmvfi_pack_weight_conv3x3": (c_i, [c_f, c_f, c_f, c_i, c_i, c_f]),
     "atmvfi_conv3x3_f16x3": (c_i, [c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_i, c_f, c_f, c_f]),
     "atmvfi_conv3x3_set_schedule": (c_i, [c_i, c_i]),
+    "atmvfi_gemm_f16x3_set_tile_width": (c_i, [c_i]),
     "atmvfi_layernorm": (c_i, [c_f, c_i, c_l, c_i, c_f, c_f, c_i, c_f, c_f, c_l, c_i, c_f, c_f, c_i, c_f]),
     "atmvfi_dwconv3x3_gelu": (c_i, [c_f, c_i, c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f]),
     "atmvfi_pack_dw_weight": (c_i, [c_f, c_f, c_i, c_f]),

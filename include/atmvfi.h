@@ -144,6 +144,9 @@ int atmvfi_conv3x3_f16x3(const float* in, int in_ld, int N, int H, int W, int Ci
  * 0 = row, 1 = half; wn 0 = cost model, 1..8 = n-tiles per workgroup.  Not thread-safe against concurrent launches; results do
  * not depend on either choice. */
 int atmvfi_conv3x3_set_schedule(int schedule, int wn);
+/* Same kind of override for the f16x3 GEMM engine behind atmvfi_conv2d / atmvfi_linear / atmvfi_deconv2x2 (fp32 inputs): 0 = cost
+ * model (default), 1..8 = n-tiles of 16 columns per 256-row workgroup tile. */
+int atmvfi_gemm_f16x3_set_tile_width(int wn);
 
 /* ------------------------------------------------------------------------------------
  * LayerNorm over the channel axis of token rows (eps 1e-5, affine), optional gather.
