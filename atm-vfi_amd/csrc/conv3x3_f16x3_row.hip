@@ -27,7 +27,8 @@ extern "C" void atmvfi_debug_set_stamp_buffer(void* p) { g_stamp_buf = (unsigned
 #endif
 
 // Diagnostic build only (`make ablate`, never the product): ATMVFI_LEGACY_ORDER bits switch pieces of the kernel off (results are
-// then wrong) to price them: 2 weight DMA after the prologue, 4 halo reloads, 8 halo convert + write, 16 epilogue stores.
+// then wrong) to price them: 2 weight DMA after the prologue, 4 halo reloads, 8 halo convert + write, 16 epilogue stores, 32 the MFMAs
+// of the pipelined loop (3+ n-tiles).
 #ifdef ATMVFI_ABLATE
 #define ABL(bit) ((a.legacy_order & (bit)) != 0)
 #else
@@ -280,12 +281,16 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void conv3x3_f16x3_row_
                 const f16x8 ch = wh[n % 3], cl = wl[n % 3];
                 const f16x8 h0 = xh[xs][0], h1 = xh[xs][1], l0 = xl[xs][0], l1 = xl[xs][1];
                 // dependent MFMAs (same accumulator) are kept 4 issues apart
-                cor[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cl, h0, cor[0][j], 0, 0, 0);
-                cor[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cl, h1, cor[1][j], 0, 0, 0);
-                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, h0, acc[0][j], 0, 0, 0);
-                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, h1, acc[1][j], 0, 0, 0);
-                cor[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, l0, cor[0][j], 0, 0, 0);
-                cor[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, l1, cor[1][j], 0, 0, 0);
+                if (!ABL(32)) {
+                    cor[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cl, h0, cor[0][j], 0, 0, 0);
+                    cor[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cl, h1, cor[1][j], 0, 0, 0);
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, h0, acc[0][j], 0, 0, 0);
+                    acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, h1, acc[1][j], 0, 0, 0);
+                    cor[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, l0, cor[0][j], 0, 0, 0);
+                    cor[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch, l1, cor[1][j], 0, 0, 0);
+                } else {
+                    acc[0][j] += (f32x4){(float)ch[0], (float)cl[0], (float)h0[0], (float)l1[0]};      // keeps the reads alive
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (!DX && j == P::JX && t + 1 < TAPS) {
                     load_x(t + 1, 0);
