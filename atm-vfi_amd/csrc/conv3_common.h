@@ -20,6 +20,12 @@ struct Conv3Dev {
     int out_ld;
     const float* bias;
     const float* prelu;
+    // optional second output: the result again as split planes (chunk-major, common.h RowSink), through its own per-channel
+    // PReLU -- the form the next layer's LDS-DMA GEMM reads (decoder: conv -> [PReLU] -> ConvTranspose2d)
+    _Float16* out_hi;
+    _Float16* out_lo;
+    long long plane_rows;
+    const float* plane_prelu;
     int tiles_x, tiles_y;
     int nblocks;    // column blocks per spatial tile (set by the launcher)
     int legacy_order;   // A/B switch (ATMVFI_LEGACY_ORDER=1): round-robin tiles over XCDs

@@ -116,7 +116,8 @@ extern "C" int atmvfi_pack_weight_split(int mode, const float* src, void* dst_hi
 
 extern "C" int atmvfi_conv3x3_f16x3(const float* in, int in_ld, int N, int H, int W, int Cin, const void* w_hi,
                                      const void* w_lo, int Cout, float* out, int out_ld, const float* bias,
-                                     const float* prelu, void* stream) {
+                                     const float* prelu, void* out_hi, void* out_lo, int64_t plane_rows,
+                                     const float* plane_prelu, void* stream) {
     ATMVFI_REQUIRE(in && w_hi && w_lo && out, ATMVFI_EINVAL, "conv3x3_f16x3: null pointer");
     ATMVFI_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, ATMVFI_EINVAL, "conv3x3_f16x3: bad shape");
     ATMVFI_REQUIRE(in_ld % 4 == 0 && in_ld >= atmvfi::round_up(Cin, 4) && out_ld % 4 == 0 && out_ld >= atmvfi::round_up(Cout, 4),
@@ -124,6 +125,12 @@ extern "C" int atmvfi_conv3x3_f16x3(const float* in, int in_ld, int N, int H, in
     ATMVFI_REQUIRE(atmvfi::aligned16(in) && atmvfi::aligned16(out) && atmvfi::aligned16(w_hi) && atmvfi::aligned16(w_lo) &&
                        (!bias || atmvfi::aligned16(bias)) && (!prelu || atmvfi::aligned16(prelu)),
                    ATMVFI_EALIGN, "conv3x3_f16x3: pointers (incl. bias/prelu) must be 16-byte aligned");
+    ATMVFI_REQUIRE((out_hi == nullptr) == (out_lo == nullptr), ATMVFI_EINVAL, "conv3x3_f16x3: plane sink needs both planes");
+    if (out_hi) {
+        ATMVFI_REQUIRE(plane_rows >= (int64_t)N * H * W, ATMVFI_EINVAL, "conv3x3_f16x3: plane_rows %lld < N*H*W", (long long)plane_rows);
+        ATMVFI_REQUIRE(atmvfi::aligned16(out_hi) && atmvfi::aligned16(out_lo) && (!plane_prelu || atmvfi::aligned16(plane_prelu)),
+                       ATMVFI_EALIGN, "conv3x3_f16x3: plane sink pointers must be 16-byte aligned");
+    }
     Conv3Dev d;
     d.in = in; d.in_ld = in_ld; d.N = N; d.H = H; d.W = W; d.Cin = Cin;
     d.w_hi = (const _Float16*)w_hi; d.w_lo = (const _Float16*)w_lo;
@@ -132,6 +139,7 @@ extern "C" int atmvfi_conv3x3_f16x3(const float* in, int in_ld, int N, int H, in
     d.cs = 0;
     d.ktot = 0;
     d.Cout = Cout; d.out = out; d.out_ld = out_ld; d.bias = bias; d.prelu = prelu;
+    d.out_hi = (_Float16*)out_hi; d.out_lo = (_Float16*)out_lo; d.plane_rows = plane_rows; d.plane_prelu = plane_prelu;
     d.stamp = nullptr;
     d.nblocks = 0;
     d.tchunk = 0;

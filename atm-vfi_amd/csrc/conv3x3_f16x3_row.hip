@@ -341,12 +341,27 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void conv3x3_f16x3_row_
 
     // ---- epilogue ----
     float* orow[2];
+    long long prow[2];                 // pixel index = row of the optional plane sink
     bool live[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int oy = oy0 + 2 * wave + i, ox = ox0 + r;
         live[i] = oy < a.H && ox < a.W;
-        orow[i] = a.out + (((long long)img * a.H + (live[i] ? oy : 0)) * a.W + (live[i] ? ox : 0)) * a.out_ld;
+        prow[i] = ((long long)img * a.H + (live[i] ? oy : 0)) * a.W + (live[i] ? ox : 0);
+        orow[i] = a.out + prow[i] * a.out_ld;
+    }
+    // slopes of the plane sink's PReLU for all of this lane's column groups, fetched before the store loop (a load inside it
+    // would put a vmcnt(0) round trip between consecutive stores)
+    f32x4 psl[WN];
+    if (a.out_hi && a.plane_prelu) {
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int co = n0 + 16 * j + 4 * g;
+            psl[j] = *reinterpret_cast<const f32x4*>(a.plane_prelu + (co < a.Cout ? co : 0));       // padded to 32 by the host
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < WN; ++j) psl[j] = (f32x4){1.f, 1.f, 1.f, 1.f};
     }
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
@@ -370,6 +385,24 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void conv3x3_f16x3_row_
                     orow[i][co] = v.x;
                     if (nvalid > 1) orow[i][co + 1] = v.y;
                     if (nvalid > 2) orow[i][co + 2] = v.z;
+                }
+                if (a.out_hi && nvalid > 0) {
+                    // plane sink (uniform branch, two layers of the network): the value the NEXT layer reads, i.e. through that
+                    // layer's leading PReLU; channels past Cout in this group of 4 are the planes' pad channels (zero weights,
+                    // zero bias: v = 0) and are written as such
+                    f32x4 u = v;
+                    const f32x4 sl = psl[j];
+                    u.x = u.x > 0.f ? u.x : sl.x * u.x;
+                    u.y = u.y > 0.f ? u.y : sl.y * u.y;
+                    u.z = u.z > 0.f ? u.z : sl.z * u.z;
+                    u.w = u.w > 0.f ? u.w : sl.w * u.w;
+                    if (nvalid < 4) {
+                        u.y = nvalid > 1 ? u.y : 0.f;
+                        u.z = nvalid > 2 ? u.z : 0.f;
+                        u.w = 0.f;
+                    }
+                    const RowSink sink{nullptr, 0, a.out_hi, a.out_lo, a.plane_rows};
+                    sink_store4(sink, prow[i], co, u);
                 }
             }
         }

@@ -69,7 +69,7 @@ SIGNATURES = {
     "atmvfi_pack_weight_split": (c_i, [c_i, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     "atmvfi_conv3x3_weight_halves": (c_l, [c_i, c_i]),
     "atmvfi_pack_weight_conv3x3": (c_i, [c_f, c_f, c_f, c_i, c_i, c_f]),
-    "atmvfi_conv3x3_f16x3": (c_i, [c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_i, c_f, c_f, c_f]),
+    "atmvfi_conv3x3_f16x3": (c_i, [c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_l, c_f, c_f]),
     "atmvfi_conv3x3_set_schedule": (c_i, [c_i, c_i]),
     "atmvfi_gemm_f16x3_set_tile_width": (c_i, [c_i]),
     "atmvfi_layernorm": (c_i, [c_f, c_i, c_l, c_i, c_f, c_f, c_i, c_f, c_f, c_l, c_i, c_f, c_f, c_i, c_f]),
@@ -292,7 +292,9 @@ class HipOps:
         return out
 
     # ------------------------------------------------------------------ GEMMs
-    def conv(self, x, w: PackedWeight, out, stride=1, pad=1, dil=1, bias=None, prelu=None, in_prelu=None):
+    def conv(self, x, w: PackedWeight, out, stride=1, pad=1, dil=1, bias=None, prelu=None, in_prelu=None,
+             planes: Optional[Planes] = None, planes_prelu=None):
+        """``planes``: also write the result as split planes (3x3 / stride 1 f16x3 kernel only), through ``planes_prelu``."""
         ld, n, h, wd, cin = nhwc_view(x, "conv.in")
         old, on, oh, ow, cout = nhwc_view(out, "conv.out")
         if cin != w.cin or cout != w.cout or on != n or w.mode != GEMM_CONV:
@@ -302,9 +304,17 @@ class HipOps:
                 "shape": f"M{n * oh * ow} N{cout} K{cin * w.kh * w.kw}"}
         if (self.precision == "f16x3" and w.hi3 is not None and w.kh == 3 and stride == 1 and pad == 1 and dil == 1
                 and in_prelu is None):
+            if planes is not None and (planes.rows < n * h * wd or planes.c != cout):
+                raise ValueError(f"conv: plane sink [{planes.rows},{planes.c}] does not match {n * h * wd} pixels x {cout} channels")
+            if planes is not None and planes_prelu is not None and planes_prelu.numel() < (cout + 31) // 32 * 32:
+                raise ValueError("conv: planes_prelu must be padded to a multiple of 32 channels")
             self._run("conv3x3_f16x3", meta, self.lib.atmvfi_conv3x3_f16x3, _ptr(x), ld, n, h, wd, cin, _ptr(w.hi3), _ptr(w.lo3),
-                      cout, _ptr(out), old, _ptr(bias), _ptr(prelu), self._stream())
+                      cout, _ptr(out), old, _ptr(bias), _ptr(prelu),
+                      planes.t[0].data_ptr() if planes is not None else None, planes.t[1].data_ptr() if planes is not None else None,
+                      planes.rows if planes is not None else 0, _ptr(planes_prelu) if planes is not None else None, self._stream())
             return
+        if planes is not None:
+            raise ValueError("conv: a plane sink needs the 3x3 / stride-1 f16x3 kernel")
         p = GemmParams(mode=GEMM_CONV, in_=x.data_ptr(), in_ld=ld, N=n, H=h, W=wd, Cin=cin, in_gstride=0, in_rpg=0,
                        weight=w.packed.data_ptr(), Cout=cout, kh=w.kh, kw=w.kw, stride=stride, pad=pad, dil=dil,
                        Ho=oh, Wo=ow, M=n * oh * ow, out=out.data_ptr(), out_ld=old, out_gstride=0, out_rpg=0,
@@ -326,7 +336,7 @@ class HipOps:
         p.precision, p.weight_hi, p.weight_lo = self._prec(w)
         use_planes = planes is not None and p.precision == 1
         if use_planes:
-            if planes.rows != n * h * wd or planes.c != cin:
+            if planes.rows < n * h * wd or planes.c != cin:
                 raise ValueError("deconv: planes do not match the input rows")
             p.in_, p.in_ld, p.in_prelu = None, planes.rows, None
             p.in_hi, p.in_lo = planes.t[0].data_ptr(), planes.t[1].data_ptr()

@@ -83,6 +83,7 @@ class Network(nn.Module):
         self._ops_obj = None
         self._precision = "f16x3"
         self.use_split_planes = os.environ.get("ATMVFI_SPLIT_PLANES", "1") != "0"     # A/B switch (tools/profile_layers.py)
+        self.use_plane_deconvs = os.environ.get("ATMVFI_PLANE_DECONV", "1") != "0"    # A/B switch: decoder deconvs from split planes
         self._prepared: Dict[str, object] = {}
         self._prepared_sig = None
         self._bufs: Dict[Tuple, torch.Tensor] = {}
@@ -233,15 +234,27 @@ class Network(nn.Module):
     def _conv_act(self, ops, P, p, x, out, stride=1):
         ops.conv(x, P[f"pk:{p}.0.weight"], out, stride=stride, pad=1, dil=1, bias=P[f"{p}.0.bias"], prelu=P[f"{p}.1.weight"])
 
-    def _conv_plain(self, ops, P, p, x, out, stride=1, pad=1, dil=1):
+    def _conv_plain(self, ops, P, p, x, out, stride=1, pad=1, dil=1, planes=None, planes_prelu=None):
+        if planes is not None:       # 3x3 epilogue also writes the split planes the next deconv reads (HIP backend only)
+            ops.conv(x, P[f"pk:{p}.weight"], out, stride=stride, pad=pad, dil=dil, bias=P[f"{p}.bias"], planes=planes,
+                     planes_prelu=planes_prelu)
+            return
         ops.conv(x, P[f"pk:{p}.weight"], out, stride=stride, pad=pad, dil=dil, bias=P[f"{p}.bias"])
 
-    def _deconv_act(self, ops, P, p, x, out, in_prelu=None, split: Optional[str] = None):
-        """``split``: workspace name -- split the input rows into fp16 planes first (one pass, through ``in_prelu``) and run the
-        deconv on the LDS-DMA GEMM: the fp32-input engine redoes that split once per column block (7x for 389 -> 4*197)."""
+    def _plane_deconvs(self, ops) -> bool:
+        """Decoder deconvs on the LDS-DMA GEMM (operands as split planes) instead of the fp32-input engine."""
+        return (getattr(ops, "precision", None) == "f16x3" and getattr(ops, "split_planes_ok", False) and self.use_split_planes
+                and self.use_plane_deconvs)
+
+    def _deconv_act(self, ops, P, p, x, out, in_prelu=None, split: Optional[str] = None, planes=None):
+        """``planes``: the input rows already in split-plane form, through ``in_prelu`` (written by the producing 3x3 conv).
+        ``split``: workspace name -- split the input rows into fp16 planes first (one pass, through ``in_prelu``).  Either way the
+        deconv runs on the LDS-DMA GEMM: the fp32-input engine redoes the split once per column block (7x for 389 -> 4*197)."""
         w = P[f"pk:{p}.0.weight"]
-        if split is not None and getattr(ops, "precision", None) == "f16x3" and getattr(ops, "split_planes_ok", False) \
-                and self.use_split_planes and w.hi is not None:
+        if planes is not None:
+            ops.deconv(x, w, out, bias=P[f"{p}.0.bias"], prelu=P[f"{p}.1.weight"], planes=planes)
+            return
+        if split is not None and self._plane_deconvs(ops) and w.hi is not None:
             b, h, wd, cin = x.shape
             xp = self.planes(split, b * h * wd, cin)
             ops.split_planes(x.flatten(0, 2), xp, prelu=in_prelu)
@@ -534,18 +547,30 @@ class Network(nn.Module):
             dsts = (bufC[..., 4 * rh:4 * rh + w1d + 5], bufB[..., 2 * rh:2 * rh + w2d + 5], rin[..., 0:w3d + 5])
             x = dec_in[..., 0:cdec]
             flow0 = flow1 = m1 = m2 = None
+            pd = self._plane_deconvs(ops)
+            xp_next = None
             for st, scale in enumerate((2, 1, 0)):
                 pfx = f"upsample_pyramid.{st}"
                 o = 1 if st else 0
                 cout = dsts[st].shape[-1]
                 hs, wsz = H >> scale, W >> scale
                 t1 = self.buf(f"dec_t1_{st}", b, hs, wsz, _r4(cout))[..., :cout]
-                # (split=f"dec_xp_{st}" -- a split pass + the LDS-DMA GEMM -- measured 1.70 against 1.77 ms for the three stages: the
-                # pass costs what the faster GEMM saves; left on the fp32-input engine)
-                self._deconv_act(ops, P, f"{pfx}.{o}", x, t1, in_prelu=P[f"inprelu:{st}"] if st else None)
+                # The deconvs run on the LDS-DMA GEMM from split planes (1.81 against 2.46 ms on the fp32-input engine for the six
+                # deconvs of the network, tools/bench_deconv_planes.py).  Stage 0's input has several producers (two warps, a 1x1
+                # conv): one split pass (0.03 ms); stages 1-2 get their planes from the epilogue of the 3x3 conv that produces
+                # their input, already through the stage's leading PReLU.
+                if st == 0 or not pd:
+                    self._deconv_act(ops, P, f"{pfx}.{o}", x, t1, in_prelu=P[f"inprelu:{st}"] if st else None,
+                                     split=f"dec_xp_{st}" if pd else None)
+                else:
+                    self._deconv_act(ops, P, f"{pfx}.{o}", x, t1, planes=xp_next)
                 t2b = self.buf(f"dec_t2_{st}", b, hs, wsz, _r4(cout))[..., :cout]
                 self._conv_act(ops, P, f"{pfx}.{o + 1}", t1, t2b)
-                self._conv_plain(ops, P, f"{pfx}.{o + 2}", t2b, dsts[st])
+                if pd and st < 2:
+                    xp_next = self.planes(f"dec_xp_{st + 1}", b * hs * wsz, cout)
+                    self._conv_plain(ops, P, f"{pfx}.{o + 2}", t2b, dsts[st], planes=xp_next, planes_prelu=P[f"inprelu:{st + 1}"])
+                else:
+                    self._conv_plain(ops, P, f"{pfx}.{o + 2}", t2b, dsts[st])
                 x = dsts[st]
                 mot = x[..., cout - 5:cout]
                 a, c, t = (ops.empty(b, 3, hs, wsz) for _ in range(3))

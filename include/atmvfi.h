@@ -136,8 +136,15 @@ int atmvfi_pack_weight_split(int mode, const float* src, void* dst_hi, void* dst
  * k-steps for five channels.  Layout details: csrc/conv3x3_f16x3.hip. */
 int64_t atmvfi_conv3x3_weight_halves(int Cout, int Cin);
 int atmvfi_pack_weight_conv3x3(const float* src, void* dst_hi, void* dst_lo, int Cout, int Cin, void* stream);
+/* Optional second output (out_hi / out_lo non-null): the result once more as split planes -- fp16 hi and lo' = (x - hi) * 1024,
+ * chunk major [ceil(Cout/32)][plane_rows][32] with pixel n*H*W + y*W + x as the row, see atmvfi_split_planes -- after a
+ * per-channel PReLU of its own (plane_prelu, padded to a multiple of 32 floats, or null).  That is the operand format of the
+ * LDS-DMA GEMM behind atmvfi_deconv2x2 / atmvfi_linear (in_hi / in_lo): the decoder's conv -> PReLU -> ConvTranspose2d chain
+ * (network_base.py:207-216) hands over without a separate split pass.  Pad channels of the last chunk must be zero in the
+ * caller's buffer; those inside the last group of 4 are written as zero. */
 int atmvfi_conv3x3_f16x3(const float* in, int in_ld, int N, int H, int W, int Cin, const void* w_hi, const void* w_lo,
-                         int Cout, float* out, int out_ld, const float* bias, const float* prelu, void* stream);
+                         int Cout, float* out, int out_ld, const float* bias, const float* prelu, void* out_hi, void* out_lo,
+                         int64_t plane_rows, const float* plane_prelu, void* stream);
 /* The 3x3 kernel has two schedules (512-thread 16x16 tiles, one workgroup per CU; 256-thread 16x8 tiles, two per CU) and 1..8
  * n-tiles of 16 output channels per workgroup, picked per layer from a cost model.  This process-wide override exists for the
  * parity tests, which must reach every instance of the kernel, and for same-box A/B timing: schedule -1 = cost model (default),

@@ -651,3 +651,44 @@ def test_conv3x3_every_kernel_instance(schedule, hip, cpu, dev):
                 assert (og[..., cout:] == 7.0).all()
     finally:
         hip.lib.atmvfi_conv3x3_set_schedule(-1, 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("schedule", [0, 1], ids=["row", "half"])
+def test_conv3x3_plane_sink(schedule, hip, dev):
+    """The 3x3 kernel's second output: the planes must be the exact split of prelu(result) -- identical, bit for bit, to
+    split_planes(+PReLU) applied to the fp32 output -- with the fp32 output unchanged, for a 32k+5-wide layer (partial last
+    group of 4, partial last chunk), ragged tiles, two images; and a deconv fed from them must equal the one fed by the split pass."""
+    g = torch.Generator().manual_seed(909 + schedule)
+    n, h, w, cin, cout = 2, 19, 21, 40, 101
+    x = rnd(g, n, h, w, cin, scale=2.0).to(dev)
+    wt = rnd(g, cout, cin, 3, 3, scale=1.0 / np.sqrt(9 * cin)).to(dev)
+    bias = rnd(g, cout, scale=0.3).to(dev)
+    inp = (0.25 + rnd(g, cout, scale=0.1)).to(dev)
+    pw = hip.pack_weight(GEMM_CONV, wt)
+    assert hip.lib.atmvfi_conv3x3_set_schedule(schedule, 0) == 0
+    try:
+        for slopes in (inp, None):
+            y0 = torch.full((n, h, w, 104), 3.0, device=dev)
+            y1 = torch.full((n, h, w, 104), 3.0, device=dev)
+            hip.conv(x, pw, y0[..., :cout], 1, 1, 1, bias, None)
+            p = hip_ops.Planes.alloc(n * h * w + 7, cout, dev)          # more plane rows than pixels: the row pitch is plane_rows
+            hip.conv(x, pw, y1[..., :cout], 1, 1, 1, bias, None, planes=p, planes_prelu=hip.pad_channels(slopes) if slopes is not None else None)
+            q = hip_ops.Planes.alloc(n * h * w, cout, dev)
+            hip.split_planes(y0[..., :cout].flatten(0, 2), q, prelu=slopes)
+            torch.cuda.synchronize()
+            assert torch.equal(y0, y1)
+            assert torch.equal(p.t[:, :, :n * h * w], q.t)
+            assert (p.t[:, :, n * h * w:] == 0).all()
+            # and through the consumer: deconv from the sink's planes == deconv from the split pass's
+            if slopes is not None:
+                wd = rnd(g, cout, 24, 2, 2, scale=0.1).to(dev)
+                pwd = hip.pack_weight(GEMM_DECONV, wd)
+                z0 = torch.empty(n, 2 * h, 2 * w, 24, device=dev)
+                z1 = torch.empty(n, 2 * h, 2 * w, 24, device=dev)
+                hip.deconv(y0[..., :cout], pwd, z0, None, None, planes=q)
+                hip.deconv(y0[..., :cout], pwd, z1, None, None, planes=p)
+                torch.cuda.synchronize()
+                assert torch.equal(z0, z1)
+    finally:
+        hip.lib.atmvfi_conv3x3_set_schedule(-1, 0)
