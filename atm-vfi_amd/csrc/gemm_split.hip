@@ -55,6 +55,14 @@ __device__ __forceinline__ void wait_vmcnt() {
 //   * fragments of stage k+1 are first read in item 2 of step k: the one barrier per step sits between items 1 and 2,
 //     behind s_waitcnt vmcnt (own DMA pieces of stage k+1 landed) and lgkmcnt(0) (own reads of stage k complete),
 //     and right after it the DMA for stage k+3 is issued into the buffer stage k just vacated (two steps of lookahead).
+// Diagnostic build only (`make ablate`): ATMVFI_SPLIT_DEBUG bits 4 / 8 / 16 switch off the activation-fragment LDS reads of the
+// loop, the activation DMA, the weight-fragment reloads (wrong results; prices the LDS traffic of each).
+#ifdef ATMVFI_ABLATE
+#define SABL(bit) ((a.dbg & (bit)) != 0)
+#else
+#define SABL(bit) false
+#endif
+
 template <int WGM, int WGN>
 __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_split_kernel(const GemmDev a) {
     constexpr int NW = WGM * WGN;
@@ -124,8 +132,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_split_kernel(const Gem
     // one third of a stage's pieces (PIECES == 6: A pieces 0-3, W pieces 0-1)
     auto issue_pair = [&](int kc, int buf, int p) {
         _Float16* st = smem + buf * STAGE_HALVES;
-        if (p == 0) { dma16(asrc[0] + kc * astep, st + adst[0]); dma16(asrc[1] + kc * astep, st + adst[1]); }
-        if (p == 1) { dma16(asrc[2] + kc * astep, st + adst[2]); dma16(asrc[3] + kc * astep, st + adst[3]); }
+        if (p == 0 && !SABL(8)) { dma16(asrc[0] + kc * astep, st + adst[0]); dma16(asrc[1] + kc * astep, st + adst[1]); }
+        if (p == 1 && !SABL(8)) { dma16(asrc[2] + kc * astep, st + adst[2]); dma16(asrc[3] + kc * astep, st + adst[3]); }
         if (p == 2) { dma16(wsrc[0] + kc * wstep, st + wdst[0]); dma16(wsrc[1] + kc * wstep, st + wdst[1]); }
     };
     // The DMA of one stage is spread over three items (an LDS-DMA instruction holds the wave's issue for 60-180 cycles)
@@ -193,13 +201,13 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_split_kernel(const Gem
         const _Float16* sn = smem + nbuf * STAGE_HALVES;
         const bool more = kc + 1 < nk;
         // item 0
-        load_x(st, 2);
+        if (!SABL(4)) load_x(st, 2);
         if (ikc < nk) issue_pair(ikc, ibuf, 2 - grp);
         mma_main(0);
         mma_cross(0);
         __builtin_amdgcn_sched_barrier(0);
         // item 1
-        load_x(st, 3);
+        if (!SABL(4)) load_x(st, 3);
         if (ikc < nk && grp == 1) issue_pair(ikc, ibuf, 2);
         mma_main(1);
         mma_cross(1);
@@ -213,7 +221,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_split_kernel(const Gem
             __builtin_amdgcn_sched_barrier(0);
             ikc = kc + 3;
             ibuf = buf;
-            load_x(sn, 0);
+            if (!SABL(4)) load_x(sn, 0);
             if (ikc < nk && grp == 0) issue_pair(ikc, ibuf, 0);
         } else {
             ikc = 0x7fffffff;
@@ -223,17 +231,17 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_split_kernel(const Gem
         mma_cross(2);
         __builtin_amdgcn_sched_barrier(0);
         // item 3 (+ weight fragments of the next step, each right behind the last MFMA that reads the old one)
-        if (more) load_x(sn, 1);
+        if (more && !SABL(4)) load_x(sn, 1);
         if (ikc < nk) issue_pair(ikc, ibuf, 1 - grp);
         mma_main(3);
-        if (more) {
+        if (more && !SABL(16)) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) wl[j] = *reinterpret_cast<const f16x8*>(sn + woff + j * 512 + BN * 32);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             cor[3][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xl[3], cor[3][j], 0, 0, 0);
-            if (more) wh[j] = *reinterpret_cast<const f16x8*>(sn + woff + j * 512);
+            if (more && !SABL(16)) wh[j] = *reinterpret_cast<const f16x8*>(sn + woff + j * 512);
         }
         __builtin_amdgcn_sched_barrier(0);
         buf = nbuf;
