@@ -15,6 +15,8 @@
 
 #include <stdlib.h>
 
+#include <atomic>
+
 #ifdef ATMVFI_STAMP
 // Diagnostic build only (`make stamp`, tools/stamp_conv.py): per-wave cycle sums of the phases of a stage.
 static unsigned long long* g_stamp_buf = nullptr;
@@ -37,7 +39,7 @@ extern "C" void atmvfi_debug_set_stamp_buffer(void* p) { g_stamp_buf = (unsigned
 
 // Override for tests and A/B runs (atmvfi_conv3x3_set_schedule): schedule -1 = cost model (default), 0 = row, 1 = half;
 // wn 0 = cost model, 1..8 = n-tiles per workgroup.
-static int g_conv3_schedule = -1, g_conv3_wn = 0;
+static std::atomic<int> g_conv3_schedule{-1}, g_conv3_wn{0};
 extern "C" int atmvfi_conv3x3_set_schedule(int schedule, int wn) {
     ATMVFI_REQUIRE(schedule >= -1 && schedule <= 1, ATMVFI_EINVAL, "conv3x3_set_schedule: schedule -1 (auto), 0 (row) or 1 (half), got %d", schedule);
     ATMVFI_REQUIRE(wn >= 0 && wn <= 8, ATMVFI_EINVAL, "conv3x3_set_schedule: wn 0 (auto) or 1..8, got %d", wn);
@@ -422,12 +424,9 @@ int launch_row(const Conv3Dev& d, int ntiles, hipStream_t s) {
     constexpr int TH = 2 * NWV, NPIX = HW_ * (TH + 2);
     const size_t lds = (size_t)(2 * NPIX * 32 + 2 * 2 * TAPS * BN * 32) * sizeof(_Float16) + epilogue_const_floats(BN) * sizeof(float);
     auto kern = conv3x3_f16x3_row_kernel<WN, NWV, TAPS>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        ATMVFI_REQUIRE(e == hipSuccess, ATMVFI_ELAUNCH, "conv3x3_f16x3_row: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    // once per template instance, thread-safe (function-local static initialisation)
+    static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    ATMVFI_REQUIRE(attr_err == hipSuccess, ATMVFI_ELAUNCH, "conv3x3_f16x3_row: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
     Conv3Dev ds = d;
     ds.nblocks = (ntiles + WN - 1) / WN;
     ds.tiles_y = (d.H + TH - 1) / TH;
@@ -461,7 +460,8 @@ int atmvfi::launch_conv3x3_row(const Conv3Dev& d, int ntiles, hipStream_t s) {
     //               and pays a barrier per tap; three taps per stage on the half tiles measured no better.
     // ATMVFI_CONV3_SCHED=row|half or atmvfi_conv3x3_set_schedule() force a schedule / width.
     static const int env_forced = [] { const char* e = getenv("ATMVFI_CONV3_SCHED"); return !e ? -1 : (e[0] == 'h' ? 1 : 0); }();
-    const int forced = g_conv3_schedule >= 0 ? g_conv3_schedule : env_forced;
+    const int sched_override = g_conv3_schedule.load(), wn_override = g_conv3_wn.load();
+    const int forced = sched_override >= 0 ? sched_override : env_forced;
     static const float rel[9] = {1.f, 1.10f, 1.20f, 0.88f, 0.95f, 1.15f, 1.07f, 1.06f, 1.02f};     // re-measured with the pipelined fragment reads (tools/tune_conv3.py)
     static const float c0 = [] { const char* e = getenv("ATMVFI_CONV3_C0"); return e ? (float)atof(e) : 2.0f; }();
     const int ncu = atmvfi::cu_count();
@@ -471,7 +471,7 @@ int atmvfi::launch_conv3x3_row(const Conv3Dev& d, int ntiles, hipStream_t s) {
     bool half = false;
     float best_cost = 1e30f;
     for (int wn = 1; wn <= 8; ++wn) {
-        if (g_conv3_wn > 0 && wn != g_conv3_wn) continue;
+        if (wn_override > 0 && wn != wn_override) continue;
         const int nb = (ntiles + wn - 1) / wn;
         const float tile = (float)wn + c0;
         const float c_row = (float)((spatial_row * nb + ncu - 1) / ncu) * tile;

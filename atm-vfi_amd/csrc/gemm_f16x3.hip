@@ -15,6 +15,8 @@
 
 #include <stdlib.h>
 
+#include <atomic>
+
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 #ifdef ATMVFI_STAMP
@@ -343,12 +345,9 @@ int launch(const GemmDev& d, int ntiles, hipStream_t s) {
     constexpr int BN = 16 * WN;
     const size_t lds = (size_t)(4 * 256 * 32 + 4 * BN * 32) * sizeof(_Float16) + 2 * atmvfi::gemm_const_floats(BN) * sizeof(float);
     auto kern = gemm_f16x3_kernel<WN>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        ATMVFI_REQUIRE(e == hipSuccess, ATMVFI_ELAUNCH, "gemm_f16x3: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    // once per template instance, thread-safe (function-local static initialisation)
+    static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    ATMVFI_REQUIRE(attr_err == hipSuccess, ATMVFI_ELAUNCH, "gemm_f16x3: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
     GemmDev dd = d;
     dd.nblocks = (ntiles + WN - 1) / WN;
     const long long mgroups = (atmvfi::ceil_div64(d.M, 256) + 7) / 8;
@@ -370,7 +369,7 @@ int launch(const GemmDev& d, int ntiles, hipStream_t s) {
 }  // namespace
 
 // Tile-width override for A/B sweeps (tools/tune_gemm.py): 0 = cost model (default), 1..8 = n-tiles per workgroup.
-static int g_gemm_wn = 0;
+static std::atomic<int> g_gemm_wn{0};
 extern "C" int atmvfi_gemm_f16x3_set_tile_width(int wn) {
     ATMVFI_REQUIRE(wn >= 0 && wn <= 8, ATMVFI_EINVAL, "gemm_f16x3_set_tile_width: 0 (auto) or 1..8, got %d", wn);
     g_gemm_wn = wn;
@@ -393,7 +392,7 @@ int atmvfi::launch_gemm_f16x3(const GemmDev& d, int ngemm, hipStream_t s) {
         const float cost = rounds * (float)wn * (1.0f + cfac / (float)wn);
         if (cost <= best_cost) { best_cost = cost; best = wn; }
     }
-    if (g_gemm_wn > 0) best = g_gemm_wn;
+    if (const int wn_override = g_gemm_wn.load(); wn_override > 0) best = wn_override;
     switch (best) {
         case 1: return launch<1>(d, ntiles, s);
         case 2: return launch<2>(d, ntiles, s);

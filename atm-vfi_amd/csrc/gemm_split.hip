@@ -324,12 +324,9 @@ int launch_split(const GemmDev& d, int ngemm, hipStream_t s) {
     constexpr int BM = 64 * WGM, BN = 64 * WGN;
     const size_t lds = (size_t)3 * (2 * BM + 2 * BN) * 32 * sizeof(_Float16) + atmvfi::gemm_const_floats(BN) * sizeof(float);
     auto kern = gemm_split_kernel<WGM, WGN>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        ATMVFI_REQUIRE(e == hipSuccess, ATMVFI_ELAUNCH, "gemm_split: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    // once per template instance, thread-safe (function-local static initialisation)
+    static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    ATMVFI_REQUIRE(attr_err == hipSuccess, ATMVFI_ELAUNCH, "gemm_split: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
     GemmDev dd = d;
     static const int dbg = [] { const char* e = getenv("ATMVFI_SPLIT_DEBUG"); return e ? atoi(e) : 0; }();
     dd.dbg = dbg;

@@ -148,8 +148,8 @@ int atmvfi_conv3x3_f16x3(const float* in, int in_ld, int N, int H, int W, int Ci
 /* The 3x3 kernel has two schedules (512-thread 16x16 tiles, one workgroup per CU; 256-thread 16x8 tiles, two per CU) and 1..8
  * n-tiles of 16 output channels per workgroup, picked per layer from a cost model.  This process-wide override exists for the
  * parity tests, which must reach every instance of the kernel, and for same-box A/B timing: schedule -1 = cost model (default),
- * 0 = row, 1 = half; wn 0 = cost model, 1..8 = n-tiles per workgroup.  Not thread-safe against concurrent launches; results do
- * not depend on either choice. */
+ * 0 = row, 1 = half; wn 0 = cost model, 1..8 = n-tiles per workgroup.  Takes effect for launches made after it
+ * returns; results do not depend on either choice. */
 int atmvfi_conv3x3_set_schedule(int schedule, int wn);
 /* Same kind of override for the f16x3 GEMM engine behind atmvfi_conv2d / atmvfi_linear / atmvfi_deconv2x2 (fp32 inputs): 0 = cost
  * model (default), 1..8 = n-tiles of 16 columns per 256-row workgroup tile. */
