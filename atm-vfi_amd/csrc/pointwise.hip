@@ -90,10 +90,10 @@ __global__ __launch_bounds__(256) void dwconv_gelu_kernel(const float* __restric
             }
         }
         f32x4 o;
-        o.x = gelu_erf(acc.x);
-        o.y = gelu_erf(acc.y);
-        o.z = gelu_erf(acc.z);
-        o.w = gelu_erf(acc.w);
+        o.x = gelu_erf2(acc.x);
+        o.y = gelu_erf2(acc.y);
+        o.z = gelu_erf2(acc.z);
+        o.w = gelu_erf2(acc.w);
         sink_store4(out, pix, c, o);
     }
 }
@@ -156,10 +156,10 @@ __global__ __launch_bounds__(256) void dwconv_gelu_rows_kernel(const float* __re
                 }
             }
             f32x4 o;
-            o.x = gelu_erf(acc.x);
-            o.y = gelu_erf(acc.y);
-            o.z = gelu_erf(acc.z);
-            o.w = gelu_erf(acc.w);
+            o.x = gelu_erf2(acc.x);
+            o.y = gelu_erf2(acc.y);
+            o.z = gelu_erf2(acc.z);
+            o.w = gelu_erf2(acc.w);
             sink_store4(out, ((long long)n * H + y) * W + x, c, o);
         }
     }
