@@ -142,19 +142,20 @@ __global__ __launch_bounds__(256) void dwconv_gelu_rows_kernel(const float* __re
         const int y = y0 + r;
         load_row(y + 1, win[(r + 2) % 3]);
         if (y < H) {
-            f32x4 acc = bv;
+            // explicit packed fused multiply-adds (v_pk_fma_f32: 18 instructions per 4-channel output instead of 36 mul + 36 add
+            // under -ffp-contract=off; always fused, so the result does not depend on how the loop is peeled)
+            f32x2 a01 = bv.xy, a23 = bv.zw;
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 const f32x4* row = win[(r + ky) % 3];
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const f32x4 v = row[kx], wt = wv[ky * 3 + kx];
-                    acc.x += v.x * wt.x;
-                    acc.y += v.y * wt.y;
-                    acc.z += v.z * wt.z;
-                    acc.w += v.w * wt.w;
+                    a01 = __builtin_elementwise_fma(v.xy, wt.xy, a01);
+                    a23 = __builtin_elementwise_fma(v.zw, wt.zw, a23);
                 }
             }
+            const f32x4 acc = {a01.x, a01.y, a23.x, a23.y};
             f32x4 o;
             o.x = gelu_erf2(acc.x);
             o.y = gelu_erf2(acc.y);
