@@ -129,6 +129,39 @@ def test_full_size_properties_1080p(nets, dev):
     net.release_workspace()
 
 
+def test_full_size_properties_4k(nets, dev):
+    """BASELINE's largest configuration (C5, 2160x4096 padded to 2176x4096, untiled): the forward runs, is bitwise deterministic
+    run to run and stays in range; with the global branch off, the warped frame agrees with a direct warp of the input by the
+    returned flow (a relation between outputs that holds at any size: I_t_0 = flow_warp(im0, opt_flow_0), flow_warp.py:50-60,
+    network_base.py:523-541)."""
+    net = nets["base"]
+    a0, a1 = pairs.smooth_pair(1, 2176, 4096, seed=71)
+    it1 = run(net, True, False, a0, a1, dev)["I_t"].clone()
+    o2 = run(net, True, False, a0, a1, dev)
+    assert torch.equal(it1, o2["I_t"])
+    assert torch.isfinite(it1).all() and it1.min().item() >= 0.0 and it1.max().item() <= 1.0
+    assert it1.shape == (1, 3, 2176, 4096)
+    # without the global branch the finest-level warp acts on the input frame itself (with it, on the globally pre-warped pyramid)
+    o3 = run(net, False, False, a0, a1, dev)
+    w0, f0 = o3["I_t_0"].clone(), o3["opt_flow_0"].clone()
+    # independent restatement of the backward bilinear warp (zero outside), on the GPU in fp64
+    im = a0.to(dev).double()
+    H, W = 2176, 4096
+    ys, xs = torch.meshgrid(torch.arange(H, device=dev, dtype=torch.float64), torch.arange(W, device=dev, dtype=torch.float64), indexing="ij")
+    px, py = xs + f0[0, 0].double(), ys + f0[0, 1].double()
+    x0, y0 = torch.floor(px), torch.floor(py)
+    ref = torch.zeros(3, H, W, device=dev, dtype=torch.float64)
+    for dy in (0, 1):
+        for dx in (0, 1):
+            xi, yi = x0 + dx, y0 + dy
+            wgt = (1 - (px - xi).abs()) * (1 - (py - yi).abs())
+            ok = (xi >= 0) & (xi <= W - 1) & (yi >= 0) & (yi <= H - 1)
+            idx = (yi.clamp(0, H - 1) * W + xi.clamp(0, W - 1)).long()
+            ref += torch.where(ok, wgt, torch.zeros_like(wgt)) * im[0].reshape(3, -1)[:, idx.reshape(-1)].reshape(3, H, W)
+    assert (w0[0].double() - ref).abs().max().item() <= 2e-4      # fp32 coordinate arithmetic at |coordinate| ~ 4096
+    net.release_workspace()
+
+
 def test_window_size_knob_and_state_dict_roundtrip(nets, dev, weights):
     """__set_{local,global}_window_size__ (network_base.py:262-270) and checkpoint reload."""
     net = pkg.NetworkLite()
