@@ -107,19 +107,30 @@ def main():
         frames.append((a.contiguous(), b.contiguous()))
     H, W = frames[0][0].shape[-2:]
 
-    gathered = [torch.empty(1, 3, H, W, device=dev) for _ in range(world)] if world > 1 else None
+    # Two sets of gather buffers: the all-gather of step k (RCCL, its own stream) runs under the forward of step k+1 and is waited
+    # for one step later, so a rank that is momentarily slower delays the others' *gather*, not their next forward.  Every step's
+    # collective is issued and completed inside the timed region (the last one is waited for before the closing synchronize).
+    gathered = [[torch.empty(1, 3, H, W, device=dev) for _ in range(world)] for _ in range(2)] if world > 1 else None
+    pending = []
+
+    def drain():
+        while pending:
+            work, _keep = pending.pop(0)
+            work.wait()
 
     def step(i):
         a, b = frames[i % n_in]
         out = net(a, b)["I_t"]
         if world > 1:
-            dist.all_gather(gathered, out)      # per-rank output frames only
+            drain()                             # the previous step's gather
+            pending.append((dist.all_gather(gathered[i % 2], out, async_op=True), out))      # per-rank output frames only
         return out
 
     net.set_precision(args.precision)
     net.enable_graphs(args.graph)             # one hipGraphLaunch per forward; the collective stays outside the graph
     for i in range(args.warmup):
         step(i)
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -127,6 +138,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -151,7 +163,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"network_{variant} {args.height}x{args.width} (padded {H}x{W}) bs=1 per GPU, "
                                    f"global {'on' if net.global_motion else 'off'}, fp32, random frame pairs, stress weights seed 1",
-                       "pairs_per_step": world, "parallelism": f"frame-batch dp{world} + all-gather" if world > 1 else "single GPU"},
+                       "pairs_per_step": world, "parallelism": f"frame-batch dp{world} + all-gather of the output frames, one step behind the forward" if world > 1 else "single GPU"},
         }
         result["launch"] = "eager (one hipLaunchKernel per op)" if not args.graph else "HIP graph replay (captured forward, inputs copied into its static buffers inside the timed region)"
         if flops:
