@@ -70,6 +70,7 @@ SIGNATURES = {
     "atmvfi_conv3x3_weight_halves": (c_l, [c_i, c_i]),
     "atmvfi_pack_weight_conv3x3": (c_i, [c_f, c_f, c_f, c_i, c_i, c_f]),
     "atmvfi_conv3x3_f16x3": (c_i, [c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_l, c_f, c_f]),
+    "atmvfi_conv3x3_planes": (c_i, [c_f, c_f, c_l, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_l, c_i, c_f, c_i, c_f]),
     "atmvfi_conv3x3_set_schedule": (c_i, [c_i, c_i]),
     "atmvfi_gemm_f16x3_set_tile_width": (c_i, [c_i]),
     "atmvfi_layernorm": (c_i, [c_f, c_i, c_l, c_i, c_f, c_f, c_i, c_f, c_f, c_l, c_i, c_f, c_f, c_i, c_f]),
@@ -126,16 +127,25 @@ class Planes:
     are finite (zero).  Producers write it in their epilogue; the split GEMM reads it by LDS-DMA, 16 rows x 64 bytes = one
     contiguous KiB per instruction."""
 
-    def __init__(self, t: torch.Tensor, c: int):
+    def __init__(self, t: torch.Tensor, c: int, rows: Optional[int] = None):
         if t.dtype != torch.float16 or t.dim() != 4 or t.shape[0] != 2 or t.shape[3] != 32 or not t.is_contiguous() or c > t.shape[1] * 32 \
                 or c <= (t.shape[1] - 1) * 32:
             raise ValueError(f"Planes: expected contiguous fp16 [2, ceil(C/32), rows, 32], got {tuple(t.shape)} {t.dtype} C={c}")
         if not t.is_cuda:
             raise TypeError("Planes: tensor must live on the GPU")
+        if rows is not None and not 0 < rows <= t.shape[2]:
+            raise ValueError(f"Planes: {rows} valid rows do not fit the {t.shape[2]} allocated ones")
         self.t, self.c = t, c
+        self._rows = t.shape[2] if rows is None else rows
 
     @property
     def rows(self):
+        """Rows that hold data.  ``ld_rows`` (>= rows) is the allocated row count = the chunk stride every kernel is given; rows past
+        ``rows`` are never written and stay zero (the 3x3 kernel on plane input reads row ``rows`` for pixels outside the image)."""
+        return self._rows
+
+    @property
+    def ld_rows(self):
         return self.t.shape[2]
 
     @property
@@ -144,11 +154,17 @@ class Planes:
 
     def to_rows(self) -> torch.Tensor:
         """[2, rows, chunks*32] row-major copy (tests / debugging)."""
-        return self.t.permute(0, 2, 1, 3).reshape(2, self.rows, self.chunks * 32)
+        return self.t[:, :, :self.rows].permute(0, 2, 1, 3).reshape(2, self.rows, self.chunks * 32)
+
+    def to_float(self) -> torch.Tensor:
+        """[rows, C] fp32 value hi + lo' / 1024 (tests / debugging)."""
+        r = self.to_rows().float()
+        return (r[0] + r[1] / 1024.0)[:, :self.c]
 
     @staticmethod
     def alloc(rows: int, c: int, device) -> "Planes":
-        return Planes(torch.zeros(2, (c + 31) // 32, rows, 32, dtype=torch.float16, device=device), c)
+        """Zero-initialised planes with one spare (zero) row behind the data."""
+        return Planes(torch.zeros(2, (c + 31) // 32, rows + 1, 32, dtype=torch.float16, device=device), c, rows)
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -311,7 +327,7 @@ class HipOps:
             self._run("conv3x3_f16x3", meta, self.lib.atmvfi_conv3x3_f16x3, _ptr(x), ld, n, h, wd, cin, _ptr(w.hi3), _ptr(w.lo3),
                       cout, _ptr(out), old, _ptr(bias), _ptr(prelu),
                       planes.t[0].data_ptr() if planes is not None else None, planes.t[1].data_ptr() if planes is not None else None,
-                      planes.rows if planes is not None else 0, _ptr(planes_prelu) if planes is not None else None, self._stream())
+                      planes.ld_rows if planes is not None else 0, _ptr(planes_prelu) if planes is not None else None, self._stream())
             return
         if planes is not None:
             raise ValueError("conv: a plane sink needs the 3x3 / stride-1 f16x3 kernel")
@@ -321,6 +337,42 @@ class HipOps:
                        out_row_map=None, bias=_ptr(bias), prelu=_ptr(prelu), in_prelu=_ptr(in_prelu), residual=None, res_ld=0)
         p.precision, p.weight_hi, p.weight_lo = self._prec(w)
         self._run("conv2d_f16x3" if p.precision else "conv2d", meta, self.lib.atmvfi_conv2d, ctypes.byref(p), self._stream())
+
+    def conv3x3_planes(self, x: Planes, n: int, h: int, wd: int, w: PackedWeight, out=None, bias=None, prelu=None,
+                       planes: Optional[Planes] = None, planes_c0: int = 0, planes_prelu=None, in_chunk0: int = 0, cin: Optional[int] = None,
+                       wn: int = 0):
+        """3x3 / stride 1 / pad 1 conv (+bias, PReLU) on split-plane input ``x`` (rows = pixels of an [n,h,wd] map; channels
+        ``32*in_chunk0 .. +cin``).  ``out``: fp32 NHWC view or None; ``planes``: plane sink written at channel offset ``planes_c0``
+        (its own ``planes_prelu`` applied to that copy only).  Needs the spare zero row of ``Planes.alloc``."""
+        cin = (x.c - 32 * in_chunk0) if cin is None else cin
+        if self.precision != "f16x3" or w.hi3 is None:
+            raise ValueError("conv3x3_planes: needs the f16x3 engine and the conv3x3 weight planes")
+        if w.mode != GEMM_CONV or w.kh != 3 or w.kw != 3 or w.cin != cin:
+            raise ValueError(f"conv3x3_planes: weight ({w.cout},{w.cin},{w.kh},{w.kw}) does not match Cin {cin}")
+        if x.rows != n * h * wd or x.ld_rows <= x.rows or 32 * in_chunk0 + cin > x.chunks * 32:
+            raise ValueError(f"conv3x3_planes: input planes [{x.rows} (+{x.ld_rows - x.rows} spare), {x.c}] do not fit {n}x{h}x{wd} pixels x {cin} channels "
+                             "(one spare zero row is required)")
+        cout = w.cout
+        old = 0
+        if out is not None:
+            old, on, oh, ow, oc = nhwc_view(out, "conv3x3_planes.out")
+            if (on, oh, ow, oc) != (n, h, wd, cout):
+                raise ValueError(f"conv3x3_planes: out {tuple(out.shape)} != [{n},{h},{wd},{cout}]")
+        elif planes is None:
+            raise ValueError("conv3x3_planes: no output")
+        if planes is not None:
+            if planes.rows != n * h * wd or planes_c0 % 4 or planes_c0 + cout > planes.chunks * 32:
+                raise ValueError(f"conv3x3_planes: plane sink [{planes.rows},{planes.c}] cannot take {cout} channels at offset {planes_c0}")
+            if planes_prelu is not None and planes_prelu.numel() < (cout + 31) // 32 * 32:
+                raise ValueError("conv3x3_planes: planes_prelu must be padded to a multiple of 32 channels")
+        meta = {"flops": 2.0 * n * h * wd * cout * cin * 9, "bytes": 4.0 * (n * h * wd * (cin + cout) + cout * cin * 9),
+                "shape": f"M{n * h * wd} N{cout} K{cin * 9}"}
+        coff = in_chunk0 * x.ld_rows * 32 * 2       # bytes
+        self._run("conv3x3_planes", meta, self.lib.atmvfi_conv3x3_planes, x.t[0].data_ptr() + coff, x.t[1].data_ptr() + coff, x.ld_rows,
+                  n, h, wd, cin, _ptr(w.hi3), _ptr(w.lo3), cout, _ptr(out), old, _ptr(bias), _ptr(prelu),
+                  planes.t[0].data_ptr() if planes is not None else None, planes.t[1].data_ptr() if planes is not None else None,
+                  planes.ld_rows if planes is not None else 0, planes_c0, _ptr(planes_prelu) if planes is not None else None, wn,
+                  self._stream())
 
     def deconv(self, x, w: PackedWeight, out, bias=None, prelu=None, in_prelu=None, planes: Optional[Planes] = None):
         """``planes``: the input rows [N*H*W, Cin] again in split-plane form (already through in_prelu): the LDS-DMA GEMM
@@ -338,7 +390,7 @@ class HipOps:
         if use_planes:
             if planes.rows < n * h * wd or planes.c != cin:
                 raise ValueError("deconv: planes do not match the input rows")
-            p.in_, p.in_ld, p.in_prelu = None, planes.rows, None
+            p.in_, p.in_ld, p.in_prelu = None, planes.ld_rows, None
             p.in_hi, p.in_lo = planes.t[0].data_ptr(), planes.t[1].data_ptr()
         meta = {"flops": 2.0 * n * h * wd * 4 * cout * cin, "bytes": 4.0 * (n * h * wd * cin + n * oh * ow * cout + 4 * cout * cin),
                 "shape": f"M{n * h * wd} N{4 * cout} K{cin}"}
@@ -356,14 +408,14 @@ class HipOps:
             raise ValueError("split_planes: prelu needs one slope per channel")
         meta = {"bytes": 4.0 * m * c + 4.0 * m * out.chunks * 32}
         self._run("split_planes", meta, self.lib.atmvfi_split_planes, _ptr(x), ld, m, c, _ptr(prelu), out.t[0].data_ptr(),
-                  out.t[1].data_ptr(), out.rows, self._stream())
+                  out.t[1].data_ptr(), out.ld_rows, self._stream())
 
     def linear(self, x, w: PackedWeight, out, bias=None, residual=None, out_row_map=None):
         planes = x if isinstance(x, Planes) else None
         if planes is not None:
             if self.precision != "f16x3" or w.hi is None:
                 raise ValueError("linear: split-plane input needs the f16x3 engine and split weights")
-            ld, m, cin, gs, rpg = planes.rows, planes.rows, planes.c, 0, 0
+            ld, m, cin, gs, rpg = planes.ld_rows, planes.rows, planes.c, 0, 0
         else:
             ld, m, cin, gs, rpg = rows_view(x, "linear.in")
         old, mo, cout, ogs, orpg = rows_view(out, "linear.out")
@@ -396,7 +448,7 @@ class HipOps:
             return None, None, 0
         if planes.rows != rows or planes.c != c:
             raise ValueError(f"{what}: planes hold {planes.rows} x {planes.c}, kernel writes {rows} x {c}")
-        return planes.t[0].data_ptr(), planes.t[1].data_ptr(), planes.rows
+        return planes.t[0].data_ptr(), planes.t[1].data_ptr(), planes.ld_rows
 
     def layernorm(self, x, out, gamma, beta, src_row_map=None, planes: Optional[Planes] = None):
         """``out`` (fp32 rows) may be None when only the split planes are wanted."""

@@ -678,7 +678,7 @@ def test_conv3x3_plane_sink(schedule, hip, dev):
             hip.split_planes(y0[..., :cout].flatten(0, 2), q, prelu=slopes)
             torch.cuda.synchronize()
             assert torch.equal(y0, y1)
-            assert torch.equal(p.t[:, :, :n * h * w], q.t)
+            assert torch.equal(p.t[:, :, :n * h * w], q.t[:, :, :n * h * w])
             assert (p.t[:, :, n * h * w:] == 0).all()
             # and through the consumer: deconv from the sink's planes == deconv from the split pass's
             if slopes is not None:
@@ -692,3 +692,65 @@ def test_conv3x3_plane_sink(schedule, hip, dev):
                 assert torch.equal(z0, z1)
     finally:
         hip.lib.atmvfi_conv3x3_set_schedule(-1, 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wn", list(range(1, 9)))
+def test_conv3x3_planes_every_width(wn, hip, cpu, dev):
+    """The 3x3 kernel on split-plane input (LDS-DMA halo, ping-pong wave groups), every tile width: ragged image, two images,
+    channel counts with a 5- and an 8-channel tap-packed tail, without a tail, and tail-only (Cin = 8).  Must equal the fp32-input
+    kernel BIT FOR BIT (same split, same k order), and the CPU restatement within the contraction tolerance; the plane sink at a
+    channel offset must be the exact split of the fp32 result."""
+    g = torch.Generator().manual_seed(7000 + wn)
+    r4 = lambda c: (c + 3) // 4 * 4
+    N, H, W = 2, 21, 35
+    for cin in (37, 64, 104, 8):
+        cout = 2 * 16 * wn - (5 if wn % 2 else 0)            # two column blocks, the second one partial for odd wn
+        x = rnd(g, N, H, W, r4(cin))[..., :cin]
+        w = rnd(g, cout, cin, 3, 3, scale=1.0 / np.sqrt(9 * cin))
+        bias = rnd(g, cout, scale=0.2)
+        slope = torch.rand(cout, generator=g) * 0.4
+        oc = torch.empty(N, H, W, r4(cout))[..., :cout]
+        cpu.conv(x, cpu.pack_weight(GEMM_CONV, w), oc, 1, 1, 1, bias, slope)
+        xg = torch.zeros(N, H, W, r4(cin), device=dev)
+        xg[..., :cin] = x.to(dev)
+        pw = hip.pack_weight(GEMM_CONV, w.to(dev))
+        y0 = torch.full((N, H, W, r4(cout)), 7.0, device=dev)
+        hip.conv(xg[..., :cin], pw, y0[..., :cout], 1, 1, 1, bias.to(dev), slope.to(dev))
+        xp = hip_ops.Planes.alloc(N * H * W, cin, dev)
+        hip.split_planes(xg[..., :cin].flatten(0, 2), xp)
+        y1 = torch.full((N, H, W, r4(cout)), 7.0, device=dev)
+        c0 = 8
+        sink = hip_ops.Planes.alloc(N * H * W, c0 + cout, dev)
+        hip.conv3x3_planes(xp, N, H, W, pw, out=y1[..., :cout], bias=bias.to(dev), prelu=slope.to(dev), planes=sink, planes_c0=c0, wn=wn)
+        only = hip_ops.Planes.alloc(N * H * W, cout, dev)
+        hip.conv3x3_planes(xp, N, H, W, pw, out=None, bias=bias.to(dev), prelu=slope.to(dev), planes=only, wn=wn)
+        q = hip_ops.Planes.alloc(N * H * W, cout, dev)
+        hip.split_planes(y0[..., :cout].flatten(0, 2), q)
+        torch.cuda.synchronize()
+        assert torch.equal(y0, y1), (wn, cin, maxdiff(y0, y1))
+        assert maxdiff(y1[..., :cout], oc) <= 1e-4, (wn, cin)
+        assert torch.equal(only.t, q.t), (wn, cin)
+        got = sink.to_rows()[:, :, c0:c0 + cout]
+        assert torch.equal(got, q.to_rows()[:, :, :cout]), (wn, cin)
+        assert (sink.to_rows()[:, :, :c0] == 0).all() and (sink.t[:, :, N * H * W:] == 0).all()
+
+
+@pytest.mark.gpu
+def test_conv3x3_planes_chunk_offset_and_auto_width(hip, dev):
+    """Input view starting at a 32-channel chunk of wider planes, automatic tile width, a large-ish ragged map: equals the fp32 kernel."""
+    g = torch.Generator().manual_seed(7100)
+    N, H, W, cin, cout = 1, 50, 70, 69, 101
+    xb = rnd(g, N, H, W, 32 + 72, scale=1.5).to(dev)
+    x = xb[..., 32:32 + cin]
+    wt = rnd(g, cout, cin, 3, 3, scale=1.0 / np.sqrt(9 * cin)).to(dev)
+    bias = rnd(g, cout, scale=0.2).to(dev)
+    pw = hip.pack_weight(GEMM_CONV, wt)
+    y0 = torch.empty(N, H, W, 104, device=dev)
+    hip.conv(x, pw, y0[..., :cout], 1, 1, 1, bias, None)
+    xp = hip_ops.Planes.alloc(N * H * W, 32 + cin, dev)
+    hip.split_planes(xb[..., :32 + cin].flatten(0, 2), xp)
+    y1 = torch.empty(N, H, W, 104, device=dev)
+    hip.conv3x3_planes(xp, N, H, W, pw, out=y1[..., :cout], bias=bias, in_chunk0=1, cin=cin)
+    torch.cuda.synchronize()
+    assert torch.equal(y0[..., :cout], y1[..., :cout])
