@@ -8,7 +8,8 @@
 //     PRODUCING layer wrote in its epilogue, so the (16+2)x(16+2) halo of a chunk goes global -> LDS by LDS-DMA
 //     (global_load_lds_dwordx4: no VGPR, no VALU split, no ds_write); pixels outside the image read a page of zeros.  The halo
 //     is double-buffered: chunk c+1 lands while chunk c is consumed;
-//   * the weights of one k-step (one tap x 32 channels) are one slot of a 4-deep LDS ring, filled three k-steps ahead;
+//   * the weights of one k-step (one tap x 32 channels) are one slot of an LDS ring of 4-6 slots (whatever fits beside the two
+//     halo buffers), filled ring - 1 k-steps ahead;
 //   * the eight waves form two groups (waves 0-3 / 4-7 = the two waves of each SIMD) that run ONE PHASE APART: while a group
 //     issues the 6*WN MFMAs of k-step u from registers, its SIMD partners read the fragments of their next k-step from LDS and
 //     issue their share of the DMA; a raw s_barrier swaps the roles.  The matrix pipe of a SIMD is therefore always fed by one of
@@ -20,10 +21,24 @@
 //     reads of k-step u (lgkmcnt(0)) at the END of its read phase, before the barrier; the group that reads k-step u+1 first
 //     does so after the barrier that follows the later group's wait;
 //   * a ring slot / halo buffer is refilled by a DMA issued at least one barrier after its last reader's lgkmcnt(0).
-// vmcnt bookkeeping is dynamic and per wave (waves issue different numbers of pieces): `issued` counts the wave's DMA
-// instructions, mark[k-step & 3] remembers the count after the pieces of that k-step (and every halo piece before them) went out;
-// the wait is vmcnt(issued - mark), through a switch on a wave-uniform value (s_waitcnt only takes an immediate).
+// Every wave issues the same number of DMA instructions in every phase (a wave without a piece of its own repeats one), and the
+// k-loop has no branch: the vmcnt waits are immediates.
 #include "conv3_common.h"
+
+#include <stdlib.h>
+
+#ifdef ATMVFI_STAMP
+// Diagnostic build only (`make stamp`, tools/stamp_conv3p.py): per-wave s_memtime sums of the phases of a k-step.
+static unsigned long long* g_planes_stamp = nullptr;
+extern "C" void atmvfi_debug_set_planes_stamp_buffer(void* p) { g_planes_stamp = (unsigned long long*)p; }
+#define PDBG(bit) ((a.dbg & (bit)) != 0)
+#define PSTAMP_DECL unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
+#define PSTAMP(k) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); st_[k] += t1_ - st_t0; st_t0 = t1_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define PDBG(bit) false
+#define PSTAMP_DECL
+#define PSTAMP(k)
+#endif
 
 namespace {
 
@@ -46,28 +61,23 @@ struct Conv3PDev {
     int out_c0;
     const float* plane_prelu;   // optional PReLU applied to the plane copy only (the next layer's leading activation)
     int tiles_x, tiles_y, nblocks, tchunk;
+    unsigned long long* stamp;  // diagnostic builds only (ATMVFI_STAMP)
+    int dbg;                    // diagnostic builds only: ATMVFI_P3_DBG bits switch pieces of the loop off (wrong results, timing only)
 };
 
-constexpr int NB_W = 4;                       // weight ring slots (k-steps)
-constexpr int LOOKAHEAD = 3;                  // k-steps between a slot's DMA issue and its first read
 constexpr int HALO_PIX = HW_ * HW_;           // 324
 constexpr int HALO_PLANE_PIECES = (HALO_PIX + 15) / 16;     // 21 one-KiB pieces (16 pixel rows x 64 B) per plane, 12 pad rows
 constexpr int HALO_LO = HALO_PLANE_PIECES * 1024;            // byte offset of the lo plane inside a halo buffer
 constexpr int HALO_BYTES = 2 * HALO_LO;
 
+// weight ring depth: as many k-steps as fit beside the two halo buffers and the epilogue constants in 160 KiB, at most 5
+constexpr int ring_slots(int wn) {
+    const int free_bytes = 160 * 1024 - 2 * HALO_BYTES - 2048;
+    const int n = free_bytes / (2 * 16 * wn * 64);
+    return n > 5 ? 5 : n;            // the static vmcnt counts of the k-loop assume a lookahead of at most 4 k-steps
+}
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-// vmcnt(min(n, 7)) for a wave-uniform n = operations that may stay outstanding (s_waitcnt only takes an immediate; waiting for a
-// smaller count than allowed is always safe).  A three-level decision tree: the switch hipcc builds costs ~40 scalar instructions.
-__device__ __forceinline__ void wait_vm_dyn(int n) {
-    if (n >= 4) {
-        if (n >= 6) { if (n >= 7) wait_vm<7>(); else wait_vm<6>(); }
-        else { if (n == 5) wait_vm<5>(); else wait_vm<4>(); }
-    } else {
-        if (n >= 2) { if (n == 3) wait_vm<3>(); else wait_vm<2>(); }
-        else { if (n == 1) wait_vm<1>(); else wait_vm<0>(); }
-    }
-}
 __device__ __forceinline__ void dma16(const unsigned char* src, unsigned char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
@@ -78,10 +88,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
     constexpr int BN = 16 * WN;
     constexpr int WSLOT = 2 * BN * 64;                  // bytes of one ring slot: [hi BN rows][lo BN rows] x 64 B
     constexpr int SW = (2 * WN + 7) / 8;                // weight pieces per wave and k-step (some waves one fewer)
+    constexpr int NB = ring_slots(WN);                  // weight ring slots (k-steps)
+    constexpr int LA = NB - 1;                          // k-steps between a slot's DMA issue and its first read
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned halo0 = lds_offset(smem);                        // two halo buffers
-    const unsigned ring0 = halo0 + 2 * HALO_BYTES;                  // NB_W weight slots
-    float* cst = reinterpret_cast<float*>(smem + 2 * HALO_BYTES + NB_W * WSLOT);
+    const unsigned ring0 = halo0 + 2 * HALO_BYTES;                  // NB weight slots
+    float* cst = reinterpret_cast<float*>(smem + 2 * HALO_BYTES + NB * WSLOT);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -116,7 +128,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
     const long long zero_row = (long long)a.N * a.H * a.W;
 #pragma unroll
     for (int s = 0; s < 6; ++s) {
-        const int k = wave + 8 * s;
+        int k = wave + 8 * s;
+        if (k >= 2 * HALO_PLANE_PIECES) k -= 8;      // waves 2..7 have no sixth piece: they send their fifth twice (see below)
         const int kp = k >= HALO_PLANE_PIECES ? k - HALO_PLANE_PIECES : k;
         const int hp = 16 * kp + (lane >> 2);
         const int hy = hp / HW_, hx = hp - hy * HW_;
@@ -126,43 +139,59 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
         const long long row = ok ? ((long long)img * a.H + iy) * a.W + ix : zero_row;
         hoff[s] = (unsigned)(row * 64 + ls * 16);
     }
-    const long long chunk_halves = a.in_rows * 32;
-    // ---- weight pieces of this wave: idx = wave + 8 s < 2 WN -> plane idx / WN, row group idx % WN (16 rows x 64 B = one
-    // contiguous KiB of the k-step-major planes); the lane part of the address is the same for every piece
+    const long long chunk_bytes = a.in_rows * 64;
+    // ---- DMA schedule.  Everything in the k-loop is branch-free and the same for every wave, so that the vmcnt waits are plain
+    // immediates: a taken scalar branch costs 20-40 cycles and the first version of this loop had ten per read phase (validity
+    // of a piece, end of the k-steps, a decision tree around s_waitcnt: 230 ticks of a 900-tick phase, tools/stamp_conv3p.py).
+    //   * weights: SW pieces per wave and k-step; piece idx = wave + 8 s -> plane idx / WN, row group idx % WN (16 rows x 64 B =
+    //     one contiguous KiB of the k-step-major planes).  A wave without a piece s (idx >= 2 WN) sends its piece s - 1 again:
+    //     same bytes to the same place.  Past the last k-step the source stops advancing: the last k-step's weights are sent again
+    //     into ring slots nobody reads any more.
+    //   * halo of the next chunk: piece wave + 8 t in k-step t = 0..5; without a next chunk the pieces of the current chunk go to
+    //     the other (idle) buffer.
     const unsigned wlane = (unsigned)((lane >> 2) * 64 + (((lane & 3) ^ swz64(lane >> 2)) << 4));
-    const long long step_halves = (long long)a.wrows * 32;
+    const long long step_bytes = (long long)a.wrows * 64;
+    const unsigned char* wsrc[SW];          // wave-uniform source of piece s at the next k-step to issue
+    int wdst[SW];                           // its byte offset inside a ring slot
+#pragma unroll
+    for (int s = 0; s < SW; ++s) {
+        int idx = wave + 8 * s;
+        if (idx >= 2 * WN) idx -= 8;
+        const int ic = idx >= 0 ? idx : 0;                       // (WN < 4: waves >= 2 WN have no piece at all and send piece 0)
+        const int icc = ic < 2 * WN ? ic : 0;
+        const int plane = icc >= WN ? 1 : 0;
+        const int j = icc - plane * WN;
+        int rg = n0 + 16 * j;
+        if (rg >= a.wrows) rg = a.wrows - 16;                    // row groups past the packed rows: columns never stored
+        wsrc[s] = reinterpret_cast<const unsigned char*>(plane ? a.w_lo : a.w_hi) + (long long)rg * 64;
+        wdst[s] = (plane * BN + 16 * j) * 64;
+    }
 
     const int nfull = a.cf >> 5;
     const int nchunks = nfull + (a.tail ? 1 : 0);
     const int nk = 9 * nfull + (a.tail ? 3 : 0);
 
-    int issued = 0;                       // DMA instructions this wave has issued
-    int mark[4] = {0, 0, 0, 0};           // issued count right after the pieces of k-step (u & 3)
-    auto issue_weights = [&](int u) {     // weights of k-step u -> ring slot u % NB_W
-        unsigned char* dst = smem + 2 * HALO_BYTES + (u & (NB_W - 1)) * WSLOT;
+    int wr_off = 0;                       // ring slot (byte offset) the next weight issue goes to
+    int kleft = nk - 1;                   // k-steps after the one whose weights are issued next
+    auto issue_weights = [&]() {          // weights of the next k-step -> next ring slot
+        unsigned char* dst = smem + 2 * HALO_BYTES + wr_off;
+        const long long adv = kleft > 0 ? step_bytes : 0;
 #pragma unroll
         for (int s = 0; s < SW; ++s) {
-            const int idx = wave + 8 * s;
-            if (idx < 2 * WN) {
-                const int plane = idx >= WN ? 1 : 0;
-                const int j = idx - plane * WN;
-                int rg = n0 + 16 * j;
-                if (rg >= a.wrows) rg = a.wrows - 16;                    // row groups past the packed rows: columns never stored
-                const _Float16* base = (plane ? a.w_lo : a.w_hi) + u * step_halves + (long long)rg * 32;      // wave-uniform
-                dma16(reinterpret_cast<const unsigned char*>(base) + wlane, dst + (plane * BN + 16 * j) * 64);
-                ++issued;
-            }
+            dma16(wsrc[s] + wlane, dst + wdst[s]);
+            wsrc[s] += adv;
         }
-        mark[u & 3] = issued;
+        --kleft;
+        wr_off = wr_off + WSLOT == NB * WSLOT ? 0 : wr_off + WSLOT;
     };
-    auto issue_halo = [&](int chunk, auto sc) {       // halo piece wave + 8 S of `chunk` -> buffer chunk & 1
+    const unsigned char* hsrc_hi = reinterpret_cast<const unsigned char*>(a.in_hi);      // plane bases of the chunk whose halo is issued next
+    const unsigned char* hsrc_lo = reinterpret_cast<const unsigned char*>(a.in_lo);
+    int hbuf = 0;                         // halo buffer (byte offset) that chunk goes to
+    auto issue_halo = [&](auto sc) {      // halo piece wave + 8 S (waves 2..7, S = 5: piece wave + 32 again)
         constexpr int S = decltype(sc)::value;
-        const int k = wave + 8 * S;
-        if (k < 2 * HALO_PLANE_PIECES) {
-            const _Float16* base = (k >= HALO_PLANE_PIECES ? a.in_lo : a.in_hi) + chunk * chunk_halves;          // wave-uniform
-            dma16(reinterpret_cast<const unsigned char*>(base) + hoff[S], smem + (chunk & 1) * HALO_BYTES + k * 1024);
-            ++issued;
-        }
+        int k = wave + 8 * S;
+        if (S == 5 && k >= 2 * HALO_PLANE_PIECES) k -= 8;
+        dma16((k >= HALO_PLANE_PIECES ? hsrc_lo : hsrc_hi) + hoff[S], smem + hbuf + k * 1024);
     };
 
     f32x4 acc[2][WN], cor[2][WN];
@@ -183,59 +212,93 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
         dtail |= (ty * HW_ + (tap - 3 * ty)) << (8 * t);
     }
 
-    // ---- prologue: epilogue constants, halo of chunk 0, weights of k-steps 0 .. LOOKAHEAD-1 ----
+    PSTAMP_DECL
+    // ---- prologue: epilogue constants, halo of chunk 0, weights of k-steps 0 .. LA-1 ----
     dma_epilogue_consts<BN>(a.bias, a.prelu, n0, cst, wave, lane, [&](int col) { return col < a.Cout ? col : -1; });
-    ++issued;
-    static_for<0, 6>([&](auto sc) { issue_halo(0, sc); });
+    static_for<0, 6>([&](auto sc) { issue_halo(sc); });
+    int chunks_left = nchunks - 1;        // chunks after the one whose halo is issued next
+    {
+        const long long adv = chunks_left > 0 ? chunk_bytes : 0;
+        hsrc_hi += adv;
+        hsrc_lo += adv;
+        --chunks_left;
+        hbuf = HALO_BYTES;
+    }
 #pragma unroll
-    for (int u = 0; u < LOOKAHEAD; ++u)
-        if (u < nk) issue_weights(u);
-    wait_vm_dyn(issued - mark[0]);
+    for (int u = 0; u < LA; ++u) issue_weights();
+    wait_vm<(LA - 1) * SW>();             // everything up to the weights of k-step 0 has landed
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();          // the second group runs one phase behind
+    PSTAMP(0)
 
     f16x8 xh[2], xl[2], wh[WN], wl[WN];
     const unsigned wfrag = ring0 + (unsigned)(r * 64 + ((g ^ swz64(r)) << 4));       // swz64(16 j + r) == swz64(r)
     const int prow = 2 * wave * HW_ + r;                                                // halo pixel of (row 2 wave, column r), tap (0,0)
+    // Activation-fragment addresses without per-read arithmetic: the fragment of tap offset C sits at pixel p = prow + C, slot
+    // g ^ swz64(p), and swz64(p) only depends on bit 2 of p, i.e. on prow and C mod 8: eight per-lane bases XA[C & 7] (current halo
+    // buffer; moved to the other buffer once per chunk) + the immediate 64 * C.
+    unsigned xa[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) xa[k] = halo0 + (unsigned)(prow * 64 + ((g ^ swz64(prow + k)) << 4));
+    int rd_off = 0;                       // ring slot (byte offset) of the k-step being read
+    int hcur = 0;                         // halo buffer of the chunk being read
 
-    // One k-step of one wave.  T = tap (regular chunk) or tail step; u = global k-step index, chunk = its 32-channel chunk.
-    auto kstep = [&](auto tc, auto tailc, int u, int chunk) {
+    // One k-step of one wave.  T = tap (regular chunk) or tail step.
+    auto kstep = [&](auto tc, auto tailc) {
         constexpr int T = decltype(tc)::value;
         constexpr bool TAIL = decltype(tailc)::value;
         // ---------------- read phase ----------------
-        const unsigned hb = halo0 + (unsigned)(chunk & 1) * HALO_BYTES;
-        int pr = prow;
-        asm volatile("" : "+v"(pr));       // opaque: keeps hipcc from hoisting the 18 fragment addresses of a chunk out of the loop
+        if constexpr (!TAIL) {
+            constexpr int C0 = (T / 3) * HW_ + T % 3, C1 = C0 + HW_;       // tap offsets of the wave's two pixel rows
+            lds_read16<64 * C0>(xh[0], xa[C0 & 7]);
+            lds_read16<64 * C0 + HALO_LO>(xl[0], xa[C0 & 7]);
+            lds_read16<64 * C1>(xh[1], xa[C1 & 7]);
+            lds_read16<64 * C1 + HALO_LO>(xl[1], xa[C1 & 7]);
+        } else {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int p = pr + i * HW_ + (TAIL ? ((dtail >> (TAIL ? 8 * T : 0)) & 0xff) : (T / 3) * HW_ + T % 3);
-            const int sl = TAIL ? 0 : g;
-            const unsigned addr = hb + (unsigned)(p * 64 + ((sl ^ swz64(p)) << 4));
-            lds_read16<0>(xh[i], addr);
-            lds_read16<HALO_LO>(xl[i], addr);
+            for (int i = 0; i < 2; ++i) {
+                const int p = prow + i * HW_ + ((dtail >> (TAIL ? 8 * T : 0)) & 0xff);
+                const unsigned addr = halo0 + (unsigned)hcur + (unsigned)(p * 64 + (swz64(p) << 4));
+                lds_read16<0>(xh[i], addr);
+                lds_read16<HALO_LO>(xl[i], addr);
+            }
         }
-        const unsigned wa = wfrag + (unsigned)(u & (NB_W - 1)) * WSLOT;
+        const unsigned wa = wfrag + (unsigned)rd_off;
         static_for<0, WN>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             lds_read16<j * 1024>(wh[j], wa);
             lds_read16<j * 1024 + BN * 64>(wl[j], wa);
         });
-        // DMA: halo of the next chunk (k-steps 0..5 of a regular chunk), weights LOOKAHEAD k-steps ahead
+        rd_off = rd_off + WSLOT == NB * WSLOT ? 0 : rd_off + WSLOT;
+        PSTAMP(1)
+        // DMA: weights LA k-steps ahead first, then one halo piece of the next chunk (k-steps 0..5 of a regular chunk): the wait
+        // for a k-step's weights then never covers the halo piece issued in the same phase (vmcnt retires in order, and the halo
+        // comes from HBM while the weights come from L2)
+        if (!PDBG(2)) issue_weights();
         if constexpr (!TAIL && T < 6) {
-            if (chunk + 1 < nchunks) issue_halo(chunk + 1, std::integral_constant<int, T>{});
+            if (!PDBG(1)) issue_halo(std::integral_constant<int, T>{});
         }
-        if (u + LOOKAHEAD < nk) issue_weights(u + LOOKAHEAD);
-        // own pieces of k-step u+1 landed (younger ones stay in flight), own fragment reads complete
-        if (u + 1 < nk) wait_vm_dyn(issued - mark[(u + 1) & 3]);
+        PSTAMP(2)
+        // Own pieces of the next k-step landed, own fragment reads complete.  The weights of the next k-step were issued LA - 1
+        // read phases ago; behind them went SW weight pieces per phase and one halo piece in each of the phases t' = T+1-LA .. T
+        // of this chunk with 0 <= t' < 6 (phases of the previous chunk that far back carry none: LA <= 4).
+        {
+            constexpr int lo = T + 1 - LA > 0 ? T + 1 - LA : 0, hi = T < 5 ? T : 5;
+            constexpr int halos = (!TAIL && hi >= lo) ? hi - lo + 1 : 0;
+            if (!PDBG(4)) wait_vm<(LA - 1) * SW + halos>();
+        }
+        PSTAMP(3)
         asm volatile("s_waitcnt lgkmcnt(0)"
                      : "+v"(xh[0]), "+v"(xh[1]), "+v"(xl[0]), "+v"(xl[1]));
 #pragma unroll
         for (int j = 0; j < WN; ++j) asm volatile("" : "+v"(wh[j]), "+v"(wl[j]));
         __builtin_amdgcn_sched_barrier(0);
+        PSTAMP(4)
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        PSTAMP(5)
         // ---------------- MFMA phase ----------------
-        __builtin_amdgcn_s_setprio(1);
+        if (!PDBG(8)) __builtin_amdgcn_s_setprio(1);
         static_for<0, WN>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             cor[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j], xh[0], cor[0][j], 0, 0, 0);
@@ -247,14 +310,30 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
         });
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
+        PSTAMP(6)
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        PSTAMP(7)
+    };
+    // the chunk being read moves to the other halo buffer; so does the chunk whose halo is issued next
+    auto next_chunk = [&]() {
+        const int d = hcur ? -HALO_BYTES : HALO_BYTES;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) xa[k] += d;
+        hcur += d;
+        const long long adv = chunks_left > 0 ? chunk_bytes : 0;
+        hsrc_hi += adv;
+        hsrc_lo += adv;
+        --chunks_left;
+        hbuf = HALO_BYTES - hbuf;
     };
 
-    for (int c = 0; c < nfull; ++c)
-        static_for<0, 9>([&](auto tc) { kstep(tc, std::false_type{}, 9 * c + decltype(tc)::value, c); });
+    for (int c = 0; c < nfull; ++c) {
+        static_for<0, 9>([&](auto tc) { kstep(tc, std::false_type{}); });
+        next_chunk();
+    }
     if (a.tail)
-        static_for<0, 3>([&](auto tc) { kstep(tc, std::true_type{}, 9 * nfull + decltype(tc)::value, nfull); });
+        static_for<0, 3>([&](auto tc) { kstep(tc, std::true_type{}); });
     if (grp == 0) __builtin_amdgcn_s_barrier();          // same number of barriers for both groups
 
     // ---- epilogue (as conv3x3_f16x3_row.hip) ----
@@ -321,12 +400,21 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
             }
         }
     }
+#ifdef ATMVFI_STAMP
+    if (a.stamp && lane == 0) {
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+        unsigned long long* o = a.stamp + ((long long)blockIdx.x * 8 + wave) * 10;
+        for (int k = 0; k < 8; ++k) o[k] = st_[k];
+        o[8] = t_end - st_t0;     // epilogue
+        o[9] = (unsigned long long)nk;
+    }
+#endif
 }
 
 template <int WN>
 int launch_planes(const Conv3PDev& d, int ntiles, hipStream_t s) {
     constexpr int BN = 16 * WN;
-    const size_t lds = (size_t)2 * HALO_BYTES + (size_t)NB_W * 2 * BN * 64 + epilogue_const_floats(BN) * sizeof(float);
+    const size_t lds = (size_t)2 * HALO_BYTES + (size_t)ring_slots(WN) * 2 * BN * 64 + epilogue_const_floats(BN) * sizeof(float);
     auto kern = conv3x3_planes_kernel<WN>;
     static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     ATMVFI_REQUIRE(attr_err == hipSuccess, ATMVFI_ELAUNCH, "conv3x3_planes: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
@@ -335,6 +423,14 @@ int launch_planes(const Conv3PDev& d, int ntiles, hipStream_t s) {
     ds.tiles_y = (d.H + 15) / 16;
     const long long sgroups = ((long long)d.N * d.tiles_x * ds.tiles_y + 7) / 8;
     ds.tchunk = (int)sgroups;
+#ifdef ATMVFI_STAMP
+    ds.stamp = g_planes_stamp;
+    static const int dbg = [] { const char* e = getenv("ATMVFI_P3_DBG"); return e ? atoi(e) : 0; }();
+    ds.dbg = dbg;
+#else
+    ds.stamp = nullptr;
+    ds.dbg = 0;
+#endif
     ATMVFI_REQUIRE(sgroups * 8 * ds.nblocks < (1LL << 31), ATMVFI_EINVAL, "conv3x3_planes: grid too large");
     hipLaunchKernelGGL(kern, dim3((unsigned)(sgroups * 8 * ds.nblocks)), dim3(512), lds, s, ds);
     return atmvfi::check_launch("conv3x3_planes");

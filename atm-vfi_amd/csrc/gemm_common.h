@@ -46,12 +46,21 @@ struct GemmDev {
     int mchunk;       // row tiles per XCD = ceil(row tiles / 8)
     int vblocks;      // virtual blocks (tiles incl. XCD padding) walked by the persistent grid
     int nblocks;      // column blocks per row tile (set by the launcher; XCD-aware tile order)
+    // optional plane sink of the f16x3 engines: the result again (or only: `out` may then be null) as split planes, chunk major
+    // (common.h RowSink), channel co of output row r at plane row / channel (r % out_rpg, out_c0 + (r / out_rpg) * out_gc + co)
+    // (out_rpg == 0: (r, out_c0 + co)); DECONV: r = output pixel
+    _Float16* out_hi;
+    _Float16* out_lo;
+    long long out_plane_rows;
+    int out_c0, out_gc;
 };
 
 
 // Output row of GEMM row m: NHWC pixel (CONV), scattered/grouped token row (LINEAR) or the (0,0)
 // position of the 2x2 output patch (DECONV).  Returns false when the row is dropped by the map.
-__device__ __forceinline__ bool gemm_out_row(const GemmDev& a, long long m, float*& orow, const float*& rrow) {
+// prow / pc0: row and first channel of the row in the optional plane sink.
+__device__ __forceinline__ bool gemm_out_row(const GemmDev& a, long long m, float*& orow, const float*& rrow, long long& prow, int& pc0) {
+    pc0 = a.out_c0;
     if (a.mode == ATMVFI_GEMM_DECONV) {
         const int hw = a.H * a.W;
         // 32-bit division whenever the row index allows (always, for this network): the 64-bit one is ~70 instructions per row
@@ -59,17 +68,29 @@ __device__ __forceinline__ bool gemm_out_row(const GemmDev& a, long long m, floa
         const int rem = (int)(m - (long long)n * hw);
         const int y = rem / a.W;
         const int x = rem - y * a.W;
-        orow = a.out + (((long long)n * a.Ho + 2 * y) * a.Wo + 2 * x) * a.out_ld;
+        prow = ((long long)n * a.Ho + 2 * y) * a.Wo + 2 * x;
+        orow = a.out + prow * a.out_ld;
     } else {
         long long ro = m;
         if (a.out_row_map) ro = a.out_row_map[m];
         if (ro < 0) return false;
-        const long long off = (a.out_rpg > 0) ? (ro / a.out_rpg) * a.out_gstride + (ro % a.out_rpg) * (long long)a.out_ld
-                                              : ro * (long long)a.out_ld;
+        prow = ro;
+        long long off = ro * (long long)a.out_ld;
+        if (a.out_rpg > 0) {
+            const long long grp = ro / a.out_rpg;
+            prow = ro - grp * a.out_rpg;
+            off = grp * a.out_gstride + prow * (long long)a.out_ld;
+            pc0 += (int)grp * a.out_gc;
+        }
         orow = a.out + off;
     }
     rrow = a.residual ? a.residual + m * (long long)a.res_ld : nullptr;
     return true;
+}
+__device__ __forceinline__ bool gemm_out_row(const GemmDev& a, long long m, float*& orow, const float*& rrow) {
+    long long prow;
+    int pc0;
+    return gemm_out_row(a, m, orow, rrow, prow, pc0);
 }
 
 // Per-n-tile channel constants (bias, PReLU slope) of GEMM columns nb..nb+3, loaded ONCE per tile as
@@ -168,22 +189,35 @@ __device__ __forceinline__ ChanPos gemm_chan_pos(const GemmDev& a, int nb) {
     return c;
 }
 // v: four consecutive GEMM columns of one row; b, p: their bias / slope (from LDS); res: residual values (or zero)
-__device__ __forceinline__ void gemm_finish_store4(const GemmDev& a, float* orow, const ChanPos& c, f32x4 v, const f32x4 b, const f32x4 p,
-                                                   const f32x4 res) {
-    float* optr = orow;
-    if (a.mode == ATMVFI_GEMM_DECONV) optr = orow + ((long long)(c.q >> 1) * a.Wo + (c.q & 1)) * a.out_ld;
+// prow / pc0: the row's position in the optional plane sink (gemm_out_row)
+__device__ __forceinline__ void gemm_finish_store4(const GemmDev& a, float* orow, long long prow, int pc0, const ChanPos& c, f32x4 v,
+                                                   const f32x4 b, const f32x4 p, const f32x4 res) {
     v += b;
     v.x = v.x > 0.f ? v.x : p.x * v.x;
     v.y = v.y > 0.f ? v.y : p.y * v.y;
     v.z = v.z > 0.f ? v.z : p.z * v.z;
     v.w = v.w > 0.f ? v.w : p.w * v.w;
     v += res;
-    if (c.nvalid >= 4) {
-        *reinterpret_cast<f32x4*>(optr + c.co) = v;
-    } else if (c.nvalid > 0) {
-        optr[c.co] = v.x;
-        if (c.nvalid > 1) optr[c.co + 1] = v.y;
-        if (c.nvalid > 2) optr[c.co + 2] = v.z;
+    if (a.out) {
+        float* optr = orow;
+        if (a.mode == ATMVFI_GEMM_DECONV) optr = orow + ((long long)(c.q >> 1) * a.Wo + (c.q & 1)) * a.out_ld;
+        if (c.nvalid >= 4) {
+            *reinterpret_cast<f32x4*>(optr + c.co) = v;
+        } else if (c.nvalid > 0) {
+            optr[c.co] = v.x;
+            if (c.nvalid > 1) optr[c.co + 1] = v.y;
+            if (c.nvalid > 2) optr[c.co + 2] = v.z;
+        }
+    }
+    if (a.out_hi && c.nvalid > 0) {
+        if (c.nvalid < 4) {            // channels past Cout inside this group of 4: the planes' pad channels, written as zero
+            v.y = c.nvalid > 1 ? v.y : 0.f;
+            v.z = c.nvalid > 2 ? v.z : 0.f;
+            v.w = 0.f;
+        }
+        if (a.mode == ATMVFI_GEMM_DECONV) prow += (long long)(c.q >> 1) * a.Wo + (c.q & 1);
+        const RowSink sink{nullptr, 0, a.out_hi, a.out_lo, a.out_plane_rows};
+        sink_store4(sink, prow, pc0 + c.co, v);
     }
 }
 __device__ __forceinline__ f32x4 gemm_load_residual4(const float* rrow, const ChanPos& c) {

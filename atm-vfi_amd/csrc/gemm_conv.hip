@@ -249,7 +249,19 @@ extern "C" int atmvfi_pack_weight(int mode, const float* src, float* dst, int Co
 extern "C" int atmvfi_gemm(const atmvfi_gemm_params* p, void* stream) {
     ATMVFI_REQUIRE(p, ATMVFI_EINVAL, "gemm: null params");
     const bool planes = p->in_hi || p->in_lo;
-    ATMVFI_REQUIRE((p->in || planes) && p->weight && p->out, ATMVFI_EINVAL, "gemm: null tensor pointer");
+    const bool sink = p->out_hi || p->out_lo;
+    ATMVFI_REQUIRE((p->in || planes) && p->weight && (p->out || sink), ATMVFI_EINVAL, "gemm: null tensor pointer");
+    if (sink) {
+        ATMVFI_REQUIRE(p->out_hi && p->out_lo && p->precision == ATMVFI_PREC_F16X3, ATMVFI_EINVAL,
+                       "gemm: the plane sink needs both planes and precision f16x3");
+        ATMVFI_REQUIRE(atmvfi::aligned16(p->out_hi) && atmvfi::aligned16(p->out_lo) && p->out_plane_c0 >= 0 && p->out_plane_c0 % 4 == 0 &&
+                           p->out_plane_gc % 4 == 0, ATMVFI_EALIGN, "gemm: plane sink: 16-byte aligned planes, channel offsets multiples of 4");
+        const long long orows = p->mode == ATMVFI_GEMM_DECONV ? (long long)p->N * p->Ho * p->Wo
+                                : p->out_rpg > 0 ? (long long)p->out_rpg : (p->mode == ATMVFI_GEMM_CONV ? (long long)p->N * p->Ho * p->Wo : (long long)p->M);
+        ATMVFI_REQUIRE(p->out_row_map || p->out_plane_rows >= orows, ATMVFI_EINVAL, "gemm: plane sink rows %lld < output rows %lld",
+                       (long long)p->out_plane_rows, orows);
+        ATMVFI_REQUIRE(p->out_plane_rows > 0, ATMVFI_EINVAL, "gemm: plane sink needs out_plane_rows");
+    }
     if (planes) {
         ATMVFI_REQUIRE(p->in_hi && p->in_lo && p->precision == ATMVFI_PREC_F16X3 && p->mode != ATMVFI_GEMM_CONV && !p->in_prelu,
                        ATMVFI_EINVAL, "gemm: split-plane input needs both planes, precision f16x3, LINEAR or DECONV mode and no in_prelu");
@@ -263,9 +275,9 @@ extern "C" int atmvfi_gemm(const atmvfi_gemm_params* p, void* stream) {
     ATMVFI_REQUIRE(p->Cin > 0 && p->Cout > 0, ATMVFI_EINVAL, "gemm: bad channel counts");
     ATMVFI_REQUIRE(planes || (p->in_ld >= atmvfi::round_up(p->Cin, 4) && p->in_ld % 4 == 0), ATMVFI_EALIGN,
                    "gemm: in_ld %d must be a multiple of 4 and >= Cin rounded to 4 (Cin %d)", p->in_ld, p->Cin);
-    ATMVFI_REQUIRE(p->out_ld % 4 == 0 && p->out_ld >= atmvfi::round_up(p->Cout, 4), ATMVFI_EALIGN,
+    ATMVFI_REQUIRE(!p->out || (p->out_ld % 4 == 0 && p->out_ld >= atmvfi::round_up(p->Cout, 4)), ATMVFI_EALIGN,
                    "gemm: out_ld %d must be a multiple of 4 and >= Cout rounded to 4 (Cout %d)", p->out_ld, p->Cout);
-    ATMVFI_REQUIRE((planes || atmvfi::aligned16(p->in)) && atmvfi::aligned16(p->out) && atmvfi::aligned16(p->weight), ATMVFI_EALIGN,
+    ATMVFI_REQUIRE((planes || atmvfi::aligned16(p->in)) && (!p->out || atmvfi::aligned16(p->out)) && atmvfi::aligned16(p->weight), ATMVFI_EALIGN,
                    "gemm: in/out/weight must be 16-byte aligned");
     ATMVFI_REQUIRE((planes || p->in_gstride % 4 == 0) && p->out_gstride % 4 == 0, ATMVFI_EALIGN, "gemm: group strides must be multiples of 4");
     if (p->residual)
@@ -318,6 +330,11 @@ extern "C" int atmvfi_gemm(const atmvfi_gemm_params* p, void* stream) {
     ATMVFI_REQUIRE(d.M < (1ll << 40), ATMVFI_EINVAL, "gemm: M too large");
     d.a_hi = (const _Float16*)p->in_hi;
     d.a_lo = (const _Float16*)p->in_lo;
+    d.out_hi = (_Float16*)p->out_hi;
+    d.out_lo = (_Float16*)p->out_lo;
+    d.out_plane_rows = p->out_plane_rows;
+    d.out_c0 = p->out_plane_c0;
+    d.out_gc = p->out_plane_gc;
     d.nblocks = 0;
     d.dbg = 0;
     d.vblocks = 0;

@@ -289,11 +289,13 @@ __global__ __launch_bounds__(512) void gemm_f16x3_kernel(const GemmDev a) {
         // output rows of THIS tile, then the next tile's origin, task set-up and first chunk (in flight under the stores)
         float* orow[2];
         const float* rrow[2];
+        long long prow[2];
+        int pc0[2];
         bool live[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const long long m = m0 + 32 * wave + 16 * i + r;
-            live[i] = m < a.M && atmvfi::gemm_out_row(a, m, orow[i], rrow[i]);
+            live[i] = m < a.M && atmvfi::gemm_out_row(a, m, orow[i], rrow[i], prow[i], pc0[i]);
         }
         const int n0_cur = n0;
         bool more = false;
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(512) void gemm_f16x3_kernel(const GemmDev a) {
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                if (live[i]) atmvfi::gemm_finish_store4(a, orow[i], cp, acc[i][j] + cor[i][j] * LO_UNSCALE, b, p, res[i]);
+                if (live[i]) atmvfi::gemm_finish_store4(a, orow[i], prow[i], pc0[i], cp, acc[i][j] + cor[i][j] * LO_UNSCALE, b, p, res[i]);
                 acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 cor[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }

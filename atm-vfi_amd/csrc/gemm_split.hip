@@ -253,7 +253,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_split_kernel(const Gem
         const long long m = m0 + 64 * wm + 16 * i + r;
         float* orow;
         const float* rrow;
-        bool live = m < a.M && atmvfi::gemm_out_row(a, m, orow, rrow);
+        long long prow;
+        int pc0;
+        bool live = m < a.M && atmvfi::gemm_out_row(a, m, orow, rrow, prow, pc0);
         if (a.dbg & 1) live = live && acc[i][0].x == 12345.678f;
         // residual vectors of the whole row first (one wait), then the four stores back to back
         f32x4 res[4];
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_split_kernel(const Gem
             const atmvfi::ChanPos cp = atmvfi::gemm_chan_pos(a, n0 + cl);
             const f32x4 b = *reinterpret_cast<const f32x4*>(cst + cl);
             const f32x4 p = *reinterpret_cast<const f32x4*>(cst + BN + cl);
-            if (live) atmvfi::gemm_finish_store4(a, orow, cp, acc[i][j] + cor[i][j] * LO_UNSCALE, b, p, res[j]);
+            if (live) atmvfi::gemm_finish_store4(a, orow, prow, pc0, cp, acc[i][j] + cor[i][j] * LO_UNSCALE, b, p, res[j]);
         }
     }
 #ifdef ATMVFI_STAMP
@@ -283,9 +285,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_split_kernel(const Gem
 
 // fp32 rows -> (hi, lo') planes in the chunk-major layout; one thread per 8 channels, pad channels of the last chunk written as
 // zero.  An optional per-channel PReLU is applied first (the leading nn.PReLU of the decoder stages, network_base.py:209,215).
+// The C channels go to plane channels c0 .. c0 + C (c0 a multiple of 8); channels up to the next multiple of `pad_to` (8 or 32)
+// are written as zero.
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ in, int in_ld, long long M, int C,
-                                                           const float* __restrict__ prelu, _Float16* hi, _Float16* lo, long long plane_rows) {
-    const int groups = (C + 31) / 32 * 4;
+                                                           const float* __restrict__ prelu, _Float16* hi, _Float16* lo, long long plane_rows,
+                                                           int c0p, int pad_to) {
+    const int groups = (C + pad_to - 1) / pad_to * (pad_to / 8);
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= M * groups) return;
     const long long m = t / groups;
@@ -314,7 +319,8 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
         l[2 * e] = ll.x;
         l[2 * e + 1] = ll.y;
     }
-    const long long off = ((long long)(c0 >> 5) * plane_rows + m) * 32 + (c0 & 31);
+    const int cp = c0p + c0;
+    const long long off = ((long long)(cp >> 5) * plane_rows + m) * 32 + (cp & 31);
     *reinterpret_cast<f16x8*>(hi + off) = h;
     *reinterpret_cast<f16x8*>(lo + off) = l;
 }
@@ -346,13 +352,19 @@ int atmvfi::launch_gemm_split(const GemmDev& d, int ngemm, hipStream_t s) {
     return launch_split<4, 2>(d, ngemm, s);
 }
 
-extern "C" int atmvfi_split_planes(const float* in, int in_ld, int64_t M, int C, const float* prelu, void* hi, void* lo, int plane_rows,
-                                   void* stream) {
+extern "C" int atmvfi_split_planes_at(const float* in, int in_ld, int64_t M, int C, const float* prelu, void* hi, void* lo, int plane_rows,
+                                      int c0, int pad_to, void* stream) {
     ATMVFI_REQUIRE(in && hi && lo && M > 0 && C > 0, ATMVFI_EINVAL, "split_planes: bad arguments");
     ATMVFI_REQUIRE(plane_rows >= M && in_ld >= C, ATMVFI_EALIGN, "split_planes: plane rows %d must cover M and in_ld %d must cover C %d", plane_rows, in_ld, C);
     ATMVFI_REQUIRE(atmvfi::aligned16(hi) && atmvfi::aligned16(lo), ATMVFI_EALIGN, "split_planes: planes must be 16-byte aligned");
-    const long long n = (long long)M * ((C + 31) / 32 * 4);
+    ATMVFI_REQUIRE(c0 >= 0 && c0 % 8 == 0 && (pad_to == 8 || pad_to == 32) && (pad_to == 8 || c0 % 32 == 0), ATMVFI_EINVAL,
+                   "split_planes: channel offset %d must be a multiple of 8 (of 32 when padding to 32), pad_to 8 or 32", c0);
+    const long long n = (long long)M * ((C + pad_to - 1) / pad_to * (pad_to / 8));
     hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, in_ld, (long long)M, C,
-                       prelu, (_Float16*)hi, (_Float16*)lo, (long long)plane_rows);
+                       prelu, (_Float16*)hi, (_Float16*)lo, (long long)plane_rows, c0, pad_to);
     return atmvfi::check_launch("split_planes");
+}
+extern "C" int atmvfi_split_planes(const float* in, int in_ld, int64_t M, int C, const float* prelu, void* hi, void* lo, int plane_rows,
+                                   void* stream) {
+    return atmvfi_split_planes_at(in, in_ld, M, C, prelu, hi, lo, plane_rows, 0, 32, stream);
 }

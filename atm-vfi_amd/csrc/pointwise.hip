@@ -273,7 +273,9 @@ __global__ __launch_bounds__(256) void warp_blend_kernel(const float* __restrict
                                                          float* __restrict__ f0o, float* __restrict__ f1o,
                                                          float* __restrict__ m1o, float* __restrict__ m2o,
                                                          const float* __restrict__ orig0, const float* __restrict__ orig1,
-                                                         float* __restrict__ pack15, int pack_ld, int B, int H, int W) {
+                                                         float* __restrict__ pack15, int pack_ld, _Float16* __restrict__ pack_hi,
+                                                         _Float16* __restrict__ pack_lo, long long pack_rows, int pack_c0, int B, int H,
+                                                         int W) {
     const long long hw = (long long)H * W;
     const long long total = (long long)B * hw;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -319,6 +321,25 @@ __global__ __launch_bounds__(256) void warp_blend_kernel(const float* __restrict
                 pp[9 + ch] = c[ch];
                 pp[12 + ch] = o[ch];
             }
+        }
+        if (pack_hi) {
+            // the same 15 values (+ one zero) as split planes at channels pack_c0 .. pack_c0 + 16: the refiner's first conv reads
+            // its input as planes (atmvfi_conv3x3_planes)
+            float v16[16];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const long long pl = ((long long)b * 3 + ch) * hw + pix;
+                v16[ch] = orig0[pl];
+                v16[3 + ch] = a[ch];
+                v16[6 + ch] = orig1[pl];
+                v16[9 + ch] = c[ch];
+                v16[12 + ch] = o[ch];
+            }
+            v16[15] = 0.f;
+            const RowSink sink{nullptr, 0, pack_hi, pack_lo, pack_rows};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                sink_store4(sink, (long long)b * hw + pix, pack_c0 + 4 * q, (f32x4){v16[4 * q], v16[4 * q + 1], v16[4 * q + 2], v16[4 * q + 3]});
         }
     }
 }
@@ -522,19 +543,32 @@ extern "C" int atmvfi_flow_warp_nhwc(const float* src, int src_ld, int64_t src_b
     return atmvfi::check_launch("flow_warp_nhwc");
 }
 
-extern "C" int atmvfi_warp_blend(const float* im0, const float* im1, const float* motion, int motion_ld,
-                                  int64_t motion_bstride, float* i0w, float* i1w, float* it, float* flow0_out,
-                                  float* flow1_out, float* mask1_out, float* mask2_out, const float* orig0,
-                                  const float* orig1, float* pack15, int pack_ld, int B, int H, int W, void* stream) {
+extern "C" int atmvfi_warp_blend_planes(const float* im0, const float* im1, const float* motion, int motion_ld,
+                                         int64_t motion_bstride, float* i0w, float* i1w, float* it, float* flow0_out,
+                                         float* flow1_out, float* mask1_out, float* mask2_out, const float* orig0,
+                                         const float* orig1, float* pack15, int pack_ld, void* pack_hi, void* pack_lo, int64_t pack_rows,
+                                         int pack_c0, int B, int H, int W, void* stream) {
     ATMVFI_REQUIRE(im0 && im1 && motion && i0w && i1w && it, ATMVFI_EINVAL, "warp_blend: null pointer");
     ATMVFI_REQUIRE(B > 0 && H > 1 && W > 1 && motion_ld >= 5, ATMVFI_EINVAL, "warp_blend: bad shape");
     ATMVFI_REQUIRE((flow0_out == nullptr) == (flow1_out == nullptr) && (mask1_out == nullptr) == (mask2_out == nullptr),
                    ATMVFI_EINVAL, "warp_blend: flow/mask outputs come in pairs");
     if (pack15) ATMVFI_REQUIRE(orig0 && orig1 && pack_ld >= 15, ATMVFI_EINVAL, "warp_blend: pack15 needs orig0/orig1 and ld >= 15");
+    ATMVFI_REQUIRE((pack_hi == nullptr) == (pack_lo == nullptr), ATMVFI_EINVAL, "warp_blend: the plane sink needs both planes");
+    if (pack_hi)
+        ATMVFI_REQUIRE(orig0 && orig1 && pack_rows >= (int64_t)B * H * W && pack_c0 >= 0 && pack_c0 % 4 == 0 && atmvfi::aligned16(pack_hi) &&
+                           atmvfi::aligned16(pack_lo), ATMVFI_EINVAL,
+                       "warp_blend: plane sink needs orig0/orig1, rows >= B*H*W, a channel offset that is a multiple of 4, aligned planes");
     hipLaunchKernelGGL(warp_blend_kernel, dim3(grid_for((long long)B * H * W)), dim3(256), 0, (hipStream_t)stream, im0, im1,
                        motion, motion_ld, (long long)motion_bstride, i0w, i1w, it, flow0_out, flow1_out, mask1_out, mask2_out,
-                       orig0, orig1, pack15, pack_ld, B, H, W);
+                       orig0, orig1, pack15, pack_ld, (_Float16*)pack_hi, (_Float16*)pack_lo, (long long)pack_rows, pack_c0, B, H, W);
     return atmvfi::check_launch("warp_blend");
+}
+extern "C" int atmvfi_warp_blend(const float* im0, const float* im1, const float* motion, int motion_ld,
+                                  int64_t motion_bstride, float* i0w, float* i1w, float* it, float* flow0_out,
+                                  float* flow1_out, float* mask1_out, float* mask2_out, const float* orig0,
+                                  const float* orig1, float* pack15, int pack_ld, int B, int H, int W, void* stream) {
+    return atmvfi_warp_blend_planes(im0, im1, motion, motion_ld, motion_bstride, i0w, i1w, it, flow0_out, flow1_out, mask1_out, mask2_out,
+                                    orig0, orig1, pack15, pack_ld, nullptr, nullptr, 0, 0, B, H, W, stream);
 }
 
 extern "C" int atmvfi_resize_bilinear_ac(const float* src, int64_t src_bstride, int64_t src_cstride, int64_t src_ystride,

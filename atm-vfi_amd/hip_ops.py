@@ -51,6 +51,8 @@ class GemmParams(ctypes.Structure):
         ("res_ld", ctypes.c_int32),
         ("precision", ctypes.c_int32), ("weight_hi", c_f), ("weight_lo", c_f),
         ("in_hi", c_f), ("in_lo", c_f),
+        ("out_hi", c_f), ("out_lo", c_f), ("out_plane_rows", ctypes.c_int64), ("out_plane_c0", ctypes.c_int32),
+        ("out_plane_gc", ctypes.c_int32),
     ]
 
 
@@ -60,6 +62,7 @@ SIGNATURES = {
     "atmvfi_last_error": (ctypes.c_char_p, []),
     "atmvfi_gemm": (c_i, [ctypes.POINTER(GemmParams), c_f]),
     "atmvfi_split_planes": (c_i, [c_f, c_i, c_l, c_i, c_f, c_f, c_f, c_i, c_f]),
+    "atmvfi_split_planes_at": (c_i, [c_f, c_i, c_l, c_i, c_f, c_f, c_f, c_i, c_i, c_i, c_f]),
     "atmvfi_conv2d": (c_i, [ctypes.POINTER(GemmParams), c_f]),
     "atmvfi_linear": (c_i, [ctypes.POINTER(GemmParams), c_f]),
     "atmvfi_deconv2x2": (c_i, [ctypes.POINTER(GemmParams), c_f]),
@@ -84,6 +87,8 @@ SIGNATURES = {
     "atmvfi_flow_warp_nhwc": (c_i, [c_f, c_i, c_l, c_f, c_l, c_i, c_i, c_f, c_i, c_l, c_i, c_i, c_i, c_i, c_f]),
     "atmvfi_warp_blend": (c_i, [c_f, c_f, c_f, c_i, c_l, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i,
                                 c_i, c_i, c_i, c_f]),
+    "atmvfi_warp_blend_planes": (c_i, [c_f, c_f, c_f, c_i, c_l, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i,
+                                       c_f, c_f, c_l, c_i, c_i, c_i, c_i, c_f]),
     "atmvfi_resize_bilinear_ac": (c_i, [c_f, c_l, c_l, c_l, c_l, c_f, c_i, c_i, c_i, c_i, c_i, c_i, ctypes.c_float, c_f]),
     "atmvfi_frame_u8_to_f32": (c_i, [c_f, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_f]),
     "atmvfi_frame_f32_to_u8": (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_f]),
@@ -308,18 +313,38 @@ class HipOps:
         return out
 
     # ------------------------------------------------------------------ GEMMs
+    @staticmethod
+    def _gemm_sink(p: "GemmParams", sink: Optional[Planes], rows: int, cout: int, c0: int, gc: int, groups: int, what: str):
+        """Fill the plane-sink fields of ``p``: ``rows`` output rows (per group) x ``cout`` channels at channel offset ``c0``
+        (+ ``gc`` per row group) of ``sink``."""
+        if sink is None:
+            return
+        if p.precision != 1:
+            raise ValueError(f"{what}: a plane sink needs the f16x3 engine")
+        top = c0 + (groups - 1) * gc + cout
+        if sink.rows != rows or c0 % 4 or gc % 4 or top > sink.chunks * 32:
+            raise ValueError(f"{what}: plane sink [{sink.rows},{sink.c}] cannot take {rows} rows x {cout} channels at offset {c0} (+{gc} per group)")
+        p.out_hi, p.out_lo = sink.t[0].data_ptr(), sink.t[1].data_ptr()
+        p.out_plane_rows, p.out_plane_c0, p.out_plane_gc = sink.ld_rows, c0, gc
+
     def conv(self, x, w: PackedWeight, out, stride=1, pad=1, dil=1, bias=None, prelu=None, in_prelu=None,
-             planes: Optional[Planes] = None, planes_prelu=None):
-        """``planes``: also write the result as split planes (3x3 / stride 1 f16x3 kernel only), through ``planes_prelu``."""
+             planes: Optional[Planes] = None, planes_prelu=None, planes_c0: int = 0, out_shape=None):
+        """``planes``: also write the result as split planes, at channel offset ``planes_c0``; through ``planes_prelu`` (3x3 / stride 1
+        f16x3 kernel only).  ``out`` may be None (planes only; generic GEMM path) when ``out_shape`` = (N, Ho, Wo, Cout) is given."""
         ld, n, h, wd, cin = nhwc_view(x, "conv.in")
-        old, on, oh, ow, cout = nhwc_view(out, "conv.out")
+        if out is None:
+            if planes is None or out_shape is None:
+                raise ValueError("conv: no output")
+            old, (on, oh, ow, cout) = 0, out_shape
+        else:
+            old, on, oh, ow, cout = nhwc_view(out, "conv.out")
         if cin != w.cin or cout != w.cout or on != n or w.mode != GEMM_CONV:
-            raise ValueError(f"conv: shape mismatch in {tuple(x.shape)} w ({w.cout},{w.cin},{w.kh},{w.kw}) out {tuple(out.shape)}")
+            raise ValueError(f"conv: shape mismatch in {tuple(x.shape)} w ({w.cout},{w.cin},{w.kh},{w.kw}) out {(on, oh, ow, cout)}")
         meta = {"flops": 2.0 * n * oh * ow * cout * cin * w.kh * w.kw,
                 "bytes": 4.0 * (n * h * wd * cin + n * oh * ow * cout + cout * cin * w.kh * w.kw),
                 "shape": f"M{n * oh * ow} N{cout} K{cin * w.kh * w.kw}"}
         if (self.precision == "f16x3" and w.hi3 is not None and w.kh == 3 and stride == 1 and pad == 1 and dil == 1
-                and in_prelu is None):
+                and in_prelu is None and out is not None and planes_c0 == 0):
             if planes is not None and (planes.rows < n * h * wd or planes.c != cout):
                 raise ValueError(f"conv: plane sink [{planes.rows},{planes.c}] does not match {n * h * wd} pixels x {cout} channels")
             if planes is not None and planes_prelu is not None and planes_prelu.numel() < (cout + 31) // 32 * 32:
@@ -329,13 +354,14 @@ class HipOps:
                       planes.t[0].data_ptr() if planes is not None else None, planes.t[1].data_ptr() if planes is not None else None,
                       planes.ld_rows if planes is not None else 0, _ptr(planes_prelu) if planes is not None else None, self._stream())
             return
-        if planes is not None:
-            raise ValueError("conv: a plane sink needs the 3x3 / stride-1 f16x3 kernel")
+        if planes is not None and planes_prelu is not None:
+            raise ValueError("conv: planes_prelu needs the 3x3 / stride-1 f16x3 kernel")
         p = GemmParams(mode=GEMM_CONV, in_=x.data_ptr(), in_ld=ld, N=n, H=h, W=wd, Cin=cin, in_gstride=0, in_rpg=0,
                        weight=w.packed.data_ptr(), Cout=cout, kh=w.kh, kw=w.kw, stride=stride, pad=pad, dil=dil,
-                       Ho=oh, Wo=ow, M=n * oh * ow, out=out.data_ptr(), out_ld=old, out_gstride=0, out_rpg=0,
+                       Ho=oh, Wo=ow, M=n * oh * ow, out=None if out is None else out.data_ptr(), out_ld=old, out_gstride=0, out_rpg=0,
                        out_row_map=None, bias=_ptr(bias), prelu=_ptr(prelu), in_prelu=_ptr(in_prelu), residual=None, res_ld=0)
         p.precision, p.weight_hi, p.weight_lo = self._prec(w)
+        self._gemm_sink(p, planes, n * oh * ow, cout, planes_c0, 0, 1, "conv")
         self._run("conv2d_f16x3" if p.precision else "conv2d", meta, self.lib.atmvfi_conv2d, ctypes.byref(p), self._stream())
 
     def conv3x3_planes(self, x: Planes, n: int, h: int, wd: int, w: PackedWeight, out=None, bias=None, prelu=None,
@@ -374,19 +400,37 @@ class HipOps:
                   planes.ld_rows if planes is not None else 0, planes_c0, _ptr(planes_prelu) if planes is not None else None, wn,
                   self._stream())
 
-    def deconv(self, x, w: PackedWeight, out, bias=None, prelu=None, in_prelu=None, planes: Optional[Planes] = None):
+    def deconv(self, x, w: PackedWeight, out, bias=None, prelu=None, in_prelu=None, planes: Optional[Planes] = None,
+               sink: Optional[Planes] = None, sink_c0: int = 0, in_shape=None):
         """``planes``: the input rows [N*H*W, Cin] again in split-plane form (already through in_prelu): the LDS-DMA GEMM
-        then replaces the fp32-input engine."""
-        ld, n, h, wd, cin = nhwc_view(x, "deconv.in")
-        old, on, oh, ow, cout = nhwc_view(out, "deconv.out")
-        if cin != w.cin or cout != w.cout or on != n or w.mode != GEMM_DECONV or oh != 2 * h or ow != 2 * wd:
-            raise ValueError(f"deconv: shape mismatch in {tuple(x.shape)} w ({w.cin},{w.cout}) out {tuple(out.shape)}")
-        p = GemmParams(mode=GEMM_DECONV, in_=x.data_ptr(), in_ld=ld, N=n, H=h, W=wd, Cin=cin, in_gstride=0, in_rpg=0,
+        then replaces the fp32-input engine (``x`` may then be None with ``in_shape`` = (N, H, W, Cin)).  ``sink``: also write the
+        result as split planes at channel offset ``sink_c0`` (``out`` may then be None)."""
+        if x is None:
+            if planes is None or in_shape is None:
+                raise ValueError("deconv: no input")
+            ld, (n, h, wd, cin) = 0, in_shape
+        else:
+            ld, n, h, wd, cin = nhwc_view(x, "deconv.in")
+        cout = w.cout
+        if out is None:
+            if sink is None:
+                raise ValueError("deconv: no output")
+            old, on, oh, ow = 0, n, 2 * h, 2 * wd
+        else:
+            old, on, oh, ow, oc = nhwc_view(out, "deconv.out")
+            if oc != cout:
+                raise ValueError(f"deconv: out has {oc} channels, weight {cout}")
+        if cin != w.cin or on != n or w.mode != GEMM_DECONV or oh != 2 * h or ow != 2 * wd:
+            raise ValueError(f"deconv: shape mismatch in {(n, h, wd, cin)} w ({w.cin},{w.cout}) out {(on, oh, ow, cout)}")
+        p = GemmParams(mode=GEMM_DECONV, in_=None if x is None else x.data_ptr(), in_ld=ld, N=n, H=h, W=wd, Cin=cin, in_gstride=0, in_rpg=0,
                        weight=w.packed.data_ptr(), Cout=cout, kh=2, kw=2, stride=2, pad=0, dil=1, Ho=oh, Wo=ow,
-                       M=n * h * wd, out=out.data_ptr(), out_ld=old, out_gstride=0, out_rpg=0, out_row_map=None,
+                       M=n * h * wd, out=None if out is None else out.data_ptr(), out_ld=old, out_gstride=0, out_rpg=0, out_row_map=None,
                        bias=_ptr(bias), prelu=_ptr(prelu), in_prelu=_ptr(in_prelu), residual=None, res_ld=0)
         p.precision, p.weight_hi, p.weight_lo = self._prec(w)
+        self._gemm_sink(p, sink, n * oh * ow, cout, sink_c0, 0, 1, "deconv")
         use_planes = planes is not None and p.precision == 1
+        if x is None and not use_planes:
+            raise ValueError("deconv: plane input needs the f16x3 engine")
         if use_planes:
             if planes.rows < n * h * wd or planes.c != cin:
                 raise ValueError("deconv: planes do not match the input rows")
@@ -399,18 +443,26 @@ class HipOps:
 
     split_planes_ok = True        # this backend has the split-plane sinks and the LDS-DMA GEMM
 
-    def split_planes(self, x, out: Planes, prelu=None):
-        """fp32 rows -> split planes, optionally through a per-channel PReLU first."""
+    def split_planes(self, x, out: Planes, prelu=None, c0: Optional[int] = None):
+        """fp32 rows -> split planes, optionally through a per-channel PReLU first.  ``c0``: write the channels at this offset
+        (multiple of 8) of wider planes and leave everything else alone (zero fill only up to the next multiple of 8)."""
         ld, m, c, gs, _ = rows_view(x, "split_planes.in")
-        if gs != 0 or m != out.rows or c != out.c:
+        if gs != 0 or m != out.rows or (c0 is None and c != out.c) or (c0 is not None and (c0 % 8 or c0 + c > out.chunks * 32)):
             raise ValueError("split_planes: expected a plain [rows,C] view matching the planes")
         if prelu is not None and prelu.numel() < c:
             raise ValueError("split_planes: prelu needs one slope per channel")
-        meta = {"bytes": 4.0 * m * c + 4.0 * m * out.chunks * 32}
-        self._run("split_planes", meta, self.lib.atmvfi_split_planes, _ptr(x), ld, m, c, _ptr(prelu), out.t[0].data_ptr(),
-                  out.t[1].data_ptr(), out.ld_rows, self._stream())
+        meta = {"bytes": 4.0 * m * c + 4.0 * m * ((c + 31) // 32 * 32 if c0 is None else (c + 7) // 8 * 8)}
+        if c0 is None:
+            self._run("split_planes", meta, self.lib.atmvfi_split_planes, _ptr(x), ld, m, c, _ptr(prelu), out.t[0].data_ptr(),
+                      out.t[1].data_ptr(), out.ld_rows, self._stream())
+        else:
+            self._run("split_planes", meta, self.lib.atmvfi_split_planes_at, _ptr(x), ld, m, c, _ptr(prelu), out.t[0].data_ptr(),
+                      out.t[1].data_ptr(), out.ld_rows, c0, 8, self._stream())
 
-    def linear(self, x, w: PackedWeight, out, bias=None, residual=None, out_row_map=None):
+    def linear(self, x, w: PackedWeight, out, bias=None, residual=None, out_row_map=None, sink: Optional[Planes] = None,
+               sink_c0: int = 0, sink_gc: int = 0):
+        """``sink``: also write the result as split planes: output row r (after ``out_row_map``; of its row group when ``out`` is a
+        grouped [G,R,C] view) at channel ``sink_c0`` (+ ``sink_gc`` per group)."""
         planes = x if isinstance(x, Planes) else None
         if planes is not None:
             if self.precision != "f16x3" or w.hi is None:
@@ -437,6 +489,8 @@ class HipOps:
         p.precision, p.weight_hi, p.weight_lo = self._prec(w)
         if planes is not None:
             p.in_hi, p.in_lo = planes.t[0].data_ptr(), planes.t[1].data_ptr()
+        if sink is not None:
+            self._gemm_sink(p, sink, orpg if orpg else mo, cout, sink_c0, sink_gc, (mo // orpg) if orpg else 1, "linear")
         meta = {"flops": 2.0 * m * cout * cin, "bytes": 4.0 * (m * cin + m * cout + cout * cin), "shape": f"M{m} N{cout} K{cin}"}
         self._run("linear_split" if planes is not None else "linear_f16x3" if p.precision else "linear", meta, self.lib.atmvfi_linear, ctypes.byref(p), self._stream())
 
@@ -533,7 +587,7 @@ class HipOps:
                   _ptr(dst), old, dst.stride(0), b, c, h, w, self._stream())
 
     def warp_blend(self, im0, im1, motion, i0w, i1w, it, flow0=None, flow1=None, mask1=None, mask2=None,
-                   orig0=None, orig1=None, pack15=None):
+                   orig0=None, orig1=None, pack15=None, pack_planes: Optional[Planes] = None, pack_c0: int = 0):
         _planar(im0, 3, "warp_blend.im0"); _planar(im1, 3, "warp_blend.im1")
         b, _, h, w = im0.shape
         mld, mb, mh, mw, mc = nhwc_view(motion, "warp_blend.motion")
@@ -548,9 +602,15 @@ class HipOps:
                 raise ValueError("warp_blend: pack15 view must be [B,H,W,15]")
             _planar(orig0, 3, "warp_blend.orig0"); _planar(orig1, 3, "warp_blend.orig1")
         meta = {"bytes": 4.0 * b * h * w * (6 + 5 + 9)}
-        self._run("warp_blend", meta, self.lib.atmvfi_warp_blend, _ptr(im0), _ptr(im1), _ptr(motion), mld, motion.stride(0),
+        if pack_planes is not None:
+            if pack_planes.rows != b * h * w or pack_c0 % 4 or pack_c0 + 16 > pack_planes.chunks * 32:
+                raise ValueError("warp_blend: the plane sink must hold B*H*W rows and 16 channels at the offset")
+            _planar(orig0, 3, "warp_blend.orig0"); _planar(orig1, 3, "warp_blend.orig1")
+        self._run("warp_blend", meta, self.lib.atmvfi_warp_blend_planes, _ptr(im0), _ptr(im1), _ptr(motion), mld, motion.stride(0),
                   _ptr(i0w), _ptr(i1w), _ptr(it), _ptr(flow0), _ptr(flow1), _ptr(mask1), _ptr(mask2), _ptr(orig0), _ptr(orig1),
-                  _ptr(pack15), pld, b, h, w, self._stream())
+                  _ptr(pack15), pld, pack_planes.t[0].data_ptr() if pack_planes is not None else None,
+                  pack_planes.t[1].data_ptr() if pack_planes is not None else None,
+                  pack_planes.ld_rows if pack_planes is not None else 0, pack_c0, b, h, w, self._stream())
 
     def resize(self, src, dst, value_scale=1.0):
         """src: any [B,C,Hi,Wi] strided view; dst: contiguous planar [B,C,Ho,Wo]."""

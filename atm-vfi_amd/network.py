@@ -84,6 +84,7 @@ class Network(nn.Module):
         self._precision = "f16x3"
         self.use_split_planes = os.environ.get("ATMVFI_SPLIT_PLANES", "1") != "0"     # A/B switch (tools/profile_layers.py)
         self.use_plane_deconvs = os.environ.get("ATMVFI_PLANE_DECONV", "1") != "0"    # A/B switch: decoder deconvs from split planes
+        self.use_plane_convs = os.environ.get("ATMVFI_PLANE_CONV", "1") != "0"        # A/B switch: 3x3 convs on split-plane input
         self._prepared: Dict[str, object] = {}
         self._prepared_sig = None
         self._bufs: Dict[Tuple, torch.Tensor] = {}
@@ -224,6 +225,14 @@ class Network(nn.Module):
                     P["pk:" + k.replace(".q.weight", ".qkv.weight")] = ops.pack_weight(GEMM_LINEAR, torch.cat([w, kv], 0))
                 else:
                     P["pk:" + k] = ops.pack_weight(GEMM_LINEAR, w)
+        # refiner input as split planes: [dec2 (w3+5) | zeros to the next multiple of 8 | 15 image channels]: the 16-channel pack of
+        # warp_blend's plane sink then starts on an 8-channel boundary (proj.0.weight gets zero input channels at the gap)
+        w3 = self._v.decoder_widths[2] + S.MOTION_OUT
+        gap = (-w3) % 8
+        if getattr(ops, "split_planes_ok", False):
+            wp = sd["proj.0.weight"].detach()
+            wpp = torch.cat([wp[:, :w3], torch.zeros(wp.shape[0], gap, 3, 3, dtype=wp.dtype, device=wp.device), wp[:, w3:]], 1)
+            P["pk:proj.0.weight:planes"] = ops.pack_weight(GEMM_CONV, wpp.contiguous())
         for st in (1, 2):     # leading PReLU of decoder stages 1-2, applied on the deconv's input load
             P[f"inprelu:{st}"] = ops.pad_channels(sd[f"upsample_pyramid.{st}.0.weight"])
         self._prepared = P
@@ -240,6 +249,25 @@ class Network(nn.Module):
                      planes_prelu=planes_prelu)
             return
         ops.conv(x, P[f"pk:{p}.weight"], out, stride=stride, pad=pad, dil=dil, bias=P[f"{p}.bias"])
+
+    def _plane_convs(self, ops) -> bool:
+        """3x3 / stride-1 convs on the split-plane kernel (LDS-DMA halo, ping-pong wave groups): their inputs are written as
+        split planes by the producing layer's sink, fp32 copies only where something other than a contraction reads them."""
+        return self._plane_deconvs(ops) and self.use_plane_convs
+
+    def _c3p(self, ops, P, p, xp, n, h, w, out=None, act=True, sink=None, sink_c0=0, sink_prelu=None, wkey=None):
+        """conv()/Conv2d 3x3 s1 p1 of the reference on split-plane input ``xp`` ([n*h*w rows]); ``p`` = parameter prefix
+        (``p.0.weight``/``p.0.bias``/``p.1.weight`` with ``act``, ``p.weight``/``p.bias`` without)."""
+        if act:
+            wk, bias, prelu = wkey or f"pk:{p}.0.weight", P[f"{p}.0.bias"], P[f"{p}.1.weight"]
+        else:
+            wk, bias, prelu = wkey or f"pk:{p}.weight", P[f"{p}.bias"], None
+        ops.conv3x3_planes(xp, n, h, w, P[wk], out=out, bias=bias, prelu=prelu, planes=sink, planes_c0=sink_c0, planes_prelu=sink_prelu)
+
+    def _conv_s2_sink(self, ops, P, p, x, sink, shape, out=None, sink_c0=0):
+        """conv() 3x3 stride 2 (+PReLU) on the fp32-input GEMM engine, result to a plane sink (and ``out`` if given)."""
+        ops.conv(x, P[f"pk:{p}.0.weight"], out, stride=2, pad=1, dil=1, bias=P[f"{p}.0.bias"], prelu=P[f"{p}.1.weight"],
+                 planes=sink, planes_c0=sink_c0, out_shape=shape)
 
     def _plane_deconvs(self, ops) -> bool:
         """Decoder deconvs on the LDS-DMA GEMM (operands as split planes) instead of the fp32-input engine."""
@@ -269,6 +297,19 @@ class Network(nn.Module):
         f, h, w, _ = x0.shape
         a = self.buf(f"{tag}e0a", f, h, w, d[0]); self._conv_act(ops, P, "feat_extracts.0.0", x0[..., :3], a)
         e0 = self.buf(f"{tag}e0", f, h, w, d[0]); self._conv_act(ops, P, "feat_extracts.0.1", a, e0)
+        if self._plane_convs(ops) and min(d[1:]) >= 32:
+            # stages 1-3: the stride-2 conv hands its result to the 3x3 / stride-1 conv as split planes only
+            fuse = self.buf(f"{tag}fuse_l", f, h // 8, w // 8, self._v.local_dim)
+            src, outs = e0, []
+            for st in (1, 2, 3):
+                hs, ws = h >> st, w >> st
+                ap = self.planes(f"{tag}e{st}a_p", f * hs * ws, d[st])
+                self._conv_s2_sink(ops, P, f"feat_extracts.{st}.0", src, ap, (f, hs, ws, d[st]))
+                dst = fuse[..., self._v.local_dim - d[3]:] if st == 3 else self.buf(f"{tag}e{st}", f, hs, ws, d[st])
+                self._c3p(ops, P, f"feat_extracts.{st}.1", ap, f, hs, ws, out=dst)
+                outs.append(dst)
+                src = dst
+            return outs[0], outs[1], fuse
         a = self.buf(f"{tag}e1a", f, h // 2, w // 2, d[1]); self._conv_act(ops, P, "feat_extracts.1.0", e0, a, 2)
         e1 = self.buf(f"{tag}e1", f, h // 2, w // 2, d[1]); self._conv_act(ops, P, "feat_extracts.1.1", a, e1)
         a = self.buf(f"{tag}e2a", f, h // 4, w // 4, d[2]); self._conv_act(ops, P, "feat_extracts.2.0", e1, a, 2)
@@ -291,7 +332,7 @@ class Network(nn.Module):
         ops.layernorm(t, out, P[f"{p}.norm.weight"], P[f"{p}.norm.bias"])
         return out
 
-    def _block(self, ops, P, p, x, frames, h, w, ws, shift, cross, out, motion_dst, tag):
+    def _block(self, ops, P, p, x, frames, h, w, ws, shift, cross, out, motion_dst, tag, out_sink=None):
         """One shifted-window transformer block (ATMFormer attention.py:265-334 when ``cross``,
         RefineBottleneck :433-495 otherwise).  x/out: token-matrix views in image order."""
         c = x.shape[-1]
@@ -327,7 +368,8 @@ class Network(nn.Module):
             ops.linear(y_p, P[f"pk:{p}.mlp.fc1.weight"], f1.reshape(frames * h * w, hid), bias=P[f"{p}.mlp.fc1.bias"])
             f2_p = self.planes(f"{tag}dw_p", frames * h * w, hid)
             ops.dwconv_gelu(f1, None, P[f"pk:{p}.mlp.dwconv.dwconv.weight"], P[f"{p}.mlp.dwconv.dwconv.bias"], planes=f2_p)
-            ops.linear(f2_p, P[f"pk:{p}.mlp.fc2.weight"], out, bias=P[f"{p}.mlp.fc2.bias"], residual=xb)
+            sk = {} if out_sink is None else {"sink": out_sink[0], "sink_c0": out_sink[1], "sink_gc": out_sink[2]}
+            ops.linear(f2_p, P[f"pk:{p}.mlp.fc2.weight"], out, bias=P[f"{p}.mlp.fc2.bias"], residual=xb, **sk)
         else:
             y = self.buf(f"{tag}ln2", frames * h * w, c)
             ops.layernorm(xb, y, P[f"{p}.norm2.weight"], P[f"{p}.norm2.bias"])
@@ -351,15 +393,27 @@ class Network(nn.Module):
         cin = 8 + 2 * c
         mlp_in = self.buf(f"{tag}mlp_in", b, h, w, cin)
         flat = mlp_in.reshape(b * h * w, cin)
+        pc = self._plane_convs(ops)
+        mlp_in_p = self.planes(f"{tag}mlp_in_p", b * h * w, cin) if pc else None
         x = x_tokens
         for blk in range(2):
             mdst = flat[:, 4 * blk:4 * blk + 4].unflatten(1, (2, 2)).permute(1, 0, 2)       # '(N B) L K -> B L (N K)'
             out = self._stacked(mlp_in, 8, c) if blk == 1 else self.buf(f"{tag}blk0", 2 * b * h * w, c)
-            self._block(ops, P, f"{branch}.{blk}", x, 2 * b, h, w, ws, 0 if blk == 0 else ws // 2, True, out, mdst, tag)
+            self._block(ops, P, f"{branch}.{blk}", x, 2 * b, h, w, ws, 0 if blk == 0 else ws // 2, True, out, mdst, tag,
+                        out_sink=(mlp_in_p, 8, c) if (pc and blk == 1) else None)
             x = out
         hid = P[f"{mlp}.0.0.bias"].shape[0]
+        t2 = self.buf(f"{tag}mm2", b, h, w, hid)
+        if pc:
+            # [motion 8 | frame0 C | frame1 C] as split planes: the features come from fc2's plane sink, the eight motion
+            # channels (written by the two motion heads) from one small split pass
+            ops.split_planes(flat[:, 0:8], mlp_in_p, c0=0)
+            t1p = self.planes(f"{tag}mm1_p", b * h * w, hid)
+            self._c3p(ops, P, f"{mlp}.0", mlp_in_p, b, h, w, sink=t1p)
+            self._c3p(ops, P, f"{mlp}.1", t1p, b, h, w, out=t2)
+            return mlp_in, t2
         t1 = self.buf(f"{tag}mm1", b, h, w, hid); self._conv_act(ops, P, f"{mlp}.0", mlp_in, t1)
-        t2 = self.buf(f"{tag}mm2", b, h, w, hid); self._conv_act(ops, P, f"{mlp}.1", t1, t2)
+        self._conv_act(ops, P, f"{mlp}.1", t1, t2)
         return mlp_in, t2
 
     def _global_motion(self, ops, P, e2, fuse_l, b, tag):
@@ -370,9 +424,14 @@ class Network(nn.Module):
         h_, w_ = h8 // 2, w8 // 2
         s3 = fuse_l[..., v.local_dim - d[3]:]
         fuse_g = self.buf(f"{tag}fuse_g", f, h_, w_, v.global_dim)
-        a = self.buf(f"{tag}ga", f, h_, w_, v.last_feat_dim)
-        self._conv_act(ops, P, "last_feat_extract.0", s3, a, 2)
-        self._conv_act(ops, P, "last_feat_extract.1", a, fuse_g[..., d[3] + 2 * d[2]:])
+        if self._plane_convs(ops):
+            ap = self.planes(f"{tag}ga_p", f * h_ * w_, v.last_feat_dim)
+            self._conv_s2_sink(ops, P, "last_feat_extract.0", s3, ap, (f, h_, w_, v.last_feat_dim))
+            self._c3p(ops, P, "last_feat_extract.1", ap, f, h_, w_, out=fuse_g[..., d[3] + 2 * d[2]:])
+        else:
+            a = self.buf(f"{tag}ga", f, h_, w_, v.last_feat_dim)
+            self._conv_act(ops, P, "last_feat_extract.0", s3, a, 2)
+            self._conv_act(ops, P, "last_feat_extract.1", a, fuse_g[..., d[3] + 2 * d[2]:])
         tokens = self._fusion(ops, P, "global_feature_fusion", e2, s3, fuse_g, d[3], d[2], tag + "g")
         mlp_in, t2 = self._motion_branch(ops, P, "global_motion_atmformer", "global_motion_mlp", tokens, b, h_, w_,
                                          self.global_motion_args["window_size"], tag + "g")
@@ -548,53 +607,111 @@ class Network(nn.Module):
             x = dec_in[..., 0:cdec]
             flow0 = flow1 = m1 = m2 = None
             pd = self._plane_deconvs(ops)
+            pc = self._plane_convs(ops) and rh >= 32
             xp_next = None
+            pack_c0 = (w3d + 5 + 7) // 8 * 8                                       # the 15 image channels inside the refiner's input planes
+            rin_p = self.planes("refine_in_p", b * H * W, pack_c0 + 15) if pc else None
             for st, scale in enumerate((2, 1, 0)):
                 pfx = f"upsample_pyramid.{st}"
                 o = 1 if st else 0
                 cout = dsts[st].shape[-1]
                 hs, wsz = H >> scale, W >> scale
-                t1 = self.buf(f"dec_t1_{st}", b, hs, wsz, _r4(cout))[..., :cout]
-                # The deconvs run on the LDS-DMA GEMM from split planes (1.81 against 2.46 ms on the fp32-input engine for the six
-                # deconvs of the network, tools/bench_deconv_planes.py).  Stage 0's input has several producers (two warps, a 1x1
-                # conv): one split pass (0.03 ms); stages 1-2 get their planes from the epilogue of the 3x3 conv that produces
-                # their input, already through the stage's leading PReLU.
-                if st == 0 or not pd:
-                    self._deconv_act(ops, P, f"{pfx}.{o}", x, t1, in_prelu=P[f"inprelu:{st}"] if st else None,
-                                     split=f"dec_xp_{st}" if pd else None)
+                if pc:
+                    # planes end to end: deconv (LDS-DMA GEMM) -> planes -> conv+PReLU -> planes -> conv -> fp32 map (flows, masks
+                    # and the refiner's strided convs read it) + planes for the next stage (through its leading PReLU) or for
+                    # the refiner's first conv
+                    if st == 0:
+                        xp_next = self.planes("dec_xp_0", b * (hs // 2) * (wsz // 2), cdec)
+                        ops.split_planes(x.flatten(0, 2), xp_next)
+                    t1p = self.planes(f"dec_t1_{st}_p", b * hs * wsz, cout)
+                    ops.deconv(None, P[f"pk:{pfx}.{o}.0.weight"], None, bias=P[f"{pfx}.{o}.0.bias"], prelu=P[f"{pfx}.{o}.1.weight"],
+                               planes=xp_next, sink=t1p, in_shape=(b, hs // 2, wsz // 2, xp_next.c))
+                    t2p = self.planes(f"dec_t2_{st}_p", b * hs * wsz, cout)
+                    self._c3p(ops, P, f"{pfx}.{o + 1}", t1p, b, hs, wsz, sink=t2p)
+                    if st < 2:
+                        xp_next = self.planes(f"dec_xp_{st + 1}", b * hs * wsz, cout)
+                        self._c3p(ops, P, f"{pfx}.{o + 2}", t2p, b, hs, wsz, out=dsts[st], act=False, sink=xp_next,
+                                  sink_prelu=P[f"inprelu:{st + 1}"])
+                    else:
+                        self._c3p(ops, P, f"{pfx}.{o + 2}", t2p, b, hs, wsz, out=dsts[st], act=False, sink=rin_p)
                 else:
-                    self._deconv_act(ops, P, f"{pfx}.{o}", x, t1, planes=xp_next)
-                t2b = self.buf(f"dec_t2_{st}", b, hs, wsz, _r4(cout))[..., :cout]
-                self._conv_act(ops, P, f"{pfx}.{o + 1}", t1, t2b)
-                if pd and st < 2:
-                    xp_next = self.planes(f"dec_xp_{st + 1}", b * hs * wsz, cout)
-                    self._conv_plain(ops, P, f"{pfx}.{o + 2}", t2b, dsts[st], planes=xp_next, planes_prelu=P[f"inprelu:{st + 1}"])
-                else:
-                    self._conv_plain(ops, P, f"{pfx}.{o + 2}", t2b, dsts[st])
+                    t1 = self.buf(f"dec_t1_{st}", b, hs, wsz, _r4(cout))[..., :cout]
+                    # The deconvs run on the LDS-DMA GEMM from split planes (1.81 against 2.46 ms on the fp32-input engine for the six
+                    # deconvs of the network, tools/bench_deconv_planes.py).  Stage 0's input has several producers (two warps, a 1x1
+                    # conv): one split pass (0.03 ms); stages 1-2 get their planes from the epilogue of the 3x3 conv that produces
+                    # their input, already through the stage's leading PReLU.
+                    if st == 0 or not pd:
+                        self._deconv_act(ops, P, f"{pfx}.{o}", x, t1, in_prelu=P[f"inprelu:{st}"] if st else None,
+                                         split=f"dec_xp_{st}" if pd else None)
+                    else:
+                        self._deconv_act(ops, P, f"{pfx}.{o}", x, t1, planes=xp_next)
+                    t2b = self.buf(f"dec_t2_{st}", b, hs, wsz, _r4(cout))[..., :cout]
+                    self._conv_act(ops, P, f"{pfx}.{o + 1}", t1, t2b)
+                    if pd and st < 2:
+                        xp_next = self.planes(f"dec_xp_{st + 1}", b * hs * wsz, cout)
+                        self._conv_plain(ops, P, f"{pfx}.{o + 2}", t2b, dsts[st], planes=xp_next, planes_prelu=P[f"inprelu:{st + 1}"])
+                    else:
+                        self._conv_plain(ops, P, f"{pfx}.{o + 2}", t2b, dsts[st])
                 x = dsts[st]
                 mot = x[..., cout - 5:cout]
                 a, c, t = (ops.empty(b, 3, hs, wsz) for _ in range(3))
                 if scale == 0:
                     flow0, flow1 = ops.empty(b, 2, H, W), ops.empty(b, 2, H, W)
                     m1, m2 = ops.empty(b, 1, H, W), ops.empty(b, 1, H, W)
-                    ops.warp_blend(pyr0[0], pyr1[0], mot, a, c, t, flow0, flow1, m1, m2, im0, im1, rin[..., w3d + 5:w3d + 20])
+                    if pc:
+                        ops.warp_blend(pyr0[0], pyr1[0], mot, a, c, t, flow0, flow1, m1, m2, im0, im1, None, pack_planes=rin_p,
+                                       pack_c0=pack_c0)
+                    else:
+                        ops.warp_blend(pyr0[0], pyr1[0], mot, a, c, t, flow0, flow1, m1, m2, im0, im1, rin[..., w3d + 5:w3d + 20])
                 else:
                     ops.warp_blend(pyr0[scale], pyr1[scale], mot, a, c, t)
                 w0_list.insert(0, a); w1_list.insert(0, c); it_list.insert(0, t)
             # residual refinement U-Net (:417-431)
-            feat0 = bufA[..., rh:2 * rh]; self._conv_act(ops, P, "proj", rin, feat0)
-            feat1 = bufB[..., rh:2 * rh]; self._conv_act(ops, P, "down1.0", feat0, feat1, 2)
-            d2a = self.buf("d2a", b, H // 4, W // 4, 2 * rh); self._conv_act(ops, P, "down2.0", bufB[..., rh:2 * rh + w2d], d2a, 2)
-            feat2 = bufC[..., 2 * rh:4 * rh]; self._conv_act(ops, P, "down2.1", d2a, feat2)
-            d3a = self.buf("d3a", b, h, w, 4 * rh); self._conv_act(ops, P, "down3.0", bufC[..., 2 * rh:4 * rh + w1d], d3a, 2)
-            d3b = self.buf("d3b", b, h, w, 4 * rh); self._conv_act(ops, P, "down3.1", d3a, d3b)
-            feat3 = self.buf("d3c", b, h, w, 4 * rh); self._conv_act(ops, P, "down3.2", d3b, feat3)
-            u1a = self.buf("u1a", b, H // 4, W // 4, 2 * rh); self._deconv_act(ops, P, "up1.0", feat3, u1a)
-            self._conv_act(ops, P, "up1.1", u1a, bufC[..., 0:2 * rh])
-            u2a = self.buf("u2a", b, H // 2, W // 2, 2 * rh); self._deconv_act(ops, P, "up2.0", bufC[..., 0:4 * rh], u2a)
-            self._conv_act(ops, P, "up2.1", u2a, bufB[..., 0:rh])
-            self._deconv_act(ops, P, "up3.0", bufB[..., 0:2 * rh], bufA[..., 0:rh])
-            r1 = self.buf("r1", b, H, W, rh); self._conv_act(ops, P, "refine_head.0", bufA, r1)
+            r1 = self.buf("r1", b, H, W, rh)
+            if pc:
+                h2, w2, h4, w4 = H // 2, W // 2, H // 4, W // 4
+                bufA_p = self.planes("bufA_p", b * H * W, 2 * rh)                  # [up3 out | feat0]
+                bufB_p = self.planes("bufB_p", b * h2 * w2, 2 * rh)                # [up2 out | feat1]
+                bufC_p = self.planes("bufC_p", b * h4 * w4, 4 * rh)                # [up1 out | feat2]
+                feat0 = bufA[..., rh:2 * rh]
+                self._c3p(ops, P, "proj", rin_p, b, H, W, out=feat0, sink=bufA_p, sink_c0=rh, wkey="pk:proj.0.weight:planes")
+                feat1 = bufB[..., rh:2 * rh]
+                self._conv_s2_sink(ops, P, "down1.0", feat0, bufB_p, (b, h2, w2, rh), out=feat1, sink_c0=rh)
+                d2a_p = self.planes("d2a_p", b * h4 * w4, 2 * rh)
+                self._conv_s2_sink(ops, P, "down2.0", bufB[..., rh:2 * rh + w2d], d2a_p, (b, h4, w4, 2 * rh))
+                feat2 = bufC[..., 2 * rh:4 * rh]
+                self._c3p(ops, P, "down2.1", d2a_p, b, h4, w4, out=feat2, sink=bufC_p, sink_c0=2 * rh)
+                d3a_p = self.planes("d3a_p", b * h * w, 4 * rh)
+                self._conv_s2_sink(ops, P, "down3.0", bufC[..., 2 * rh:4 * rh + w1d], d3a_p, (b, h, w, 4 * rh))
+                d3b_p = self.planes("d3b_p", b * h * w, 4 * rh)
+                self._c3p(ops, P, "down3.1", d3a_p, b, h, w, sink=d3b_p)
+                d3c_p = self.planes("d3c_p", b * h * w, 4 * rh)
+                self._c3p(ops, P, "down3.2", d3b_p, b, h, w, sink=d3c_p)
+                u1a_p = self.planes("u1a_p", b * h4 * w4, 2 * rh)
+                ops.deconv(None, P["pk:up1.0.0.weight"], None, bias=P["up1.0.0.bias"], prelu=P["up1.0.1.weight"], planes=d3c_p, sink=u1a_p,
+                           in_shape=(b, h, w, 4 * rh))
+                self._c3p(ops, P, "up1.1", u1a_p, b, h4, w4, sink=bufC_p, sink_c0=0)
+                u2a_p = self.planes("u2a_p", b * h2 * w2, 2 * rh)
+                ops.deconv(None, P["pk:up2.0.0.weight"], None, bias=P["up2.0.0.bias"], prelu=P["up2.0.1.weight"], planes=bufC_p, sink=u2a_p,
+                           in_shape=(b, h4, w4, 4 * rh))
+                self._c3p(ops, P, "up2.1", u2a_p, b, h2, w2, sink=bufB_p, sink_c0=0)
+                ops.deconv(None, P["pk:up3.0.0.weight"], None, bias=P["up3.0.0.bias"], prelu=P["up3.0.1.weight"], planes=bufB_p, sink=bufA_p,
+                           in_shape=(b, h2, w2, 2 * rh))
+                self._c3p(ops, P, "refine_head.0", bufA_p, b, H, W, out=r1)
+            else:
+                feat0 = bufA[..., rh:2 * rh]; self._conv_act(ops, P, "proj", rin, feat0)
+                feat1 = bufB[..., rh:2 * rh]; self._conv_act(ops, P, "down1.0", feat0, feat1, 2)
+                d2a = self.buf("d2a", b, H // 4, W // 4, 2 * rh); self._conv_act(ops, P, "down2.0", bufB[..., rh:2 * rh + w2d], d2a, 2)
+                feat2 = bufC[..., 2 * rh:4 * rh]; self._conv_act(ops, P, "down2.1", d2a, feat2)
+                d3a = self.buf("d3a", b, h, w, 4 * rh); self._conv_act(ops, P, "down3.0", bufC[..., 2 * rh:4 * rh + w1d], d3a, 2)
+                d3b = self.buf("d3b", b, h, w, 4 * rh); self._conv_act(ops, P, "down3.1", d3a, d3b)
+                feat3 = self.buf("d3c", b, h, w, 4 * rh); self._conv_act(ops, P, "down3.2", d3b, feat3)
+                u1a = self.buf("u1a", b, H // 4, W // 4, 2 * rh); self._deconv_act(ops, P, "up1.0", feat3, u1a)
+                self._conv_act(ops, P, "up1.1", u1a, bufC[..., 0:2 * rh])
+                u2a = self.buf("u2a", b, H // 2, W // 2, 2 * rh); self._deconv_act(ops, P, "up2.0", bufC[..., 0:4 * rh], u2a)
+                self._conv_act(ops, P, "up2.1", u2a, bufB[..., 0:rh])
+                self._deconv_act(ops, P, "up3.0", bufB[..., 0:2 * rh], bufA[..., 0:rh])
+                self._conv_act(ops, P, "refine_head.0", bufA, r1)
             r = self.buf("r", b, H, W, 4); self._conv_act(ops, P, "refine_head.1", r1, r[..., :3])
             it_sum, it_final = ops.empty(b, 3, H, W), ops.empty(b, 3, H, W)
             ops.final_residual(it_list[0], r[..., :3], it_sum, it_final)

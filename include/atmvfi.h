@@ -90,6 +90,16 @@ typedef struct atmvfi_gemm_params {
        finite (they meet zero weights). */
     const void* in_hi;
     const void* in_lo;
+    /* Plane sink (F16X3 only): when out_hi/out_lo are set the result is written (also, or -- with out == NULL -- only) as split
+       planes in the same chunk-major layout with out_plane_rows rows per chunk: channel co of output row r goes to plane row
+       r % out_rpg, channel out_plane_c0 + (r / out_rpg) * out_plane_gc + co (out_rpg == 0: row r, channel out_plane_c0 + co;
+       DECONV: r = output pixel n*Ho*Wo + y*Wo + x; with out_row_map, r is the mapped row).  Channel offsets are multiples of 4;
+       channels past Cout inside the last group of 4 are written as zero.  This is the input format of atmvfi_conv3x3_planes
+       and of atmvfi_gemm's in_hi/in_lo: consecutive contraction layers hand activations over without an fp32 copy. */
+    void* out_hi;
+    void* out_lo;
+    int64_t out_plane_rows;
+    int32_t out_plane_c0, out_plane_gc;
 } atmvfi_gemm_params;
 
 #define ATMVFI_PREC_F32   0
@@ -102,6 +112,10 @@ int atmvfi_gemm(const atmvfi_gemm_params* p, void* stream);
    (each plane holds ceil(C / 32) * plane_rows * 32 halves; the pad channels of the last chunk are written as zero).
    `prelu` (optional, [C]) is applied to the values first. */
 int atmvfi_split_planes(const float* in, int in_ld, int64_t M, int C, const float* prelu, void* hi, void* lo, int plane_rows, void* stream);
+/* The same into a channel range of wider planes: the C channels go to plane channels c0 .. c0 + C (c0 a multiple of 8), channels up to
+   the next multiple of pad_to (8, or 32 with c0 a multiple of 32) are written as zero, everything else is left alone. */
+int atmvfi_split_planes_at(const float* in, int in_ld, int64_t M, int C, const float* prelu, void* hi, void* lo, int plane_rows, int c0,
+                           int pad_to, void* stream);
 
 /* Convenience wrappers with the reference-layer names (thin shims over atmvfi_gemm). */
 int atmvfi_conv2d(const atmvfi_gemm_params* p, void* stream);
@@ -249,6 +263,13 @@ int atmvfi_warp_blend(const float* im0, const float* im1 /*[B,3,H,W] (pre-warped
                       float* flow0_out, float* flow1_out /*[B,2,H,W]*/, float* mask1_out, float* mask2_out /*[B,1,H,W]*/,
                       const float* orig0, const float* orig1, float* pack15, int pack_ld,
                       int B, int H, int W, void* stream);
+/* The same with a plane sink for the pack: the 15 values and one zero as split planes (atmvfi_split_planes layout, pack_rows rows per
+ * chunk, row = pixel b*H*W + y*W + x) at channels pack_c0 .. pack_c0 + 16 (pack_c0 a multiple of 4) -- the operand format of
+ * atmvfi_conv3x3_planes, which the refiner's first conv runs on.  pack_hi / pack_lo may be NULL (= atmvfi_warp_blend). */
+int atmvfi_warp_blend_planes(const float* im0, const float* im1, const float* motion, int motion_ld, int64_t motion_bstride,
+                             float* i0w, float* i1w, float* it, float* flow0_out, float* flow1_out, float* mask1_out, float* mask2_out,
+                             const float* orig0, const float* orig1, float* pack15, int pack_ld, void* pack_hi, void* pack_lo,
+                             int64_t pack_rows, int pack_c0, int B, int H, int W, void* stream);
 #define atmvfi_blend atmvfi_warp_blend   /* SURVEY.md section 8b name */
 
 /* Bilinear resize with align_corners=True, src = dst*(in-1)/(out-1), values * value_scale:
