@@ -60,6 +60,7 @@ struct Conv3PDev {
     long long plane_rows;
     int out_c0;
     const float* plane_prelu;   // optional PReLU applied to the plane copy only (the next layer's leading activation)
+    int out_cmin;               // fp32 output: only channels >= out_cmin (multiple of 4) are stored
     int tiles_x, tiles_y, nblocks, tchunk;
     unsigned long long* stamp;  // diagnostic builds only (ATMVFI_STAMP)
     int dbg;                    // diagnostic builds only: ATMVFI_P3_DBG bits switch pieces of the loop off (wrong results, timing only)
@@ -149,7 +150,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
     //     into ring slots nobody reads any more.
     //   * halo of the next chunk: piece wave + 8 t in k-step t = 0..5; without a next chunk the pieces of the current chunk go to
     //     the other (idle) buffer.
-    const unsigned wlane = (unsigned)((lane >> 2) * 64 + (((lane & 3) ^ swz64(lane >> 2)) << 4));
+    // LDS row i of a 16-row group <- weight row 8 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3): rows 4g..4g+3 of the MFMA result are
+    // then channels {0, 8, 4, 12}[g] .. + 3 (see the epilogue)
+    const int wrow = 8 * ((lane >> 4) & 1) + 4 * (lane >> 5) + ((lane >> 2) & 3);
+    const unsigned wlane = (unsigned)(wrow * 64 + (((lane & 3) ^ swz64(lane >> 2)) << 4));
     const long long step_bytes = (long long)a.wrows * 64;
     const unsigned char* wsrc[SW];          // wave-uniform source of piece s at the next k-step to issue
     int wdst[SW];                           // its byte offset inside a ring slot
@@ -336,7 +340,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
         static_for<0, 3>([&](auto tc) { kstep(tc, std::true_type{}); });
     if (grp == 0) __builtin_amdgcn_s_barrier();          // same number of barriers for both groups
 
-    // ---- epilogue (as conv3x3_f16x3_row.hip) ----
+    // ---- epilogue.  Lane (r, g) holds rows 4g..4g+3 of every 16-row n-tile = channels cb(g)..cb(g)+3 with cb = {0, 8, 4, 12}:
+    // the weight rows were permuted that way on their way into LDS (wlane), so that lanes g and g + 2 -- the two halves of the
+    // wave, which v_permlane32_swap exchanges -- hold the two halves of one 8-channel group.
+    const int cb = 8 * (g & 1) + 4 * (g >> 1);
     float* orow[2];
     long long prow_o[2];
     bool live[2];
@@ -347,22 +354,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
         prow_o[i] = ((long long)img * a.H + (live[i] ? oy : 0)) * a.W + (live[i] ? ox : 0);
         orow[i] = a.out ? a.out + prow_o[i] * a.out_ld : nullptr;
     }
-    f32x4 psl[WN];
-    if (a.out_hi && a.plane_prelu) {
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const int co = n0 + 16 * j + 4 * g;
-            psl[j] = *reinterpret_cast<const f32x4*>(a.plane_prelu + (co < a.Cout ? co : 0));       // padded to 32 by the host
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < WN; ++j) psl[j] = (f32x4){1.f, 1.f, 1.f, 1.f};
-    }
+    f32x4 vv[2][WN];
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
-        const int cl = 16 * j + 4 * g;
-        const int co = n0 + cl;
-        const int nvalid = a.Cout - co;
+        const int cl = 16 * j + cb;
         const f32x4 bv = *reinterpret_cast<const f32x4*>(cst + cl);
         const f32x4 pv = *reinterpret_cast<const f32x4*>(cst + BN + cl);
 #pragma unroll
@@ -372,8 +367,20 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
             v.y = v.y > 0.f ? v.y : pv.y * v.y;
             v.z = v.z > 0.f ? v.z : pv.z * v.z;
             v.w = v.w > 0.f ? v.w : pv.w * v.w;
-            if (live[i]) {
-                if (a.out) {
+            vv[i][j] = v;
+        }
+    }
+    if (a.out) {
+        // fp32 NHWC rows: 16 bytes per lane, the four lanes of a pixel cover 64 contiguous bytes.  Only channels >= out_cmin are
+        // wanted in fp32 (e.g. the five flow / mask channels of a decoder map whose features go on as planes).
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int co = n0 + 16 * j + cb;
+            const int nvalid = a.Cout - co;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const f32x4 v = vv[i][j];
+                if (live[i] && co + 4 > a.out_cmin) {
                     if (nvalid >= 4) {
                         *reinterpret_cast<f32x4*>(orow[i] + co) = v;
                     } else if (nvalid > 0) {
@@ -382,20 +389,54 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
                         if (nvalid > 2) orow[i][co + 2] = v.z;
                     }
                 }
-                if (a.out_hi && nvalid > 0) {
-                    f32x4 u = v;
-                    const f32x4 sl = psl[j];
-                    u.x = u.x > 0.f ? u.x : sl.x * u.x;
-                    u.y = u.y > 0.f ? u.y : sl.y * u.y;
-                    u.z = u.z > 0.f ? u.z : sl.z * u.z;
-                    u.w = u.w > 0.f ? u.w : sl.w * u.w;
-                    if (nvalid < 4) {          // channels past Cout in this group of 4: the planes' pad channels, written as zero
-                        u.y = nvalid > 1 ? u.y : 0.f;
-                        u.z = nvalid > 2 ? u.z : 0.f;
-                        u.w = 0.f;
-                    }
-                    const RowSink sink{nullptr, 0, a.out_hi, a.out_lo, a.plane_rows};
-                    sink_store4(sink, prow_o[i], a.out_c0 + co, u);
+            }
+        }
+    }
+    if (a.out_hi) {
+        // Plane sink, fully coalesced: n-tiles in pairs (j, j+1); one swap per dword gives the lower half-wave the 8 channels
+        // 16j + 8g .. of n-tile j and the upper half-wave those of n-tile j+1 (T21 of the programming guide), so ONE 16-byte
+        // store per lane and plane writes 16 pixels x 32 channels x 2 bytes = one contiguous KiB of the chunk-major plane.
+        // Channels past Cout inside the last group of 8 are zero (zero weight rows, zero bias); groups beyond are not stored.
+        const int climit = (a.Cout + 7) & ~7;
+        constexpr int NP = (WN + 1) / 2;
+#pragma unroll
+        for (int jp = 0; jp < NP; ++jp) {
+            const int j0 = 2 * jp, j1 = (2 * jp + 1 < WN) ? 2 * jp + 1 : 2 * jp;
+            f32x4 s0 = (f32x4){1.f, 1.f, 1.f, 1.f}, s1 = s0;
+            if (a.plane_prelu) {               // padded to a multiple of 32 floats by the host
+                const int c0 = n0 + 16 * j0 + cb, c1 = n0 + 16 * j1 + cb;
+                s0 = *reinterpret_cast<const f32x4*>(a.plane_prelu + (c0 < a.Cout ? c0 : 0));
+                s1 = *reinterpret_cast<const f32x4*>(a.plane_prelu + (c1 < a.Cout ? c1 : 0));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                f32x4 u0 = vv[i][j0], u1 = vv[i][j1];
+                u0.x = u0.x > 0.f ? u0.x : s0.x * u0.x;  u0.y = u0.y > 0.f ? u0.y : s0.y * u0.y;
+                u0.z = u0.z > 0.f ? u0.z : s0.z * u0.z;  u0.w = u0.w > 0.f ? u0.w : s0.w * u0.w;
+                u1.x = u1.x > 0.f ? u1.x : s1.x * u1.x;  u1.y = u1.y > 0.f ? u1.y : s1.y * u1.y;
+                u1.z = u1.z > 0.f ? u1.z : s1.z * u1.z;  u1.w = u1.w > 0.f ? u1.w : s1.w * u1.w;
+                f16x2 h00, l00, h01, l01, h10, l10, h11, l11;
+                split_pair((f32x2){u0.x, u0.y}, h00, l00);
+                split_pair((f32x2){u0.z, u0.w}, h01, l01);
+                split_pair((f32x2){u1.x, u1.y}, h10, l10);
+                split_pair((f32x2){u1.z, u1.w}, h11, l11);
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                auto bits = [](f16x2 v) { return __builtin_bit_cast(unsigned, v); };
+                // vdst = n-tile j0's dword, src = n-tile j1's: lower lanes end up with [own j0 | upper's j0], upper lanes with
+                // [lower's j1 | own j1]
+                const auto sh0 = __builtin_amdgcn_permlane32_swap(bits(h00), bits(h10), false, false);
+                const auto sh1 = __builtin_amdgcn_permlane32_swap(bits(h01), bits(h11), false, false);
+                const auto sl0 = __builtin_amdgcn_permlane32_swap(bits(l00), bits(l10), false, false);
+                const auto sl1 = __builtin_amdgcn_permlane32_swap(bits(l01), bits(l11), false, false);
+                const u32x4 hv = {sh0[0], sh1[0], sh0[1], sh1[1]};
+                const u32x4 lv = {sl0[0], sl1[0], sl0[1], sl1[1]};
+                const int jt = g < 2 ? j0 : 2 * jp + 1;                       // the n-tile this lane stores
+                const int cs = n0 + 16 * jt + 8 * (g & 1);                      // first of its 8 channels
+                if (live[i] && jt < WN && cs < climit) {
+                    const int c = a.out_c0 + cs;
+                    const long long off = ((long long)(c >> 5) * a.plane_rows + prow_o[i]) * 32 + (c & 31);
+                    *reinterpret_cast<u32x4*>(a.out_hi + off) = hv;
+                    *reinterpret_cast<u32x4*>(a.out_lo + off) = lv;
                 }
             }
         }
@@ -440,8 +481,8 @@ int launch_planes(const Conv3PDev& d, int ntiles, hipStream_t s) {
 
 extern "C" int atmvfi_conv3x3_planes(const void* in_hi, const void* in_lo, int64_t in_rows, int N, int H, int W, int Cin, const void* w_hi,
                                       const void* w_lo, int Cout, float* out, int out_ld, const float* bias, const float* prelu,
-                                      void* out_hi, void* out_lo, int64_t plane_rows, int out_c0, const float* plane_prelu, int wn,
-                                      void* stream) {
+                                      void* out_hi, void* out_lo, int64_t plane_rows, int out_c0, const float* plane_prelu, int out_cmin,
+                                      int wn, void* stream) {
     ATMVFI_REQUIRE(in_hi && in_lo && w_hi && w_lo && (out || out_hi), ATMVFI_EINVAL, "conv3x3_planes: null pointer");
     ATMVFI_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, ATMVFI_EINVAL, "conv3x3_planes: bad shape");
     ATMVFI_REQUIRE(in_rows > (int64_t)N * H * W && in_rows * 64 < (1ll << 32), ATMVFI_EINVAL,
@@ -454,12 +495,13 @@ extern "C" int atmvfi_conv3x3_planes(const void* in_hi, const void* in_lo, int64
                        "conv3x3_planes: fp32 output must be 16-byte aligned with ld %% 4 == 0 covering the channels");
     ATMVFI_REQUIRE((out_hi == nullptr) == (out_lo == nullptr), ATMVFI_EINVAL, "conv3x3_planes: plane sink needs both planes");
     if (out_hi) {
-        ATMVFI_REQUIRE(plane_rows >= (int64_t)N * H * W && out_c0 >= 0 && out_c0 % 4 == 0, ATMVFI_EINVAL,
-                       "conv3x3_planes: plane sink needs plane_rows >= N*H*W and a channel offset that is a multiple of 4");
+        ATMVFI_REQUIRE(plane_rows >= (int64_t)N * H * W && out_c0 >= 0 && out_c0 % 8 == 0, ATMVFI_EINVAL,
+                       "conv3x3_planes: plane sink needs plane_rows >= N*H*W and a channel offset that is a multiple of 8");
         ATMVFI_REQUIRE(atmvfi::aligned16(out_hi) && atmvfi::aligned16(out_lo) && (!plane_prelu || atmvfi::aligned16(plane_prelu)),
                        ATMVFI_EALIGN, "conv3x3_planes: plane sink pointers must be 16-byte aligned");
     }
     ATMVFI_REQUIRE(wn >= 0 && wn <= 8, ATMVFI_EINVAL, "conv3x3_planes: wn 0 (auto) or 1..8");
+    ATMVFI_REQUIRE(out_cmin >= 0 && out_cmin % 4 == 0, ATMVFI_EINVAL, "conv3x3_planes: out_cmin must be a non-negative multiple of 4");
     Conv3PDev d;
     d.in_hi = (const _Float16*)in_hi; d.in_lo = (const _Float16*)in_lo; d.in_rows = in_rows;
     d.N = N; d.H = H; d.W = W; d.Cin = Cin;
@@ -469,6 +511,7 @@ extern "C" int atmvfi_conv3x3_planes(const void* in_hi, const void* in_lo, int64
     if (t >= 1 && t <= 8) { d.cf = Cin - t; d.tail = t; } else { d.cf = atmvfi::round_up(Cin, 32); d.tail = 0; }
     d.Cout = Cout; d.out = out; d.out_ld = out_ld; d.bias = bias; d.prelu = prelu;
     d.out_hi = (_Float16*)out_hi; d.out_lo = (_Float16*)out_lo; d.plane_rows = plane_rows; d.out_c0 = out_c0; d.plane_prelu = plane_prelu;
+    d.out_cmin = out_cmin;
     d.tiles_x = (W + TW - 1) / TW;
     d.tiles_y = 0; d.nblocks = 0; d.tchunk = 0;
     const int ntiles = (Cout + 15) / 16;

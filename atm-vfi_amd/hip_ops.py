@@ -73,7 +73,7 @@ SIGNATURES = {
     "atmvfi_conv3x3_weight_halves": (c_l, [c_i, c_i]),
     "atmvfi_pack_weight_conv3x3": (c_i, [c_f, c_f, c_f, c_i, c_i, c_f]),
     "atmvfi_conv3x3_f16x3": (c_i, [c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_l, c_f, c_f]),
-    "atmvfi_conv3x3_planes": (c_i, [c_f, c_f, c_l, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_l, c_i, c_f, c_i, c_f]),
+    "atmvfi_conv3x3_planes": (c_i, [c_f, c_f, c_l, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_l, c_i, c_f, c_i, c_i, c_f]),
     "atmvfi_conv3x3_set_schedule": (c_i, [c_i, c_i]),
     "atmvfi_gemm_f16x3_set_tile_width": (c_i, [c_i]),
     "atmvfi_layernorm": (c_i, [c_f, c_i, c_l, c_i, c_f, c_f, c_i, c_f, c_f, c_l, c_i, c_f, c_f, c_i, c_f]),
@@ -366,10 +366,11 @@ class HipOps:
 
     def conv3x3_planes(self, x: Planes, n: int, h: int, wd: int, w: PackedWeight, out=None, bias=None, prelu=None,
                        planes: Optional[Planes] = None, planes_c0: int = 0, planes_prelu=None, in_chunk0: int = 0, cin: Optional[int] = None,
-                       wn: int = 0):
+                       wn: int = 0, out_cmin: int = 0):
         """3x3 / stride 1 / pad 1 conv (+bias, PReLU) on split-plane input ``x`` (rows = pixels of an [n,h,wd] map; channels
         ``32*in_chunk0 .. +cin``).  ``out``: fp32 NHWC view or None; ``planes``: plane sink written at channel offset ``planes_c0``
-        (its own ``planes_prelu`` applied to that copy only).  Needs the spare zero row of ``Planes.alloc``."""
+        (its own ``planes_prelu`` applied to that copy only).  ``out_cmin``: only channels >= it are stored in ``out``.  Needs the spare
+        zero row of ``Planes.alloc``."""
         cin = (x.c - 32 * in_chunk0) if cin is None else cin
         if self.precision != "f16x3" or w.hi3 is None:
             raise ValueError("conv3x3_planes: needs the f16x3 engine and the conv3x3 weight planes")
@@ -387,7 +388,7 @@ class HipOps:
         elif planes is None:
             raise ValueError("conv3x3_planes: no output")
         if planes is not None:
-            if planes.rows != n * h * wd or planes_c0 % 4 or planes_c0 + cout > planes.chunks * 32:
+            if planes.rows != n * h * wd or planes_c0 % 8 or planes_c0 + cout > planes.chunks * 32:
                 raise ValueError(f"conv3x3_planes: plane sink [{planes.rows},{planes.c}] cannot take {cout} channels at offset {planes_c0}")
             if planes_prelu is not None and planes_prelu.numel() < (cout + 31) // 32 * 32:
                 raise ValueError("conv3x3_planes: planes_prelu must be padded to a multiple of 32 channels")
@@ -397,7 +398,7 @@ class HipOps:
         self._run("conv3x3_planes", meta, self.lib.atmvfi_conv3x3_planes, x.t[0].data_ptr() + coff, x.t[1].data_ptr() + coff, x.ld_rows,
                   n, h, wd, cin, _ptr(w.hi3), _ptr(w.lo3), cout, _ptr(out), old, _ptr(bias), _ptr(prelu),
                   planes.t[0].data_ptr() if planes is not None else None, planes.t[1].data_ptr() if planes is not None else None,
-                  planes.ld_rows if planes is not None else 0, planes_c0, _ptr(planes_prelu) if planes is not None else None, wn,
+                  planes.ld_rows if planes is not None else 0, planes_c0, _ptr(planes_prelu) if planes is not None else None, out_cmin, wn,
                   self._stream())
 
     def deconv(self, x, w: PackedWeight, out, bias=None, prelu=None, in_prelu=None, planes: Optional[Planes] = None,

@@ -255,14 +255,15 @@ class Network(nn.Module):
         split planes by the producing layer's sink, fp32 copies only where something other than a contraction reads them."""
         return self._plane_deconvs(ops) and self.use_plane_convs
 
-    def _c3p(self, ops, P, p, xp, n, h, w, out=None, act=True, sink=None, sink_c0=0, sink_prelu=None, wkey=None):
+    def _c3p(self, ops, P, p, xp, n, h, w, out=None, act=True, sink=None, sink_c0=0, sink_prelu=None, wkey=None, out_cmin=0):
         """conv()/Conv2d 3x3 s1 p1 of the reference on split-plane input ``xp`` ([n*h*w rows]); ``p`` = parameter prefix
         (``p.0.weight``/``p.0.bias``/``p.1.weight`` with ``act``, ``p.weight``/``p.bias`` without)."""
         if act:
             wk, bias, prelu = wkey or f"pk:{p}.0.weight", P[f"{p}.0.bias"], P[f"{p}.1.weight"]
         else:
             wk, bias, prelu = wkey or f"pk:{p}.weight", P[f"{p}.bias"], None
-        ops.conv3x3_planes(xp, n, h, w, P[wk], out=out, bias=bias, prelu=prelu, planes=sink, planes_c0=sink_c0, planes_prelu=sink_prelu)
+        ops.conv3x3_planes(xp, n, h, w, P[wk], out=out, bias=bias, prelu=prelu, planes=sink, planes_c0=sink_c0, planes_prelu=sink_prelu,
+                           out_cmin=out_cmin)
 
     def _conv_s2_sink(self, ops, P, p, x, sink, shape, out=None, sink_c0=0):
         """conv() 3x3 stride 2 (+PReLU) on the fp32-input GEMM engine, result to a plane sink (and ``out`` if given)."""
@@ -633,7 +634,9 @@ class Network(nn.Module):
                         self._c3p(ops, P, f"{pfx}.{o + 2}", t2p, b, hs, wsz, out=dsts[st], act=False, sink=xp_next,
                                   sink_prelu=P[f"inprelu:{st + 1}"])
                     else:
-                        self._c3p(ops, P, f"{pfx}.{o + 2}", t2p, b, hs, wsz, out=dsts[st], act=False, sink=rin_p)
+                        # finest level: only the five flow / mask channels are read in fp32 (by warp_blend); the features go on
+                        # to the refiner as planes
+                        self._c3p(ops, P, f"{pfx}.{o + 2}", t2p, b, hs, wsz, out=dsts[st], act=False, sink=rin_p, out_cmin=(cout - 5) // 4 * 4)
                 else:
                     t1 = self.buf(f"dec_t1_{st}", b, hs, wsz, _r4(cout))[..., :cout]
                     # The deconvs run on the LDS-DMA GEMM from split planes (1.81 against 2.46 ms on the fp32-input engine for the six

@@ -191,6 +191,7 @@ def main():
             # kernel families and the MFMA peak that bounds them: the f16x3 engines issue three
             # 16-bit MFMAs per algorithmic multiply-add, so their algorithmic peak is 2500/3 TFLOP/s.
             families = {
+                "conv3x3_planes_kernel (3x3 s1 convs on split-plane input, LDS-DMA halo, ping-pong wave groups)": (["conv3x3_planes"], PEAK_F16_MFMA_TFLOPS / 3.0),
                 "conv3x3_f16x3_row_kernel": (["conv3x3_f16x3"], PEAK_F16_MFMA_TFLOPS / 3.0),
                 "gemm_f16x3_kernel (linear + deconv2x2 + strided conv2d)": (["linear_f16x3", "deconv2x2_f16x3", "conv2d_f16x3"], PEAK_F16_MFMA_TFLOPS / 3.0),
                 "gemm_split_kernel (nn.Linear rows from split planes, LDS-DMA)": (["linear_split", "deconv2x2_split"], PEAK_F16_MFMA_TFLOPS / 3.0),

@@ -165,12 +165,13 @@ int atmvfi_conv3x3_f16x3(const float* in, int in_ld, int N, int H, int W, int Ci
  * issues MFMAs while the other reads fragments and issues DMA).  Bit-identical to atmvfi_conv3x3_f16x3 on the same values.
  * Contract of the input planes: in_rows > N*H*W and row N*H*W of every chunk is ZERO (it is the source of the halo pixels that
  * fall outside the image; atm-vfi_amd's Planes.alloc reserves it); pad channels of the last chunk are zero; in_rows * 64 < 2^32.
- * Outputs: fp32 NHWC view `out` (may be NULL) and / or the plane sink out_hi / out_lo (may be NULL; not both NULL) at channel
- * offset out_c0 (multiple of 4) of a plane buffer with plane_rows rows, through plane_prelu (as atmvfi_conv3x3_f16x3).
+ * Outputs: fp32 NHWC view `out` (may be NULL; only channels >= out_cmin, a multiple of 4, are stored) and / or the plane sink
+ * out_hi / out_lo (may be NULL; not both NULL) at channel offset out_c0 (multiple of 8) of a plane buffer with plane_rows rows,
+ * through plane_prelu (as atmvfi_conv3x3_f16x3); plane channels from Cout up to the next multiple of 8 are written as zero.
  * wn: 0 = pick the tile width (n-tiles of 16 output channels per workgroup) from the cost model, 1..8 = force it (tests, sweeps). */
 int atmvfi_conv3x3_planes(const void* in_hi, const void* in_lo, int64_t in_rows, int N, int H, int W, int Cin, const void* w_hi,
                           const void* w_lo, int Cout, float* out, int out_ld, const float* bias, const float* prelu, void* out_hi,
-                          void* out_lo, int64_t plane_rows, int out_c0, const float* plane_prelu, int wn, void* stream);
+                          void* out_lo, int64_t plane_rows, int out_c0, const float* plane_prelu, int out_cmin, int wn, void* stream);
 /* The 3x3 kernel has two schedules (512-thread 16x16 tiles, one workgroup per CU; 256-thread 16x8 tiles, two per CU) and 1..8
  * n-tiles of 16 output channels per workgroup, picked per layer from a cost model.  This process-wide override exists for the
  * parity tests, which must reach every instance of the kernel, and for same-box A/B timing: schedule -1 = cost model (default),

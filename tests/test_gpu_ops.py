@@ -451,14 +451,15 @@ def test_split_planes_format(hip, dev):
     buf = torch.zeros(150, 72)
     buf[:, :70] = x
     p = hip_ops.Planes.alloc(150, 70, dev)
-    assert p.chunks == 3 and tuple(p.t.shape) == (2, 3, 150, 32)          # chunk major: [plane, chunk, row, 32]
+    assert p.chunks == 3 and p.rows == 150 and tuple(p.t.shape) == (2, 3, 151, 32)     # chunk major: [plane, chunk, row (+1 spare zero row), 32]
     hip.split_planes(buf.to(dev)[:, :70], p)
     torch.cuda.synchronize()
     hi = x.clamp(-65504, 65504).half()
     lo = ((x.clamp(-3e38, 3e38) - hi.float()) * 1024).clamp(-65504, 65504).half()
     pr = p.to_rows()
     assert torch.equal(pr[0, :, :70].cpu(), hi) and torch.equal(pr[1, :, :70].cpu(), lo)
-    assert torch.equal(p.t[0, 2, :, 5].cpu(), hi[:, 69])                  # channel 69 = chunk 2, element 5
+    assert torch.equal(p.t[0, 2, :150, 5].cpu(), hi[:, 69])               # channel 69 = chunk 2, element 5
+    assert (p.t[:, :, 150] == 0).all()                                    # the spare row stays zero
     assert (pr[:, :, 70:] == 0).all()                                     # pad channels are written as zero
     err = (planes_to_f32(p) - x.double()).abs()
     normal = (x.abs() <= 65504) & (x.abs() >= 2.0 ** -14)
