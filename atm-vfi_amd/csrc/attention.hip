@@ -191,8 +191,8 @@ int launch_attn(const float* qkv, const RowSink out, float* motion, const int* l
     ATMVFI_REQUIRE(lds <= 160 * 1024, ATMVFI_EINVAL,
                    "window_attention: K/V tile of %zu bytes exceeds the 160 KiB LDS (ws %d, hd %d)", lds, ws, hd);
     auto kern = window_attn_kernel<NT>;
-    if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 48 * 1024) {       // raised once per device and kernel instance (common.h), not on every launch
+        const hipError_t e = atmvfi::allow_dynamic_lds<window_attn_kernel<NT>>(lds);
         ATMVFI_REQUIRE(e == hipSuccess, ATMVFI_ELAUNCH, "window_attention: hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
     const float scale = 1.0f / sqrtf((float)hd);

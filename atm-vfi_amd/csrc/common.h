@@ -6,6 +6,8 @@
 #include <stdio.h>
 #include <type_traits>
 
+#include <atomic>
+
 #include "atmvfi.h"
 
 namespace atmvfi {
@@ -16,16 +18,35 @@ int check_launch(const char* what);
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
-// compute units of the current device rounded down to a multiple of 8 (persistent grids keep block % 8 == XCD group)
+constexpr int kMaxDevices = 64;
+// compute units of the CURRENT device rounded down to a multiple of 8 (persistent grids keep block % 8 == XCD group); cached per
+// device id (one process may drive several GPUs)
 static inline int cu_count() {
-    static int n = 0;
+    static std::atomic<int> cache[kMaxDevices];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 256;
+    int n = cache[dev].load(std::memory_order_relaxed);
     if (n == 0) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8)
-            cus = 256;
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
         n = cus / 8 * 8;
+        cache[dev].store(n, std::memory_order_relaxed);
     }
     return n;
+}
+// hipFuncAttributeMaxDynamicSharedMemorySize of one kernel, raised once per device (the attribute belongs to the device's copy of
+// the function; a process-wide "done" flag would leave the second GPU of a process at the 64 KiB default)
+template <auto Kern>
+static inline hipError_t allow_dynamic_lds(size_t bytes) {
+    static std::atomic<int> granted[kMaxDevices];
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const bool cached = dev >= 0 && dev < kMaxDevices;
+    if (cached && granted[dev].load(std::memory_order_acquire) >= (int)bytes) return hipSuccess;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(Kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess && cached) granted[dev].store((int)bytes, std::memory_order_release);
+    return e;
 }
 
 }  // namespace atmvfi

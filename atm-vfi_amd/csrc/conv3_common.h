@@ -30,6 +30,7 @@ struct Conv3Dev {
     int nblocks;    // column blocks per spatial tile (set by the launcher)
     int legacy_order;   // A/B switch (ATMVFI_LEGACY_ORDER=1): round-robin tiles over XCDs
     int tchunk;     // spatial tiles per XCD = ceil(tiles / 8) (set by the launcher)
+    int force_schedule, force_wn;   // per-call overrides: schedule -1 = cost model, 0 = row, 1 = half; wn 0 = cost model, 1..8
     unsigned long long* stamp;   // diagnostic builds only (ATMVFI_STAMP)
 };
 // conv3x3_f16x3_row.hip: three taps (one kernel row) per stage, single-buffered halo

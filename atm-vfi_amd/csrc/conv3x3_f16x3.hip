@@ -117,8 +117,10 @@ extern "C" int atmvfi_pack_weight_split(int mode, const float* src, void* dst_hi
 extern "C" int atmvfi_conv3x3_f16x3(const float* in, int in_ld, int N, int H, int W, int Cin, const void* w_hi,
                                      const void* w_lo, int Cout, float* out, int out_ld, const float* bias,
                                      const float* prelu, void* out_hi, void* out_lo, int64_t plane_rows,
-                                     const float* plane_prelu, void* stream) {
+                                     const float* plane_prelu, int schedule, int wn, void* stream) {
     ATMVFI_REQUIRE(in && w_hi && w_lo && out, ATMVFI_EINVAL, "conv3x3_f16x3: null pointer");
+    ATMVFI_REQUIRE(schedule >= -1 && schedule <= 1 && wn >= 0 && wn <= 8, ATMVFI_EINVAL,
+                   "conv3x3_f16x3: schedule -1 (auto), 0 (row) or 1 (half), wn 0 (auto) or 1..8; got %d, %d", schedule, wn);
     ATMVFI_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, ATMVFI_EINVAL, "conv3x3_f16x3: bad shape");
     ATMVFI_REQUIRE(in_ld % 4 == 0 && in_ld >= atmvfi::round_up(Cin, 4) && out_ld % 4 == 0 && out_ld >= atmvfi::round_up(Cout, 4),
                    ATMVFI_EALIGN, "conv3x3_f16x3: leading dimensions must be multiples of 4 and cover the channels");
@@ -144,6 +146,8 @@ extern "C" int atmvfi_conv3x3_f16x3(const float* in, int in_ld, int N, int H, in
     d.nblocks = 0;
     d.tchunk = 0;
     d.legacy_order = 0;
+    d.force_schedule = schedule;
+    d.force_wn = wn;
     d.tiles_x = (W + TW - 1) / TW;
     d.tiles_y = 0;                                  // set by the launcher: the tile height depends on the schedule
     ATMVFI_REQUIRE((long long)N * d.tiles_x * ((H + 7) / 8) * 8 < (1ll << 31), ATMVFI_EINVAL, "conv3x3_f16x3: grid too large");

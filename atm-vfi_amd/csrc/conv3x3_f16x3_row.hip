@@ -15,8 +15,6 @@
 
 #include <stdlib.h>
 
-#include <atomic>
-
 #ifdef ATMVFI_STAMP
 // Diagnostic build only (`make stamp`, tools/stamp_conv.py): per-wave cycle sums of the phases of a stage.
 static unsigned long long* g_stamp_buf = nullptr;
@@ -36,17 +34,6 @@ extern "C" void atmvfi_debug_set_stamp_buffer(void* p) { g_stamp_buf = (unsigned
 #else
 #define ABL(bit) false
 #endif
-
-// Override for tests and A/B runs (atmvfi_conv3x3_set_schedule): schedule -1 = cost model (default), 0 = row, 1 = half;
-// wn 0 = cost model, 1..8 = n-tiles per workgroup.
-static std::atomic<int> g_conv3_schedule{-1}, g_conv3_wn{0};
-extern "C" int atmvfi_conv3x3_set_schedule(int schedule, int wn) {
-    ATMVFI_REQUIRE(schedule >= -1 && schedule <= 1, ATMVFI_EINVAL, "conv3x3_set_schedule: schedule -1 (auto), 0 (row) or 1 (half), got %d", schedule);
-    ATMVFI_REQUIRE(wn >= 0 && wn <= 8, ATMVFI_EINVAL, "conv3x3_set_schedule: wn 0 (auto) or 1..8, got %d", wn);
-    g_conv3_schedule = schedule;
-    g_conv3_wn = wn;
-    return 0;
-}
 
 namespace {
 
@@ -424,16 +411,19 @@ int launch_row(const Conv3Dev& d, int ntiles, hipStream_t s) {
     constexpr int TH = 2 * NWV, NPIX = HW_ * (TH + 2);
     const size_t lds = (size_t)(2 * NPIX * 32 + 2 * 2 * TAPS * BN * 32) * sizeof(_Float16) + epilogue_const_floats(BN) * sizeof(float);
     auto kern = conv3x3_f16x3_row_kernel<WN, NWV, TAPS>;
-    // once per template instance, thread-safe (function-local static initialisation)
-    static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const hipError_t attr_err = atmvfi::allow_dynamic_lds<conv3x3_f16x3_row_kernel<WN, NWV, TAPS>>(lds);
     ATMVFI_REQUIRE(attr_err == hipSuccess, ATMVFI_ELAUNCH, "conv3x3_f16x3_row: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
     Conv3Dev ds = d;
     ds.nblocks = (ntiles + WN - 1) / WN;
     ds.tiles_y = (d.H + TH - 1) / TH;
     const long long sgroups = ((long long)d.N * d.tiles_x * ds.tiles_y + 7) / 8;
     ds.tchunk = (int)sgroups;
-    static const int legacy = [] { const char* e = getenv("ATMVFI_LEGACY_ORDER"); return e ? atoi(e) : 0; }();
+#if defined(ATMVFI_ABLATE) || defined(ATMVFI_STAMP)
+    static const int legacy = [] { const char* e = getenv("ATMVFI_LEGACY_ORDER"); return e ? atoi(e) : 0; }();     // diagnostic builds only
     ds.legacy_order = legacy;
+#else
+    ds.legacy_order = 0;
+#endif
     ATMVFI_REQUIRE(sgroups * 8 * ds.nblocks < (1LL << 31), ATMVFI_EINVAL, "conv3x3_f16x3_row: grid too large");
     dim3 grid((unsigned)(sgroups * 8 * ds.nblocks));
 #ifdef ATMVFI_STAMP
@@ -458,12 +448,15 @@ int atmvfi::launch_conv3x3_row(const Conv3Dev& d, int ntiles, hipStream_t s) {
     //               112-wide ones are even).  The half schedule overlaps two workgroups' DMA issue, barrier waits and halo
     //               conversion and quantises better on small images (8-row tiles), but streams the weights twice per 256 pixels
     //               and pays a barrier per tap; three taps per stage on the half tiles measured no better.
-    // ATMVFI_CONV3_SCHED=row|half or atmvfi_conv3x3_set_schedule() force a schedule / width.
-    static const int env_forced = [] { const char* e = getenv("ATMVFI_CONV3_SCHED"); return !e ? -1 : (e[0] == 'h' ? 1 : 0); }();
-    const int sched_override = g_conv3_schedule.load(), wn_override = g_conv3_wn.load();
-    const int forced = sched_override >= 0 ? sched_override : env_forced;
+    // The caller may force either (atmvfi_conv3x3_f16x3's `schedule` / `wn` arguments: parity tests, sweeps); the library keeps no
+    // override of its own.
+    const int forced = d.force_schedule, wn_override = d.force_wn;
     static const float rel[9] = {1.f, 1.10f, 1.20f, 0.88f, 0.95f, 1.15f, 1.07f, 1.06f, 1.02f};     // re-measured with the pipelined fragment reads (tools/tune_conv3.py)
-    static const float c0 = [] { const char* e = getenv("ATMVFI_CONV3_C0"); return e ? (float)atof(e) : 2.0f; }();
+#if defined(ATMVFI_ABLATE) || defined(ATMVFI_STAMP)
+    static const float c0 = [] { const char* e = getenv("ATMVFI_CONV3_C0"); return e ? (float)atof(e) : 2.0f; }();     // diagnostic builds only
+#else
+    constexpr float c0 = 2.0f;
+#endif
     const int ncu = atmvfi::cu_count();
     const long long spatial_row = (long long)d.N * d.tiles_x * ((d.H + 15) / 16);
     const long long spatial_half = (long long)d.N * d.tiles_x * ((d.H + 7) / 8);
@@ -479,8 +472,10 @@ int atmvfi::launch_conv3x3_row(const Conv3Dev& d, int ntiles, hipStream_t s) {
         if (forced != 1 && c_row <= best_cost) { best_cost = c_row; best = wn; half = false; }
         if (forced != 0 && c_half <= best_cost) { best_cost = c_half; best = wn; half = true; }
     }
+#if defined(ATMVFI_ABLATE) || defined(ATMVFI_STAMP)
     static const bool verbose = getenv("ATMVFI_CONV3_VERBOSE") != nullptr;
     if (verbose) fprintf(stderr, "conv3x3 N%d H%d W%d Cin%d Cout%d -> WN %d %s (cost %.2f)\n", d.N, d.H, d.W, d.Cin, d.Cout, best, half ? "half" : "row", best_cost);
+#endif
 #define ATMVFI_C3_CASE(W) case W: return half ? launch_row<W, 4, 1>(d, ntiles, s) : launch_row<W, 8, 3>(d, ntiles, s);
     switch (best) {
         ATMVFI_C3_CASE(1) ATMVFI_C3_CASE(2) ATMVFI_C3_CASE(3) ATMVFI_C3_CASE(4) ATMVFI_C3_CASE(5) ATMVFI_C3_CASE(6) ATMVFI_C3_CASE(7)

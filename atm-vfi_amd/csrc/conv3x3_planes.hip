@@ -457,7 +457,7 @@ int launch_planes(const Conv3PDev& d, int ntiles, hipStream_t s) {
     constexpr int BN = 16 * WN;
     const size_t lds = (size_t)2 * HALO_BYTES + (size_t)ring_slots(WN) * 2 * BN * 64 + epilogue_const_floats(BN) * sizeof(float);
     auto kern = conv3x3_planes_kernel<WN>;
-    static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const hipError_t attr_err = atmvfi::allow_dynamic_lds<conv3x3_planes_kernel<WN>>(lds);
     ATMVFI_REQUIRE(attr_err == hipSuccess, ATMVFI_ELAUNCH, "conv3x3_planes: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
     Conv3PDev ds = d;
     ds.nblocks = (ntiles + WN - 1) / WN;

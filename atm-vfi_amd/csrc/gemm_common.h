@@ -53,6 +53,7 @@ struct GemmDev {
     _Float16* out_lo;
     long long out_plane_rows;
     int out_c0, out_gc;
+    int force_wn;     // per-call tile-width override of gemm_f16x3 (0 = cost model)
 };
 
 

@@ -15,7 +15,6 @@
 
 #include <stdlib.h>
 
-#include <atomic>
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
@@ -347,8 +346,7 @@ int launch(const GemmDev& d, int ntiles, hipStream_t s) {
     constexpr int BN = 16 * WN;
     const size_t lds = (size_t)(4 * 256 * 32 + 4 * BN * 32) * sizeof(_Float16) + 2 * atmvfi::gemm_const_floats(BN) * sizeof(float);
     auto kern = gemm_f16x3_kernel<WN>;
-    // once per template instance, thread-safe (function-local static initialisation)
-    static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const hipError_t attr_err = atmvfi::allow_dynamic_lds<gemm_f16x3_kernel<WN>>(lds);
     ATMVFI_REQUIRE(attr_err == hipSuccess, ATMVFI_ELAUNCH, "gemm_f16x3: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
     GemmDev dd = d;
     dd.nblocks = (ntiles + WN - 1) / WN;
@@ -356,8 +354,12 @@ int launch(const GemmDev& d, int ntiles, hipStream_t s) {
     ATMVFI_REQUIRE(mgroups * 8 * dd.nblocks < (1LL << 31), ATMVFI_EINVAL, "gemm_f16x3: too many tiles");
     dd.vblocks = (int)(mgroups * 8 * dd.nblocks);
     dd.mchunk = (int)mgroups;
-    static const int legacy = [] { const char* e = getenv("ATMVFI_LEGACY_ORDER"); return e ? atoi(e) : 0; }();
+#if defined(ATMVFI_ABLATE) || defined(ATMVFI_STAMP)
+    static const int legacy = [] { const char* e = getenv("ATMVFI_LEGACY_ORDER"); return e ? atoi(e) : 0; }();     // diagnostic builds only
     dd.dbg = legacy ? 8 : 0;
+#else
+    dd.dbg = 0;
+#endif
 #ifdef ATMVFI_STAMP
     dd.stamp = g_gemm_stamp;
 #endif
@@ -370,20 +372,16 @@ int launch(const GemmDev& d, int ntiles, hipStream_t s) {
 
 }  // namespace
 
-// Tile-width override for A/B sweeps (tools/tune_gemm.py): 0 = cost model (default), 1..8 = n-tiles per workgroup.
-static std::atomic<int> g_gemm_wn{0};
-extern "C" int atmvfi_gemm_f16x3_set_tile_width(int wn) {
-    ATMVFI_REQUIRE(wn >= 0 && wn <= 8, ATMVFI_EINVAL, "gemm_f16x3_set_tile_width: 0 (auto) or 1..8, got %d", wn);
-    g_gemm_wn = wn;
-    return 0;
-}
-
 int atmvfi::launch_gemm_f16x3(const GemmDev& d, int ngemm, hipStream_t s) {
     const int ntiles = (ngemm + 15) / 16;
     // tile width: time ~ rounds x tile time; tile time ~ WN * (1 + cfac/WN) (MFMA work ~ WN; operand staging incl. the fp32 ->
     // fp16-pair split, redone per column block, ~ const: weight 2 measured best, deconv 788x389 -12 %); rounds = ceil(tiles / CUs)
     // of the persistent grid, which is what keeps small maps busy (M = 8 640, N = 256: 68 tiles at WN = 8, 204 at WN = 3)
-    static const float cfac = [] { const char* e = getenv("ATMVFI_WN_COST"); return e ? (float)atof(e) : 2.0f; }();
+#if defined(ATMVFI_ABLATE) || defined(ATMVFI_STAMP)
+    static const float cfac = [] { const char* e = getenv("ATMVFI_WN_COST"); return e ? (float)atof(e) : 2.0f; }();     // diagnostic builds only
+#else
+    constexpr float cfac = 2.0f;
+#endif
     const int ncu = atmvfi::cu_count();
     const long long mtiles = atmvfi::ceil_div64(d.M, 256);
     int best = 1;
@@ -394,7 +392,7 @@ int atmvfi::launch_gemm_f16x3(const GemmDev& d, int ngemm, hipStream_t s) {
         const float cost = rounds * (float)wn * (1.0f + cfac / (float)wn);
         if (cost <= best_cost) { best_cost = cost; best = wn; }
     }
-    if (const int wn_override = g_gemm_wn.load(); wn_override > 0) best = wn_override;
+    if (d.force_wn > 0) best = d.force_wn;          // per-call override (atmvfi_gemm_params.tile_wn: sweeps, tests)
     switch (best) {
         case 1: return launch<1>(d, ntiles, s);
         case 2: return launch<2>(d, ntiles, s);

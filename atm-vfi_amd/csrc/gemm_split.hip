@@ -330,12 +330,15 @@ int launch_split(const GemmDev& d, int ngemm, hipStream_t s) {
     constexpr int BM = 64 * WGM, BN = 64 * WGN;
     const size_t lds = (size_t)3 * (2 * BM + 2 * BN) * 32 * sizeof(_Float16) + atmvfi::gemm_const_floats(BN) * sizeof(float);
     auto kern = gemm_split_kernel<WGM, WGN>;
-    // once per template instance, thread-safe (function-local static initialisation)
-    static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const hipError_t attr_err = atmvfi::allow_dynamic_lds<gemm_split_kernel<WGM, WGN>>(lds);
     ATMVFI_REQUIRE(attr_err == hipSuccess, ATMVFI_ELAUNCH, "gemm_split: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
     GemmDev dd = d;
-    static const int dbg = [] { const char* e = getenv("ATMVFI_SPLIT_DEBUG"); return e ? atoi(e) : 0; }();
+#if defined(ATMVFI_ABLATE) || defined(ATMVFI_STAMP)
+    static const int dbg = [] { const char* e = getenv("ATMVFI_SPLIT_DEBUG"); return e ? atoi(e) : 0; }();     // diagnostic builds only
     dd.dbg = dbg;
+#else
+    dd.dbg = 0;
+#endif
 #ifdef ATMVFI_STAMP
     dd.stamp = g_split_stamp;
 #endif

@@ -52,7 +52,7 @@ class GemmParams(ctypes.Structure):
         ("precision", ctypes.c_int32), ("weight_hi", c_f), ("weight_lo", c_f),
         ("in_hi", c_f), ("in_lo", c_f),
         ("out_hi", c_f), ("out_lo", c_f), ("out_plane_rows", ctypes.c_int64), ("out_plane_c0", ctypes.c_int32),
-        ("out_plane_gc", ctypes.c_int32),
+        ("out_plane_gc", ctypes.c_int32), ("tile_wn", ctypes.c_int32),
     ]
 
 
@@ -72,10 +72,8 @@ SIGNATURES = {
     "atmvfi_pack_weight_split": (c_i, [c_i, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     "atmvfi_conv3x3_weight_halves": (c_l, [c_i, c_i]),
     "atmvfi_pack_weight_conv3x3": (c_i, [c_f, c_f, c_f, c_i, c_i, c_f]),
-    "atmvfi_conv3x3_f16x3": (c_i, [c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_l, c_f, c_f]),
+    "atmvfi_conv3x3_f16x3": (c_i, [c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_l, c_f, c_i, c_i, c_f]),
     "atmvfi_conv3x3_planes": (c_i, [c_f, c_f, c_l, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_l, c_i, c_f, c_i, c_i, c_f]),
-    "atmvfi_conv3x3_set_schedule": (c_i, [c_i, c_i]),
-    "atmvfi_gemm_f16x3_set_tile_width": (c_i, [c_i]),
     "atmvfi_layernorm": (c_i, [c_f, c_i, c_l, c_i, c_f, c_f, c_i, c_f, c_f, c_l, c_i, c_f, c_f, c_i, c_f]),
     "atmvfi_dwconv3x3_gelu": (c_i, [c_f, c_i, c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f]),
     "atmvfi_pack_dw_weight": (c_i, [c_f, c_f, c_i, c_f]),
@@ -236,6 +234,10 @@ class HipOps:
         # "f16x3": 3x3/s1 convs run split-precision on the 16-bit MFMA (hi*hi + hi*lo + lo*hi, fp32 accumulate);
         # "f32": everything on the exact-fp32 MFMA.
         self.precision = "f16x3"
+        # per-call kernel-instance overrides (parity tests, sweeps): (schedule, wn) of the fp32-input 3x3 kernel, tile width of the
+        # fp32-input f16x3 GEMM; None / 0 = the library's cost model
+        self.conv3_instance = None
+        self.gemm_tile_wn = 0
 
     # ------------------------------------------------------------------ utils
     def _stream(self):
@@ -352,7 +354,8 @@ class HipOps:
             self._run("conv3x3_f16x3", meta, self.lib.atmvfi_conv3x3_f16x3, _ptr(x), ld, n, h, wd, cin, _ptr(w.hi3), _ptr(w.lo3),
                       cout, _ptr(out), old, _ptr(bias), _ptr(prelu),
                       planes.t[0].data_ptr() if planes is not None else None, planes.t[1].data_ptr() if planes is not None else None,
-                      planes.ld_rows if planes is not None else 0, _ptr(planes_prelu) if planes is not None else None, self._stream())
+                      planes.ld_rows if planes is not None else 0, _ptr(planes_prelu) if planes is not None else None,
+                      *(self.conv3_instance or (-1, 0)), self._stream())
             return
         if planes is not None and planes_prelu is not None:
             raise ValueError("conv: planes_prelu needs the 3x3 / stride-1 f16x3 kernel")
@@ -361,6 +364,7 @@ class HipOps:
                        Ho=oh, Wo=ow, M=n * oh * ow, out=None if out is None else out.data_ptr(), out_ld=old, out_gstride=0, out_rpg=0,
                        out_row_map=None, bias=_ptr(bias), prelu=_ptr(prelu), in_prelu=_ptr(in_prelu), residual=None, res_ld=0)
         p.precision, p.weight_hi, p.weight_lo = self._prec(w)
+        p.tile_wn = self.gemm_tile_wn
         self._gemm_sink(p, planes, n * oh * ow, cout, planes_c0, 0, 1, "conv")
         self._run("conv2d_f16x3" if p.precision else "conv2d", meta, self.lib.atmvfi_conv2d, ctypes.byref(p), self._stream())
 
@@ -428,6 +432,7 @@ class HipOps:
                        M=n * h * wd, out=None if out is None else out.data_ptr(), out_ld=old, out_gstride=0, out_rpg=0, out_row_map=None,
                        bias=_ptr(bias), prelu=_ptr(prelu), in_prelu=_ptr(in_prelu), residual=None, res_ld=0)
         p.precision, p.weight_hi, p.weight_lo = self._prec(w)
+        p.tile_wn = self.gemm_tile_wn
         self._gemm_sink(p, sink, n * oh * ow, cout, sink_c0, 0, 1, "deconv")
         use_planes = planes is not None and p.precision == 1
         if x is None and not use_planes:
@@ -488,6 +493,7 @@ class HipOps:
                        out=out.data_ptr(), out_ld=old, out_gstride=ogs, out_rpg=orpg, out_row_map=_ptr(out_row_map),
                        bias=_ptr(bias), prelu=None, in_prelu=None, residual=_ptr(residual), res_ld=res_ld)
         p.precision, p.weight_hi, p.weight_lo = self._prec(w)
+        p.tile_wn = self.gemm_tile_wn
         if planes is not None:
             p.in_hi, p.in_lo = planes.t[0].data_ptr(), planes.t[1].data_ptr()
         if sink is not None:

@@ -87,9 +87,20 @@ class Network(nn.Module):
         self.use_plane_convs = os.environ.get("ATMVFI_PLANE_CONV", "1") != "0"        # A/B switch: 3x3 convs on split-plane input
         self._prepared: Dict[str, object] = {}
         self._prepared_sig = None
-        self._bufs: Dict[Tuple, torch.Tensor] = {}
+        # Workspaces: one dict of named buffers per (device, input shape, mode) key, least recently used first.  The reference's
+        # evaluation loops (benchmark/test_snufilm.py, test_xiph.py) feed one model frames of many sizes and never call
+        # release_workspace(), so the cache evicts by itself: at most `max_workspaces` shapes and `workspace_cap_bytes` in total
+        # (checked when a forward starts; the workspace in use always stays).  ~13 GB per 1080p shape of the GPU's 288 GB.
+        self.max_workspaces = 2
+        self.workspace_cap_bytes = 96 << 30
+        self._workspaces: Dict[Tuple, Dict[Tuple, object]] = {}
+        self._ws_key: Optional[Tuple] = None
+        self._bufs: Dict[Tuple, object] = {}
         self._geo: Dict[Tuple, Tuple[WindowGeometry, torch.Tensor, Optional[torch.Tensor]]] = {}
         self.use_graphs = False
+        self._frame_cache_on = False
+        self._frame_cache = None          # (workspace key, tokens of the last call's second frame)
+        self._reuse_first = False
         self._graphs: Dict[Tuple, Tuple] = {}
         self._graph_sig = None
 
@@ -140,10 +151,7 @@ class Network(nn.Module):
         """Inject the op backend (tests inject a CPU double to check host logic; the
         default is the HIP library and nothing else)."""
         self._ops_obj = ops
-        self._prepared_sig = None
-        self._graphs.clear()
-        self._bufs.clear()
-        self._geo.clear()
+        self._drop_device_state()
 
     def set_precision(self, precision: str):
         """"f16x3" (default): contractions as fp16 hi/lo split, three 16-bit MFMAs per product, fp32 accumulate
@@ -155,7 +163,24 @@ class Network(nn.Module):
         if self._ops_obj is not None and hasattr(self._ops_obj, "precision"):
             self._ops_obj.precision = precision
 
+    def _drop_device_state(self):
+        """Everything that lives on one device or was derived there: packed weights, workspaces, window maps, captured graphs."""
+        self._prepared = {}
+        self._prepared_sig = None
+        self._graphs.clear()
+        self._workspaces.clear()
+        self._bufs = {}
+        self._ws_key = None
+        self._geo.clear()
+        self._frame_cache = None
+
     def _ops(self, device: torch.device):
+        cur = getattr(self._ops_obj, "device", None)
+        if isinstance(self._ops_obj, HipOps) and cur is not None and torch.device(cur) != torch.device(device):
+            # the model (or its inputs) moved to another GPU: buffers, packed weights and maps of the old device must not meet
+            # tensors of the new one in a launch
+            self._ops_obj = None
+            self._drop_device_state()
         if self._ops_obj is None:
             if device.type != "cuda":
                 raise RuntimeError("atm-vfi_amd.Network.forward runs on MI355X only: move the model and its inputs to "
@@ -183,7 +208,36 @@ class Network(nn.Module):
 
     def release_workspace(self):
         self._graphs.clear()          # captured graphs launch into the workspace
-        self._bufs.clear()
+        self._workspaces.clear()
+        self._bufs = {}
+        self._ws_key = None
+        self._frame_cache = None
+
+    @staticmethod
+    def _nbytes(ws: Dict) -> int:
+        n = 0
+        for t in ws.values():
+            t = t.t if isinstance(t, Planes) else t
+            n += t.numel() * t.element_size()
+        return n
+
+    def workspace_bytes(self) -> int:
+        return sum(self._nbytes(ws) for ws in self._workspaces.values())
+
+    def _select_workspace(self, key: Tuple):
+        """Make the workspace of ``key`` current (creating it empty) and evict the least recently used others beyond the limits."""
+        ws = self._workspaces.pop(key, None)
+        self._workspaces[key] = {} if ws is None else ws          # most recently used last
+        self._bufs = self._workspaces[key]
+        self._ws_key = key
+        while len(self._workspaces) > 1 and (len(self._workspaces) > self.max_workspaces or self.workspace_bytes() > self.workspace_cap_bytes):
+            old = next(iter(self._workspaces))
+            del self._workspaces[old]
+            for gk in [g for g in self._graphs if g[-1] == old]:      # graphs captured into that workspace
+                del self._graphs[gk]
+        if len(self._geo) > 64:                                        # window maps are small; bound them all the same
+            for gk in list(self._geo)[:len(self._geo) - 64]:
+                del self._geo[gk]
 
     def geometry(self, frames, h, w, ws, shift):
         key = (frames, h, w, ws, shift)
@@ -490,8 +544,18 @@ class Network(nn.Module):
         if not flag:
             self._graphs.clear()
 
-    def forward(self, im0: torch.Tensor, im1: torch.Tensor):
-        if not self.use_graphs or not im0.is_cuda:
+    def enable_frame_cache(self, flag: bool = True):
+        """Video mode (demo_2x.py:129-168: pair i+1's first frame is pair i's second): keep the second frame's encoder + fusion
+        tokens of every call, so that ``forward(im0, im1, reuse_first=True)`` runs ``shared_feat_extraction`` and the cross-scale
+        fusion (network_base.py:342-352, 451-455) on the new frame only.  Exact (the encoder is per frame); used only with
+        ``global_motion`` off, where nothing else reads the encoder maps; ~3 % of the FLOPs.  Not part of the
+        reference's API; off by default."""
+        self._frame_cache_on = bool(flag)
+        self._frame_cache = None
+
+    def forward(self, im0: torch.Tensor, im1: torch.Tensor, reuse_first: bool = False):
+        self._reuse_first = bool(reuse_first)
+        if not self.use_graphs or not im0.is_cuda or self._frame_cache_on:
             return self._forward_eager(im0, im1)
         ops = self._ops(im0.device)
         self._prepare(ops)
@@ -499,7 +563,8 @@ class Network(nn.Module):
             self._graphs.clear()
             self._graph_sig = self._prepared_sig
         key = (tuple(im0.shape), tuple(im1.shape), str(im0.device), self.global_motion, self.ensemble_global_motion,
-               self._precision, self.use_split_planes, self.local_motion_args["window_size"], self.global_motion_args["window_size"])
+               self._precision, self.use_split_planes, self.use_plane_convs, self.local_motion_args["window_size"],
+               self.global_motion_args["window_size"], self._workspace_key(im0))
         ent = self._graphs.get(key)
         if ent is None:
             for _ in range(2):                               # validation, workspace, window maps, packed weights, kernel attributes
@@ -518,10 +583,26 @@ class Network(nn.Module):
         graph.replay()
         return out
 
+    def _workspace_key(self, im0: torch.Tensor) -> Tuple:
+        return (str(im0.device), tuple(im0.shape), bool(self.global_motion), bool(self.ensemble_global_motion))
+
     def _forward_eager(self, im0: torch.Tensor, im1: torch.Tensor):
         if im0.shape != im1.shape or im0.dim() != 4 or im0.shape[1] != 3:
             raise ValueError(f"expected two [B,3,H,W] frames, got {tuple(im0.shape)} and {tuple(im1.shape)}")
+        if im0.device != im1.device:
+            raise ValueError(f"the two frames live on different devices ({im0.device}, {im1.device})")
         ops = self._ops(im0.device)
+        if im0.is_cuda:
+            for prm in self.parameters():
+                if prm.device != im0.device:
+                    raise RuntimeError(f"model parameters are on {prm.device}, inputs on {im0.device}: move the model with .to(device)")
+                break
+            with torch.cuda.device(im0.device):       # the kernels launch on the current device's stream
+                return self._forward_on_device(ops, im0, im1)
+        return self._forward_on_device(ops, im0, im1)
+
+    def _forward_on_device(self, ops, im0: torch.Tensor, im1: torch.Tensor):
+        self._select_workspace(self._workspace_key(im0))
         b, _, H, W = im0.shape
         need = 16 if self.global_motion else 8
         if H % need or W % need:
@@ -542,8 +623,24 @@ class Network(nn.Module):
                 pyr0.append(t0); pyr1.append(t1)
             # encoder + local fusion (:451-455)
             x0 = self.buf("x0", 2 * b, H, W, 4); ops.pack_frames(im0, im1, x0)
-            e1, e2, fuse_l = self._encoder(ops, P, x0, "")
-            feat = self._fusion(ops, P, "cross_scale_feature_fusion", e1, e2, fuse_l, d[2], d[1], "l")   # [2B*h*w, C]
+            cache_ok = self._frame_cache_on and not self.global_motion
+            ck = (self._ws_key, self._prepared_sig)         # same device, shape, mode and weights as the call that filled the cache
+            hit = cache_ok and self._reuse_first and self._frame_cache is not None and self._frame_cache[0] == ck
+            if hit:
+                # frame 0 of this pair was frame 1 of the previous call: encoder + fusion on the new frame only
+                e1, e2, fuse_l = self._encoder(ops, P, x0[b:], "fc")
+                one = self._fusion(ops, P, "cross_scale_feature_fusion", e1, e2, fuse_l, d[2], d[1], "fcl")   # [B*h*w, C]
+                feat = self.buf("lfnorm", 2 * b * h * w, C)
+                feat[:b * h * w].copy_(self._frame_cache[1])
+                feat[b * h * w:].copy_(one)
+            else:
+                e1, e2, fuse_l = self._encoder(ops, P, x0, "")
+                feat = self._fusion(ops, P, "cross_scale_feature_fusion", e1, e2, fuse_l, d[2], d[1], "l")   # [2B*h*w, C]
+            if cache_ok:
+                keep = self.buf("frame_cache_tokens", b * h * w, C)
+                keep.copy_(feat[b * h * w:])
+                self._frame_cache = (ck, keep)
+            self._reuse_first = False
             it_list: List[torch.Tensor] = []
             w0_list: List[torch.Tensor] = []
             w1_list: List[torch.Tensor] = []

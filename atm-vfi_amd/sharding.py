@@ -47,3 +47,111 @@ def interpolate_sharded(forward: Callable, im0: torch.Tensor, im1: torch.Tensor,
         outs.append(forward(im0[idx], im1[idx])["I_t"])
     local = torch.cat(outs, 0) if outs else im0.new_zeros((0,) + tuple(im0.shape[1:]))
     return gather_frames(local, n, rank, world)
+
+
+class PipelinedGather:
+    """The benchmark's and the video path's collective: all-gather of per-rank output frames, ONE STEP BEHIND the compute.
+
+    ``submit(local)`` copies this rank's frames of step k into a send buffer of its own (so the producer -- e.g. a captured HIP
+    graph's static output -- may be overwritten by step k+1 straight away), issues the all-gather asynchronously (RCCL runs it on
+    its own stream, under the forward of step k+1) and returns the gathered frames of step k-1, waiting for that older collective
+    first; ``drain()`` returns the last step's.  Two sets of buffers alternate, so a set is reused two steps after its gather
+    was waited for.  A rank without a frame in the last (ragged) step submits ``None``: it sends zeros, and ``valid`` counts say
+    how many ranks' frames are real.  ``encode`` (optional) maps the fp32 frames to the wire format before sending, e.g. rounding
+    to uint8 (4x fewer bytes over xGMI); it must return a tensor of ``wire_shape`` / ``wire_dtype``.
+    Frames come back as a list of ``world`` tensors in rank order (views of the receive buffers: consume or copy them before the
+    next-but-one submit)."""
+
+    def __init__(self, world: int, wire_shape, device, wire_dtype=torch.float32, encode: Callable = None, group=None):
+        self.world, self.encode, self.group = world, encode, group
+        self.send = [torch.zeros(wire_shape, dtype=wire_dtype, device=device) for _ in range(2)]
+        self.recv = [[torch.empty(wire_shape, dtype=wire_dtype, device=device) for _ in range(world)] for _ in range(2)]
+        self.pending = None            # (work, buffer set, valid count)
+        self.k = 0
+
+    def _finish(self):
+        if self.pending is None:
+            return None
+        work, s, valid = self.pending
+        self.pending = None
+        if work is not None:
+            work.wait()
+        return self.recv[s][:valid]
+
+    def submit(self, local, valid: int = None):
+        """local: this rank's frames of the step (wire_shape after ``encode``) or None; valid: ranks holding a real frame this
+        step (default: all).  Returns the previous step's gathered frames (list, rank order) or None on the first call."""
+        s = self.k & 1
+        self.k += 1
+        if local is None:
+            self.send[s].zero_()
+        else:
+            self.send[s].copy_(self.encode(local) if self.encode is not None else local)
+        prev = self._finish()                       # the older collective first: its receive buffers are about to be handed out
+        if self.world == 1:
+            self.recv[s][0].copy_(self.send[s])
+            work = None
+        else:
+            work = dist.all_gather(self.recv[s], self.send[s], group=self.group, async_op=True)
+        self.pending = (work, s, self.world if valid is None else valid)
+        return prev
+
+    def drain(self):
+        return self._finish()
+
+
+def shard_blocks(n_items: int, world: int, block: int):
+    """Rounds of ``world * block`` consecutive items; in a round rank r owns the ``block`` consecutive items
+    ``[round_start + r * block, +block)`` (clipped to ``n_items``).  Consecutive items on one rank let the video path reuse the
+    shared frame of consecutive pairs.  Yields (round_start, [per-rank (start, stop)])."""
+    step = world * block
+    for start in range(0, n_items, step):
+        spans = []
+        for r in range(world):
+            a = min(n_items, start + r * block)
+            b = min(n_items, a + block)
+            spans.append((a, b))
+        yield start, spans
+
+
+def interpolate_video_2x_sharded(frames: Sequence, interpolate_pair: Callable, rank: int, world: int, wire_shape, wire_dtype=torch.uint8,
+                                 block: int = 1, decode: Callable = None, device="cpu", group=None):
+    """demo_2x.py:129-168's frame loop over the GPUs of a node: pair i = (frames[i], frames[i+1]); rounds of ``world * block`` pairs,
+    rank r interpolating ``block`` consecutive pairs of each round; the predictions of a round are all-gathered (one step behind the
+    next round's compute, PipelinedGather) so that EVERY rank yields the full 2n-1 sequence f0, I(f0,f1), f1, ..., f_{n-1} in order.
+
+    ``frames``: a sequence every rank can index (decoding stays with the caller).  ``interpolate_pair(f_a, f_b, reuse_first)`` returns
+    this rank's prediction as a tensor of ``wire_shape`` / ``wire_dtype`` on ``device`` (e.g. the uint8 [H,W,3] frame of
+    ``FramePipeline``: 4x fewer bytes over xGMI than fp32); ``reuse_first`` is True when f_a was the previous call's f_b on this
+    rank, so an implementation may reuse that frame's encoder features (``Network.enable_frame_cache``).  ``decode`` converts a
+    gathered wire tensor to what is yielded (default: the tensor itself)."""
+    n = len(frames)
+    if n == 0:
+        return
+    gather = PipelinedGather(world, (block,) + tuple(wire_shape), device, wire_dtype, group=group)
+
+    def emit(start, spans, got):
+        i = start
+        for r, (a, b) in enumerate(spans):
+            for j in range(b - a):
+                yield frames[i]
+                yield decode(got[r][j]) if decode is not None else got[r][j].clone()
+                i += 1
+
+    prev_meta = None
+    last_b = None
+    for start, spans in shard_blocks(n - 1, world, block):
+        a, b = spans[rank]
+        local = None
+        if b > a:
+            local = torch.zeros((block,) + tuple(wire_shape), dtype=wire_dtype, device=device)
+            for i in range(a, b):
+                local[i - a].copy_(interpolate_pair(frames[i], frames[i + 1], last_b == i))
+                last_b = i + 1
+        got = gather.submit(local)
+        if prev_meta is not None:
+            yield from emit(prev_meta[0], prev_meta[1], got)
+        prev_meta = (start, spans)
+    if prev_meta is not None:
+        yield from emit(prev_meta[0], prev_meta[1], gather.drain())
+    yield frames[n - 1]          # the last frame is written once (demo_2x.py:160)

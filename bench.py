@@ -10,12 +10,13 @@ and the N output frames are all-gathered over RCCL/xGMI -- the only collective o
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
 Rank 0 prints ONE JSON line.  Besides the contract's fields it carries
-  roofline     : the kernel family with the largest share of the forward (today conv3x3_f16x3_kernel),
+  roofline     : the kernel family with the largest share of the forward (today conv3x3_planes_kernel),
                  achieved = sum of algorithmic FLOPs / sum of launch durations, measured live with HIP
                  events on the launch stream in a separate instrumented pass after the timed region;
-                 `traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/);
+                 `traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), reported only
+                 while the kernel sources hash to the build those passes were taken on;
   cpu_baseline : the CPU oracle (oracle/atmvfi_oracle.py, a port of the reference's algorithm) timed on this
-                 node's host cores on a bounded sample (rank 0, N=1 only);
+                 node's host cores (cgroup quota) on a bounded sample, 1 warm-up + median of 3 (rank 0, N=1 only);
   kernels      : per-kernel-family time split of one forward (ms), for DESIGN.md / profiles/.
 """
 from __future__ import annotations
@@ -46,6 +47,46 @@ PEAK_F16_MFMA_TFLOPS = 2500.0  # dense fp16/bf16 matrix peak (no sparsity)
 PEAK_HBM_GBS = 8000.0
 
 
+def csrc_digest() -> str:
+    """sha256 over the kernel sources: stamps the committed PMC traffic figures with the build they were measured on."""
+    import hashlib
+    hsh = hashlib.sha256()
+    d = os.path.join(ROOT, "atm-vfi_amd", "csrc")
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".hip", ".h")):
+            hsh.update(fn.encode())
+            hsh.update(open(os.path.join(d, fn), "rb").read())
+    return hsh.hexdigest()
+
+
+def host_cores():
+    """(threads to use, description): the cgroup CPU quota if there is one, else the affinity mask; plus the CPU model string."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(float(q) / float(per) + 0.5))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = max(1, int(q / per + 0.5))
+        except Exception:
+            pass
+    model = "unknown CPU"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    use = min(n, quota) if quota else n
+    return use, f"{model}; {n} logical CPUs visible, cgroup quota {quota if quota else 'none'}"
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -59,6 +100,7 @@ def parse():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f32"])
     ap.add_argument("--no-host-io", action="store_true", help="skip the PCIe-inclusive measurement (uint8 frames in host memory in and out)")
+    ap.add_argument("--gather-u8", action="store_true", help="N > 1: all-gather the output frames rounded to uint8 (4x fewer bytes over xGMI)")
     ap.add_argument("--graph", action="store_true", help="replay the forward from a captured HIP graph (Network.enable_graphs); measured "
                     "within 0.5 %% of eager launches at 1080p and at 256x448: the stream is already back to back")
     return ap.parse_args()
@@ -107,23 +149,33 @@ def main():
         frames.append((a.contiguous(), b.contiguous()))
     H, W = frames[0][0].shape[-2:]
 
-    # Two sets of gather buffers: the all-gather of step k (RCCL, its own stream) runs under the forward of step k+1 and is waited
-    # for one step later, so a rank that is momentarily slower delays the others' *gather*, not their next forward.  Every step's
-    # collective is issued and completed inside the timed region (the last one is waited for before the closing synchronize).
-    gathered = [[torch.empty(1, 3, H, W, device=dev) for _ in range(world)] for _ in range(2)] if world > 1 else None
-    pending = []
+    # The collective is sharding.PipelinedGather -- the class the gloo world-size-2 tests exercise (tests/test_sharding_gloo.py):
+    # the all-gather of step k (RCCL, its own stream) is issued from a send buffer of its own, runs under the forward of step k+1
+    # and is waited for one step later, so a rank that is momentarily slower delays the others' *gather*, not their next forward,
+    # and a captured graph may overwrite its static output at once.  Every step's collective is issued and completed inside the
+    # timed region (the last one is waited for before the closing synchronize).  --gather-u8 sends the frame rounded to uint8.
+    sharding = importlib.import_module("atm-vfi_amd.sharding")
+    gather = None
+    if world > 1:
+        if args.gather_u8:
+            u8 = torch.empty(H, W, 3, dtype=torch.uint8, device=dev)
+
+            def enc(x):                      # fp32 [1,3,H,W] -> uint8 [H,W,3] (np.round(x * 255)), one HIP kernel
+                net._ops_obj.frame_f32_to_u8(x[0], u8, 0, 0, False)
+                return u8
+            gather = sharding.PipelinedGather(world, (H, W, 3), dev, torch.uint8, encode=enc)
+        else:
+            gather = sharding.PipelinedGather(world, (1, 3, H, W), dev, torch.float32)
 
     def drain():
-        while pending:
-            work, _keep = pending.pop(0)
-            work.wait()
+        if gather is not None:
+            gather.drain()
 
     def step(i):
         a, b = frames[i % n_in]
         out = net(a, b)["I_t"]
-        if world > 1:
-            drain()                             # the previous step's gather
-            pending.append((dist.all_gather(gathered[i % 2], out, async_op=True), out))      # per-rank output frames only
+        if gather is not None:
+            gather.submit(out)                  # per-rank output frames only; returns step i-1's frames
         return out
 
     net.set_precision(args.precision)
@@ -163,7 +215,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"network_{variant} {args.height}x{args.width} (padded {H}x{W}) bs=1 per GPU, "
                                    f"global {'on' if net.global_motion else 'off'}, fp32, random frame pairs, stress weights seed 1",
-                       "pairs_per_step": world, "parallelism": f"frame-batch dp{world} + all-gather of the output frames, one step behind the forward" if world > 1 else "single GPU"},
+                       "pairs_per_step": world, "parallelism": f"frame-batch dp{world} + all-gather of the {'uint8' if args.gather_u8 else 'fp32'} output frames, one step behind the forward (sharding.PipelinedGather)" if world > 1 else "single GPU"},
         }
         result["launch"] = "eager (one hipLaunchKernel per op)" if not args.graph else "HIP graph replay (captured forward, inputs copied into its static buffers inside the timed region)"
         if flops:
@@ -209,17 +261,22 @@ def main():
                                 "frac": round(ach / peak, 4), "traffic": None, "kernel": fam, "launches": nl,
                                 "avg_launch_ms": round(ms / nl, 4), "algorithmic_gflop_per_forward": round(fl / 1e9, 1),
                                 "share_of_forward_time": round(ms / total_ms, 4)}
-            # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled
-            # per the gfx950 correction); only meaningful for the workload they were taken on (base 1088x1920)
+            # HBM traffic per launch: PMC counters cannot be read from inside this process (rocprofv3 wraps the run), so the value
+            # comes from the committed passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH doubled per the
+            # gfx950 correction; tools/pmc_hbm.sh) -- and only while the kernel sources are the ones those passes were taken on
+            # (sha256 over atm-vfi_amd/csrc, stamped into the file); otherwise `traffic` stays null rather than going stale.
             try:
                 if key == ("base", 1088, 1920, True):
-                    pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))["per_forward"]
-                    for fam, kn in (("conv3x3_f16x3_row_kernel", "conv3x3_f16x3_row_kernel"),
-                                    ("gemm_f16x3_kernel (linear + deconv2x2 + strided conv2d)", "gemm_f16x3_kernel"),
-                                    ("gemm_split_kernel (nn.Linear rows from split planes, LDS-DMA)", "gemm_split_kernel")):
-                        if fam in fam_out and kn in pmc:
-                            fam_out[fam]["traffic"] = round(pmc[kn]["traffic_GB_per_launch"] * 1e9)
-                            fam_out[fam]["traffic_unit"] = "bytes/launch (PMC, profiles/r01_pmc_hbm_traffic.json)"
+                    pmc_file = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")
+                    pmc_all = json.load(open(pmc_file))
+                    fresh = pmc_all.get("csrc_sha256") == csrc_digest()
+                    pmc = pmc_all["per_forward"]
+                    for fam in fam_out:
+                        kn = fam.split(" ")[0]
+                        if kn in pmc:
+                            fam_out[fam]["traffic"] = round(pmc[kn]["traffic_GB_per_launch"] * 1e9) if fresh else None
+                            fam_out[fam]["traffic_unit"] = ("bytes/launch (PMC, profiles/r02_pmc_hbm_traffic.json, same kernel sources)" if fresh else
+                                                            "null: the committed PMC passes were taken on other kernel sources")
             except Exception:
                 pass
             if fam_out:
@@ -252,14 +309,27 @@ def main():
                                  **hio, "bytes_over_pcie_per_frame": 3 * args.height * args.width * 3}
         # ---- CPU baseline: the oracle on this node's host cores, bounded sample ----
         if world == 1 and not args.no_cpu_baseline:
+            # threads = the cores this process may really use (cgroup quota), CPU model stated, one warm-up,
+            # median of three.  Bounded sample: the same network on a frame pair with a quarter of the pixels (every layer's cost is
+            # proportional to the pixel count), scaled to the timed workload by the pixel ratio.
             from oracle import atmvfi_oracle as O
+            ncore, cpu_desc = host_cores()
+            torch.set_num_threads(ncore)
+            sh, sw = (H // 2 + 15) // 16 * 16, (W // 2 + 15) // 16 * 16
             a, b = frames[0]
-            a, b = a.cpu(), b.cpu()
-            tc = time.perf_counter()
-            O.forward(sd, a, b, global_motion=net.global_motion)
-            tc = time.perf_counter() - tc
-            result["cpu_baseline"] = {"value": round(1.0 / tc, 5), "unit": "frames/s", "cores": torch.get_num_threads(),
-                                      "kind": "port", "sample": f"1 frame pair of the same workload ({H}x{W}), single run, no warm-up, {tc:.1f} s"}
+            a, b = a[..., :sh, :sw].cpu().contiguous(), b[..., :sh, :sw].cpu().contiguous()
+            runs = []
+            for rep in range(4):
+                tc = time.perf_counter()
+                O.forward(sd, a, b, global_motion=net.global_motion)
+                runs.append(time.perf_counter() - tc)
+            med = float(np.median(runs[1:]))
+            scale = (H * W) / float(sh * sw)
+            result["cpu_baseline"] = {"value": round(1.0 / (med * scale), 5), "unit": "frames/s", "cores": ncore, "kind": "port",
+                                      "cpu": cpu_desc,
+                                      "sample": f"oracle forward on a {sh}x{sw} crop of the same frame pair (1/{scale:.2f} of the {H}x{W} "
+                                                f"pixels; per-layer cost is proportional to pixels), {ncore} threads, 1 warm-up + median of 3: "
+                                                f"{med:.2f} s per crop (runs {', '.join(f'{t:.2f}' for t in runs)}), scaled by the pixel ratio"}
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()

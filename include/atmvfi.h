@@ -9,7 +9,9 @@
  *
  * Conventions
  *  - every pointer is a DEVICE pointer to fp32 unless stated; the library allocates
- *    nothing, owns nothing and keeps no mutable global state (re-entrant per stream);
+ *    nothing, owns nothing and keeps no mutable global state (re-entrant per stream; the only caches are per-device
+ *    constants: CU count and "dynamic LDS limit already raised for this kernel"); it reads no environment variable -- the
+ *    diagnostic builds (`make stamp`, `make ablate`) do, and are never loaded by the product;
  *  - `stream` is a hipStream_t passed as void* (0 = default stream);
  *  - feature maps are NHWC "views": (ptr, ld) with ptr already advanced to the first
  *    channel of the view and `ld` = floats between consecutive pixels.  Views let a
@@ -100,6 +102,8 @@ typedef struct atmvfi_gemm_params {
     void* out_lo;
     int64_t out_plane_rows;
     int32_t out_plane_c0, out_plane_gc;
+    /* F16X3, fp32 input: n-tiles of 16 columns per 256-row workgroup tile, 0 = cost model (default), 1..8 = forced (sweeps). */
+    int32_t tile_wn;
 } atmvfi_gemm_params;
 
 #define ATMVFI_PREC_F32   0
@@ -158,7 +162,11 @@ int atmvfi_pack_weight_conv3x3(const float* src, void* dst_hi, void* dst_lo, int
  * caller's buffer; those inside the last group of 4 are written as zero. */
 int atmvfi_conv3x3_f16x3(const float* in, int in_ld, int N, int H, int W, int Cin, const void* w_hi, const void* w_lo,
                          int Cout, float* out, int out_ld, const float* bias, const float* prelu, void* out_hi, void* out_lo,
-                         int64_t plane_rows, const float* plane_prelu, void* stream);
+                         int64_t plane_rows, const float* plane_prelu, int schedule, int wn, void* stream);
+/* schedule / wn: the kernel has two schedules (512-thread 16x16 tiles, one workgroup per CU; 256-thread 16x8 tiles, two per CU) and
+ * 1..8 n-tiles of 16 output channels per workgroup, picked per layer from a cost model.  Per call: schedule -1 = cost model,
+ * 0 = row, 1 = half; wn 0 = cost model, 1..8 = n-tiles per workgroup (parity tests reach every instance this way; results do not
+ * depend on either).  The library keeps no process-wide override. */
 /* The same convolution on SPLIT-PLANE input (csrc/conv3x3_planes.hip): the activations are the two fp16 planes (hi, lo', chunk major
  * [ceil(Cin/32)][in_rows][32], row = pixel n*H*W + y*W + x) that the producing layer's sink wrote, so the input halo goes
  * global -> LDS by LDS-DMA with no register staging and no conversion, and the two waves of each SIMD run one phase apart (one
@@ -172,16 +180,6 @@ int atmvfi_conv3x3_f16x3(const float* in, int in_ld, int N, int H, int W, int Ci
 int atmvfi_conv3x3_planes(const void* in_hi, const void* in_lo, int64_t in_rows, int N, int H, int W, int Cin, const void* w_hi,
                           const void* w_lo, int Cout, float* out, int out_ld, const float* bias, const float* prelu, void* out_hi,
                           void* out_lo, int64_t plane_rows, int out_c0, const float* plane_prelu, int out_cmin, int wn, void* stream);
-/* The 3x3 kernel has two schedules (512-thread 16x16 tiles, one workgroup per CU; 256-thread 16x8 tiles, two per CU) and 1..8
- * n-tiles of 16 output channels per workgroup, picked per layer from a cost model.  This process-wide override exists for the
- * parity tests, which must reach every instance of the kernel, and for same-box A/B timing: schedule -1 = cost model (default),
- * 0 = row, 1 = half; wn 0 = cost model, 1..8 = n-tiles per workgroup.  Takes effect for launches made after it
- * returns; results do not depend on either choice. */
-int atmvfi_conv3x3_set_schedule(int schedule, int wn);
-/* Same kind of override for the f16x3 GEMM engine behind atmvfi_conv2d / atmvfi_linear / atmvfi_deconv2x2 (fp32 inputs): 0 = cost
- * model (default), 1..8 = n-tiles of 16 columns per 256-row workgroup tile. */
-int atmvfi_gemm_f16x3_set_tile_width(int wn);
-
 /* ------------------------------------------------------------------------------------
  * LayerNorm over the channel axis of token rows (eps 1e-5, affine), optional gather.
  * Replaces nn.LayerNorm at attention.py:316 (norm1 on windowed tokens), :333 (norm2) and

@@ -315,3 +315,70 @@ def test_video_2x_frame_order(nets, dev):
     one = list(host_io.interpolate_video_2x(iter(frames[:1]), net))
     assert len(one) == 1 and np.array_equal(one[0], frames[0])
     net.global_motion = True
+
+
+def test_frame_cache_is_exact_and_video_distributed_single_rank(nets, dev):
+    """Network.enable_frame_cache(): with the global branch off, forward(b, c, reuse_first=True) after forward(a, b) must equal
+    forward(b, c) bit for bit (the encoder and the cross-scale fusion are per frame, network_base.py:342-352); and the
+    multi-GPU video loop (host_io.interpolate_video_2x_distributed, here with one rank) must yield exactly the single-GPU sequence,
+    with and without the global branch."""
+    net = nets["lite"]
+    net.ensemble_global_motion = False
+    net.global_motion = False
+    a, _ = pairs.smooth_pair(1, 128, 192, seed=91)
+    b, c = pairs.smooth_pair(1, 128, 192, seed=92)
+    a, b, c = a.to(dev), b.to(dev), c.to(dev)
+    plain = {k: v.clone() for k, v in net(b, c).items() if torch.is_tensor(v)}
+    net.enable_frame_cache(True)
+    try:
+        net(a, b)
+        cached = net(b, c, reuse_first=True)
+        for k, v in plain.items():
+            assert torch.equal(cached[k], v), k
+        # a cache filled at another shape (or a call without reuse_first) must not be used
+        x, y = pairs.smooth_pair(1, 64, 96, seed=93)
+        net(x.to(dev), y.to(dev))
+        again = net(b, c, reuse_first=True)                 # cache belongs to the 64x96 workspace: recomputed, still right
+        assert torch.equal(again["I_t"], plain["I_t"])
+    finally:
+        net.enable_frame_cache(False)
+    rng = np.random.default_rng(11)
+    frames = [rng.integers(0, 256, (64, 96, 3), dtype=np.uint8) for _ in range(6)]
+    for g in (False, True):
+        net.global_motion = g
+        want = list(host_io.interpolate_video_2x(iter(frames), net))
+        got = list(host_io.interpolate_video_2x_distributed(frames, net, 0, 1, block=2))
+        assert len(got) == len(want) == 11 and all(np.array_equal(p, q) for p, q in zip(got, want)), g
+    net.global_motion = True
+
+
+def test_flip_tta_on_the_hip_path(nets, dev, weights):
+    """host_io.forward_tta (benchmark/test_snufilm.py:135-139: average of the prediction and of the un-flipped prediction on the
+    H- and W-flipped frames) run on the HIP path against the CPU oracle doing the same."""
+    net = nets["lite"]
+    net.global_motion = True
+    net.ensemble_global_motion = False
+    im0, im1 = pairs.smooth_pair(1, 128, 192, seed=95)
+    got = host_io.forward_tta(net, im0.to(dev), im1.to(dev)).cpu()
+    sd = weights("lite")
+    ref = O.forward(sd, im0, im1, global_motion=True)["I_t"]
+    ref_f = O.forward(sd, im0.flip(2).flip(3).contiguous(), im1.flip(2).flip(3).contiguous(), global_motion=True)["I_t"]
+    want = (ref + ref_f.flip(2).flip(3)) / 2
+    assert (got - want).abs().max().item() <= TOL
+    assert (got - ref).abs().max().item() > 0            # the augmentation really changes the result (asymmetric network)
+
+
+def test_model_moved_to_other_device_drops_device_state(dev, weights):
+    """The workspace, packed weights and window maps are per device: a forward with inputs on a device other than the model's
+    parameters must raise (not launch mixed pointers), and release / re-use on the same device must keep working."""
+    net = pkg.NetworkLite()
+    net.load_state_dict(weights("lite"), strict=True)
+    net.to(dev).eval()
+    a, b = pairs.smooth_pair(1, 64, 64, seed=97)
+    o1 = net(a.to(dev), b.to(dev))["I_t"].clone()
+    assert net.workspace_bytes() > 0 and len(net._workspaces) == 1
+    net.cpu()
+    with pytest.raises(RuntimeError):
+        net(a.to(dev), b.to(dev))                          # parameters on the CPU, inputs on the GPU
+    net.to(dev)
+    assert torch.equal(net(a.to(dev), b.to(dev))["I_t"], o1)

@@ -633,7 +633,7 @@ def test_conv3x3_every_kernel_instance(schedule, hip, cpu, dev):
     r4 = lambda c: (c + 3) // 4 * 4
     try:
         for wn in range(1, 9):
-            assert hip.lib.atmvfi_conv3x3_set_schedule(schedule, wn) == 0
+            hip.conv3_instance = (schedule, wn)
             for cin in (37, 64):
                 cout = 2 * 16 * wn - (5 if wn % 2 else 0)            # two column blocks, the second one partial for odd wn
                 N, H, W = 2, 21, 35
@@ -651,7 +651,7 @@ def test_conv3x3_every_kernel_instance(schedule, hip, cpu, dev):
                 assert maxdiff(og[..., :cout], oc) <= 1e-4, (schedule, wn, cin)
                 assert (og[..., cout:] == 7.0).all()
     finally:
-        hip.lib.atmvfi_conv3x3_set_schedule(-1, 0)
+        hip.conv3_instance = None
 
 
 @pytest.mark.gpu
@@ -667,7 +667,7 @@ def test_conv3x3_plane_sink(schedule, hip, dev):
     bias = rnd(g, cout, scale=0.3).to(dev)
     inp = (0.25 + rnd(g, cout, scale=0.1)).to(dev)
     pw = hip.pack_weight(GEMM_CONV, wt)
-    assert hip.lib.atmvfi_conv3x3_set_schedule(schedule, 0) == 0
+    hip.conv3_instance = (schedule, 0)
     try:
         for slopes in (inp, None):
             y0 = torch.full((n, h, w, 104), 3.0, device=dev)
@@ -692,7 +692,7 @@ def test_conv3x3_plane_sink(schedule, hip, dev):
                 torch.cuda.synchronize()
                 assert torch.equal(z0, z1)
     finally:
-        hip.lib.atmvfi_conv3x3_set_schedule(-1, 0)
+        hip.conv3_instance = None
 
 
 @pytest.mark.gpu

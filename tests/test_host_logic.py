@@ -224,3 +224,86 @@ def test_isa_of_counted_lds_waits():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_isa.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_product_library_reads_no_environment():
+    """the C ABI keeps no global mutable state and takes every knob per call.  The product build must not even import
+    getenv (the diagnostic `make stamp` / `make ablate` builds do), nor export a process-wide override."""
+    import subprocess
+    if not os.path.exists(hip_ops.LIB_PATH):
+        import __graft_entry__ as ge
+        ge.build()
+    und = subprocess.run(["nm", "-D", "--undefined-only", hip_ops.LIB_PATH], capture_output=True, text=True).stdout
+    assert not re.search(r"\b(secure_)?getenv\b", und), "libatmvfi_hip.so imports getenv"
+    defd = subprocess.run(["nm", "-D", "--defined-only", hip_ops.LIB_PATH], capture_output=True, text=True).stdout
+    assert not re.search(r"atmvfi_\w*set_(schedule|tile_width)", defd)
+
+
+def test_reference_callers_import_lines_resolve():
+    """The reference's own import lines, verbatim, in fresh interpreters: demo_2x.py:7-12 (cwd = repo root), README.md:31, and
+    benchmark/test_*.py:12-16 (cwd = benchmark/, `sys.path.append('../')`).  They must resolve to this package's Network."""
+    import subprocess
+    import sys
+    demo = ("import sys\n"
+            "from benchmark.utils import InputPadder\n"
+            "sys.path.append('./network/')\n"
+            "from network_base import Network\n"
+            "from network_lite import Network as NetworkLite\n"
+            "from network.network_base import Network as ReadmeNetwork\n"
+            "import torch\n"
+            "m = Network(); assert isinstance(m, torch.nn.Module) and type(m).__module__.startswith('atm-vfi_amd'), type(m).__module__\n"
+            "assert ReadmeNetwork is Network and NetworkLite is not Network\n"
+            "assert InputPadder((1, 3, 270, 480), divisor=64)._pad == [16, 16, 25, 25]\n"
+            "print(sum(p.numel() for p in m.parameters()))\n")
+    r = subprocess.run([sys.executable, "-c", demo], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert int(r.stdout.split()[-1]) > 50_000_000           # network_base: 51.6 M parameters (README)
+    bench = ("import sys\n"
+             "sys.path.append('../')\n"
+             "from network_base import Network\n"
+             "from utils import InputPadder\n"
+             "print(Network.__module__)\n")
+    r = subprocess.run([sys.executable, "-c", bench], cwd=os.path.join(ROOT, "benchmark"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "atm-vfi_amd" in r.stdout, r.stdout + r.stderr[-2000:]
+
+
+def test_golden_generator_imports_the_reference_not_the_shims():
+    """oracle/gen_golden.py must import the reference's `network` / `benchmark` namespace packages although the repo ships regular
+    packages of the same names (the round-1 recipe broke exactly there).  Needs /root/reference: skipped on the GPU box."""
+    import subprocess
+    import sys
+    if not os.path.isdir("/root/reference/network"):
+        pytest.skip("reference not present")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "gen_golden.py"), "--imports-only"], cwd=ROOT, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "/root/reference/network/attention.py" in r.stdout, r.stdout + r.stderr[-2000:]
+
+
+def test_workspace_cache_evicts_by_itself(nets):
+    """Unchanged evaluation loops (benchmark/test_snufilm.py, test_xiph.py) feed one model many frame sizes and never release
+    anything: the per-shape workspaces must stay bounded (LRU over shapes + a byte cap), and results must not depend on eviction."""
+    import pairs
+    net = nets["lite"]
+    net.global_motion = True
+    net.ensemble_global_motion = False
+    net.release_workspace()
+    shapes = [(64, 64), (64, 96), (96, 64), (64, 64)]
+    first = None
+    for i, (h, w) in enumerate(shapes):
+        a, b = pairs.smooth_pair(1, h, w, seed=5)
+        out = net(a, b)["I_t"].clone()
+        assert len(net._workspaces) <= net.max_workspaces
+        if i == 0:
+            first = out
+    assert torch.equal(out, first)                     # (64, 64) again after its workspace had been evicted
+    keys = list(net._workspaces)
+    assert keys[-1][1] == (1, 3, 64, 64) and keys[0][1] == (1, 3, 96, 64)
+    cap, net.workspace_cap_bytes = net.workspace_cap_bytes, 1
+    try:
+        a, b = pairs.smooth_pair(1, 64, 96, seed=5)
+        net(a, b)
+        assert len(net._workspaces) == 1               # over the byte cap: only the workspace in use survives
+    finally:
+        net.workspace_cap_bytes = cap
+        net.release_workspace()
+    assert net.workspace_bytes() == 0

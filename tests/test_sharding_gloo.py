@@ -43,6 +43,97 @@ def _worker(rank, world, port, n_pairs, q):
     q.put((rank, bool(ok)))
 
 
+def _pipelined_worker(rank, world, port, n_steps, q):
+    """The function bench.py --gpus N and the sharded video loop run: PipelinedGather, one step behind, with a ragged last step
+    and the uint8 wire format."""
+    sys.path.insert(0, ROOT)
+    sharding = importlib.import_module("atm-vfi_amd.sharding")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ok = True
+    for as_u8 in (False, True):
+        enc = (lambda x: (x * 255).round().clamp(0, 255).to(torch.uint8)) if as_u8 else None
+        pg = sharding.PipelinedGather(world, (1, 3, 6, 10), "cpu", torch.uint8 if as_u8 else torch.float32, encode=enc)
+        frame = lambda step, r: torch.full((1, 3, 6, 10), (7 * step + 3 * r + 1) / 64.0)
+        static_out = torch.empty(1, 3, 6, 10)          # stands in for a captured graph's static output buffer
+        got_steps = []
+        for step in range(n_steps):
+            last_ragged = step == n_steps - 1
+            mine = None
+            valid = world
+            if last_ragged:
+                valid = 1                                # only rank 0 has a frame in the last step
+                if rank == 0:
+                    static_out.copy_(frame(step, rank)); mine = static_out
+            else:
+                static_out.copy_(frame(step, rank)); mine = static_out
+            prev = pg.submit(mine, valid)
+            static_out.fill_(-1.0)                       # the producer overwrites its output right away: the gather must not see it
+            ok = ok and ((prev is None) == (step == 0))
+            if prev is not None:
+                got_steps.append([t.clone() for t in prev])
+        got_steps.append([t.clone() for t in pg.drain()])
+        ok = ok and pg.drain() is None and len(got_steps) == n_steps
+        for step, got in enumerate(got_steps):
+            nvalid = 1 if step == n_steps - 1 else world
+            ok = ok and len(got) == nvalid
+            for r, t in enumerate(got):
+                want = frame(step, r)
+                want = enc(want) if as_u8 else want
+                ok = ok and torch.equal(t, want)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, bool(ok)))
+
+
+def _video_worker(rank, world, port, n_frames, block, q):
+    sys.path.insert(0, ROOT)
+    sharding = importlib.import_module("atm-vfi_amd.sharding")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    frames = [torch.full((4, 5, 3), 10 * i, dtype=torch.uint8) for i in range(n_frames)]
+    calls = []
+
+    def pair(fa, fb, reuse_first):
+        calls.append((int(fa[0, 0, 0]) // 10, bool(reuse_first)))
+        return ((fa.to(torch.int32) + fb.to(torch.int32)) // 2).to(torch.uint8)     # "interpolated" frame 10 i + 5
+    out = list(sharding.interpolate_video_2x_sharded(frames, pair, rank, world, (4, 5, 3), torch.uint8, block=block))
+    vals = [int(t[0, 0, 0]) for t in out]
+    ok = vals == [5 * k for k in range(2 * n_frames - 1)]                            # f0, I01, f1, ..., f_{n-1}: every rank, in order
+    # this rank computed exactly its blocks, and reuse is announced exactly for consecutive pairs inside a block
+    mine = [i for _, spans in sharding.shard_blocks(n_frames - 1, world, block) for i in range(*spans[rank])]
+    ok = ok and [c[0] for c in calls] == mine
+    ok = ok and all(reuse == (k > 0 and mine[k - 1] == mine[k] - 1) for k, (_, reuse) in enumerate(calls))
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, bool(ok)))
+
+
+def _run_world2(target, *args):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, 2, port) + args + (q,)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+@pytest.mark.parametrize("n_steps", [1, 2, 5])
+def test_pipelined_gather_world2(n_steps):
+    _run_world2(_pipelined_worker, n_steps)
+
+
+@pytest.mark.parametrize("n_frames,block", [(2, 1), (6, 1), (8, 2), (7, 3), (1, 1)])
+def test_sharded_video_frame_order_world2(n_frames, block):
+    _run_world2(_video_worker, n_frames, block)
+
+
 @pytest.mark.parametrize("n_pairs", [8, 5, 1])
 def test_sharded_interpolation_world2(n_pairs):
     ctx = mp.get_context("spawn")

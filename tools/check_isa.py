@@ -44,13 +44,56 @@ def check(asm_text):
     return problems
 
 
+def check_planes(asm_text):
+    """conv3x3_planes_kernel<WN>: the k-loop alternates read phases and MFMA phases between raw s_barriers.  Its vmcnt waits are
+    immediates computed for a loop in which every wave issues the same DMA instructions in every phase, so the loop must contain
+    no branch; a read phase must end in a counted vmcnt wait and lgkmcnt(0); an MFMA phase must hold exactly 6*WN MFMAs and
+    nothing that touches memory."""
+    problems = []
+    lines = asm_text.splitlines()
+    found = 0
+    for wn in range(1, 9):
+        starts = [i for i, l in enumerate(lines) if re.match(rf"^_ZN\S*conv3x3_planes_kernelILi{wn}E\S*:", l)]
+        if not starts:
+            problems.append(f"planes<{wn}>: kernel not found")
+            continue
+        found += 1
+        end = next(i for i in range(starts[0], len(lines)) if "s_endpgm" in lines[i])
+        body = [l.split(";")[0] for l in lines[starts[0]:end]]
+        bars = [i for i, l in enumerate(body) if re.search(r"\bs_barrier\b", l)]
+        if len(bars) != 27:          # 2 (prologue) + 2 * 9 (chunk loop body) + 2 * 3 (tail steps) + 1
+            problems.append(f"planes<{wn}>: expected 27 s_barrier, found {len(bars)}")
+            continue
+        loop = bars[2:-1]            # barriers of the twelve k-step bodies
+        for k in range(0, len(loop) - 1):
+            seg = body[loop[k] + 1:loop[k + 1]]
+            n_mfma = sum("v_mfma" in l for l in seg)
+            mem = [l for l in seg if re.search(r"\b(ds_|global_|buffer_|flat_|scratch_)", l)]
+            if any(re.search(r"\bs_cbranch|\bs_branch", l) for l in seg) and k not in (17,):     # (the chunk loop's back edge sits after k-step 8's last barrier)
+                problems.append(f"planes<{wn}>: branch inside phase {k}")
+            if n_mfma:
+                if n_mfma != 6 * wn or mem:
+                    problems.append(f"planes<{wn}>: MFMA phase {k} has {n_mfma} MFMAs and {len(mem)} memory instructions")
+            else:
+                waits = [l.strip() for l in seg if "s_waitcnt" in l]
+                if not any(re.search(r"vmcnt\([1-9]\d*\)", w) for w in waits) or not any("lgkmcnt(0)" in w for w in waits):
+                    problems.append(f"planes<{wn}>: read phase {k} lacks a counted vmcnt wait or lgkmcnt(0): {waits}")
+                if sum("global_load_lds" in l for l in seg) == 0 or sum("ds_read_b128" in l for l in seg) != 4 + 2 * wn:
+                    problems.append(f"planes<{wn}>: read phase {k}: unexpected DMA / fragment read count")
+    return problems
+
+
+def compile_asm(src, out):
+    cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", f"-I{ROOT}/include",
+           "-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", out]
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return open(out).read()
+
+
 def main():
     with tempfile.TemporaryDirectory() as td:
-        out = os.path.join(td, "row.s")
-        cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", f"-I{ROOT}/include",
-               "-S", "--cuda-device-only", os.path.join(CSRC, "conv3x3_f16x3_row.hip"), "-o", out]
-        subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        problems = check(open(out).read())
+        problems = check(compile_asm("conv3x3_f16x3_row.hip", os.path.join(td, "row.s")))
+        problems += check_planes(compile_asm("conv3x3_planes.hip", os.path.join(td, "planes.s")))
     for p in problems:
         print("ISA check:", p)
     print("ISA check: ok" if not problems else f"ISA check: {len(problems)} problem(s)")

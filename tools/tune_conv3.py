@@ -32,9 +32,9 @@ for (N, H, W, cin, cout) in LAYERS:
         for sched in (0, 1):
             for wn in range(1, 9):
                 if wn > nt and wn != 1: continue
-                ops.lib.atmvfi_conv3x3_set_schedule(sched, wn)
+                ops.conv3_instance = (sched, wn)
                 res[(sched, wn)] = min(res.get((sched, wn), 1e9), timed(run, 8))
-        ops.lib.atmvfi_conv3x3_set_schedule(-1, 0)
+        ops.conv3_instance = None
         t_auto = min(t_auto, timed(run, 8))
     best = min(res, key=res.get)
     row = " ".join(f"{'rh'[s]}{wn}:{t:.3f}" for (s, wn), t in sorted(res.items(), key=lambda kv: kv[1])[:5])

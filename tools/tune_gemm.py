@@ -21,9 +21,9 @@ def sweep(tag, run, nt):
     for rep in range(2):
         for wn in range(1, 9):
             if wn > nt: continue
-            ops.lib.atmvfi_gemm_f16x3_set_tile_width(wn)
+            ops.gemm_tile_wn = wn
             res[wn] = min(res.get(wn, 1e9), timed(run))
-        ops.lib.atmvfi_gemm_f16x3_set_tile_width(0)
+        ops.gemm_tile_wn = 0
         t_auto = min(t_auto, timed(run))
     best = min(res, key=res.get)
     print(f"{tag}: auto {t_auto:.3f} ms | best wn{best} {res[best]:.3f} ({100 * (t_auto / res[best] - 1):+.1f} %) | " +
