@@ -1,11 +1,11 @@
 // Fused window attention for gfx950 (ATMFormer cross-attention + motion, Swin self-attention).
 //
 // One workgroup per (window, head); one wavefront per 16-query tile.
-//   S^T = K Q^T   : MFMA A = K fragment (LDS, ds_read_b128), B = Q fragment (global, once per wave)
+//   S^T = K Q^T   : MFMA A = K fragment (LDS, ds_read_b128), B = Q fragment (global, all chunks requested up front)
 //                   -> lane (r = lane&15, g = lane>>4) holds S[q = 16w + r][key = 16kt + 4g + e]
 //   softmax       : lane-local over its 4*NT keys, then two __shfl_xor (16, 32) across the 4 lane groups
 //   motion        : sum_k P[q,k] * (k_xy - q_xy) from the same registers (no relative_coord table)
-//   O^T = V^T P^T : MFMA A = V^T fragment (LDS), B = P^T = the S accumulators as they stand
+//   O^T = V^T P^T : MFMA A = V^T fragment (LDS holds V transposed: ds_read_b128), B = P^T = the S accumulators as they stand
 //                   (key index on the register axis = the k axis of the next MFMA; no LDS round trip)
 //                   -> lane holds O[q][d = 16dt + 4g + e]: one 16-byte store per d-tile.
 // The N x N attention matrix and the 2 x N x N motion product of the reference
@@ -16,6 +16,15 @@
 
 namespace {
 
+// LDS images, both read as MFMA A-operand fragments by ONE ds_read_b128 per lane and 4 k-steps:
+//   Ks [NPAD keys][PK slots of 16 B]   K[key][d],   fragment (key tile kt, d chunk c): row 16 kt + r, slot 4 c + g
+//   Vt [DPAD d   ][PV slots of 16 B]   V^T[d][key], fragment (d tile dt, key tile kt): row 16 dt + r, slot 4 kt + g
+// with the slot XOR-swizzled by (row & 15): the 16 lanes ds_read_b128 serves per cycle ({0-3,12-15,20-27}, ...) are rows
+// {0-3,12-15} at slot s and rows {4-11} at slot s + 1, and (s ^ {0-3,12-15}) u ((s+1) ^ {4-11}) are 16 different slots = all 64
+// banks once.  (The first version kept V row-major and fed the PV MFMAs from scalar ds_read_b32 column reads, and its K rows had a
+// pitch of hd + 4 floats: SQ_LDS_BANK_CONFLICT was 75 % of SQ_INSTS_LDS, profiles/r01_lds_counters.txt.)
+__device__ __forceinline__ int slots16(int n) { return (n + 15) & ~15; }
+
 template <int NT>
 __global__ __launch_bounds__(64 * NT) void window_attn_kernel(
     const float* __restrict__ qkv, const RowSink out, float* __restrict__ motion,
@@ -23,35 +32,24 @@ __global__ __launch_bounds__(64 * NT) void window_attn_kernel(
     float scale) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NPAD = NT * 16;
-    const int stride = hd + ((hd & 7) ? 0 : 4);   // stride % 8 == 4: conflict-free V^T column reads
-    float* Ks = smem;
-    float* Vs = Ks + NPAD * stride;
-    int* Ls = reinterpret_cast<int*>(Vs + NPAD * stride);
+    const int nchunks = (hd + 15) >> 4;          // 16-wide d chunks (QK^T) = 16-row d tiles (PV)
+    const int DPAD = 16 * nchunks;
+    const int PK = slots16(DPAD / 4), PV = slots16(NPAD / 4);
+    float* Ks = smem;                            // [NPAD][PK * 4]
+    float* Vt = Ks + NPAD * PK * 4;              // [DPAD][PV * 4]
+    int* Ls = reinterpret_cast<int*>(Vt + DPAD * PV * 4);
 
     const int tid = threadIdx.x;
-    const int b = blockIdx.x / heads;
-    const int h = blockIdx.x - b * heads;
+    // XCD-aware order: blocks i and i + 8 share an XCD (and its L2), so the `heads` workgroups of one window run back to back on
+    // ONE XCD: a head's slice of a qkv row is hd * 4 bytes (192 B at hd = 48), i.e. it shares cache lines with its neighbours,
+    // and with the heads of a window dealt round-robin over the eight L2s every one of them fetched those lines from HBM again
+    // (PMC: 1.34x the algorithmic read bytes).
+    const int slot = blockIdx.x >> 3;
+    const int b = (slot / heads) * 8 + (blockIdx.x & 7);
+    const int h = slot % heads;
+    if (b >= Bw) return;
     const int bk = (b + kv_shift) % Bw;
     const int C3 = 3 * C;
-
-    // ---- stage K and V of this head (zero rows for padded keys) ----
-    const int hd4 = hd >> 2;
-    for (int idx = tid; idx < NPAD * hd4; idx += 64 * NT) {
-        const int key = idx / hd4;
-        const int d = (idx - key * hd4) << 2;
-        f32x4 kv = (f32x4){0.f, 0.f, 0.f, 0.f}, vv = kv;
-        if (key < N) {
-            const float* p = qkv + ((long long)bk * N + key) * C3 + C + h * hd + d;
-            kv = *reinterpret_cast<const f32x4*>(p);
-            vv = *reinterpret_cast<const f32x4*>(p + C);
-        }
-        *reinterpret_cast<f32x4*>(Ks + key * stride + d) = kv;
-        *reinterpret_cast<f32x4*>(Vs + key * stride + d) = vv;
-    }
-    for (int idx = tid; idx < NPAD; idx += 64 * NT)
-        Ls[idx] = (labels && idx < N) ? labels[(long long)(b % nW) * N + idx] : 0;
-    __syncthreads();
-
     const int lane = tid & 63;
     const int w = tid >> 6;
     const int r = lane & 15;
@@ -59,24 +57,69 @@ __global__ __launch_bounds__(64 * NT) void window_attn_kernel(
     const int q = 16 * w + r;
     const bool qok = q < N;
 
+    // ---- Q fragments of this wave, requested before anything else: they land while K and V are staged ----
+    constexpr int MAXC = NT >= 13 ? 4 : 8;       // hd <= 128 (<= 64 for the 13..16-tile windows: 1024 threads leave 128 registers)
+    f32x4 qf[MAXC];
+    const float* qrow = qkv + ((long long)b * N + (qok ? q : 0)) * C3 + h * hd;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        qf[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int d = 16 * c + 4 * g;
+        if (c < nchunks && qok && d < hd) qf[c] = *reinterpret_cast<const f32x4*>(qrow + d);
+    }
+
+    // ---- stage K (row-major) and V (transposed) of this head; zero for padded keys / head-dim padding.  All global loads of
+    // the pass are requested before the first LDS write (unconditional loads from clamped addresses, zeroed by selects: a
+    // predicated load makes hipcc wait for each one on the spot), so a workgroup pays ONE memory latency for its K/V tile. ----
+    const int dg = DPAD >> 2;
+    constexpr int UNR = 6;                                   // local: 64 keys x 12 groups / 256 threads = 3; global: 144 x 24 / 576 = 6
+    for (int base = 0; base < NPAD * dg; base += 64 * NT * UNR) {
+        f32x4 kv[UNR], vv[UNR];
+        int keyv[UNR], d4v[UNR];
+        bool okv[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int idx = base + u * 64 * NT + tid;
+            const int key = idx / dg;
+            const int d4 = idx - key * dg;
+            keyv[u] = key;
+            d4v[u] = d4;
+            okv[u] = key < N && (d4 << 2) < hd;
+            const float* p = qkv + ((long long)bk * N + (okv[u] ? key : 0)) * C3 + C + h * hd + (okv[u] ? (d4 << 2) : 0);
+            kv[u] = *reinterpret_cast<const f32x4*>(p);
+            vv[u] = *reinterpret_cast<const f32x4*>(p + C);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int key = keyv[u], d4 = d4v[u], d = d4 << 2;
+            if (key < NPAD) {
+                const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const f32x4 k4 = okv[u] ? kv[u] : z, v4 = okv[u] ? vv[u] : z;
+                *reinterpret_cast<f32x4*>(Ks + (key * PK + (d4 ^ (key & 15))) * 4) = k4;
+                const int ks = key >> 2, ke = key & 3;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Vt[((d + e) * PV + (ks ^ ((d + e) & 15))) * 4 + ke] = v4[e];
+            }
+        }
+    }
+    for (int idx = tid; idx < NPAD; idx += 64 * NT)
+        Ls[idx] = (labels && idx < N) ? labels[(long long)(b % nW) * N + idx] : 0;
+    __syncthreads();
+
     // ---- S^T = K Q^T ----
     f32x4 s[NT];
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const float* qrow = qkv + ((long long)b * N + (qok ? q : 0)) * C3 + h * hd;
-    const int nchunks = (hd + 15) >> 4;
-    for (int c = 0; c < nchunks; ++c) {
-        const int d = 16 * c + 4 * g;
-        const bool dok = d < hd;
-        f32x4 qf = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (qok && dok) qf = *reinterpret_cast<const f32x4*>(qrow + d);
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt) {
-            f32x4 kf = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (dok) kf = *reinterpret_cast<const f32x4*>(Ks + (16 * kt + r) * stride + d);
+    for (int c = 0; c < MAXC; ++c) {
+        if (c < nchunks) {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[ks], qf[ks], s[kt], 0, 0, 0);
+            for (int kt = 0; kt < NT; ++kt) {
+                const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + ((16 * kt + r) * PK + ((4 * c + g) ^ r)) * 4);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[ks], qf[c][ks], s[kt], 0, 0, 0);
+            }
         }
     }
 
@@ -108,10 +151,11 @@ __global__ __launch_bounds__(64 * NT) void window_attn_kernel(
             s[kt][e] = p;
             sum += p;
         }
+    const float inv_ws = 1.0f / (float)ws;        // key / ws for key < 256, ws <= 16: floor((key + 0.5) / ws) is exact in fp32
     sum += __shfl_xor(sum, 16);
     sum += __shfl_xor(sum, 32);
     const float inv = 1.0f / sum;
-    const float qx = (float)(q % ws), qy = (float)(q / ws);
+    const float qy = floorf(((float)q + 0.5f) * inv_ws), qx = (float)q - qy * (float)ws;
     float mox = 0.f, moy = 0.f;
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
@@ -120,9 +164,9 @@ __global__ __launch_bounds__(64 * NT) void window_attn_kernel(
             const int key = 16 * kt + 4 * g + e;
             const float p = s[kt][e] * inv;
             s[kt][e] = p;
-            const int ky = key / ws;
-            mox += p * ((float)(key - ky * ws) - qx);
-            moy += p * ((float)ky - qy);
+            const float ky = floorf(((float)key + 0.5f) * inv_ws);
+            mox += p * (((float)key - ky * (float)ws) - qx);
+            moy += p * (ky - qy);
         }
     if (motion) {
         mox += __shfl_xor(mox, 16);
@@ -136,20 +180,17 @@ __global__ __launch_bounds__(64 * NT) void window_attn_kernel(
         }
     }
 
-    // ---- O^T = V^T P^T ----
-    const int ndt = (hd + 15) >> 4;
+    // ---- O^T = V^T P^T: the S accumulators as they stand are the B operand (key index on the register axis) ----
     const long long orow = (long long)b * N + (qok ? q : 0);
-    for (int dt = 0; dt < ndt; ++dt) {
+    for (int dt = 0; dt < nchunks; ++dt) {
         f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const int dcol = 16 * dt + r;
-        const bool cok = dcol < hd;
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt)
+        for (int kt = 0; kt < NT; ++kt) {
+            const f32x4 vf = *reinterpret_cast<const f32x4*>(Vt + ((16 * dt + r) * PV + ((4 * kt + g) ^ r)) * 4);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const float vf = cok ? Vs[(16 * kt + 4 * g + ks) * stride + dcol] : 0.f;
-                o = __builtin_amdgcn_mfma_f32_16x16x4f32(vf, s[kt][ks], o, 0, 0, 0);
-            }
+            for (int ks = 0; ks < 4; ++ks)
+                o = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[ks], s[kt][ks], o, 0, 0, 0);
+        }
         const int d = 16 * dt + 4 * g;
         if (qok && d < hd) sink_store4(out, orow, h * hd + d, o);
     }
@@ -186,8 +227,9 @@ __global__ void motion_head_kernel(const float* __restrict__ motion, const int* 
 template <int NT>
 int launch_attn(const float* qkv, const RowSink out, float* motion, const int* labels, int Bw, int nW, int N, int ws,
                 int heads, int hd, int kv_shift, hipStream_t s) {
-    const int stride = hd + ((hd & 7) ? 0 : 4);
-    const size_t lds = (size_t)(2 * NT * 16 * stride + NT * 16) * sizeof(float);
+    const int dpad = (hd + 15) / 16 * 16, npad = NT * 16;
+    const size_t lds = ((size_t)npad * ((dpad / 4 + 15) / 16 * 16) * 4 + (size_t)dpad * ((npad / 4 + 15) / 16 * 16) * 4 + npad) * sizeof(float);
+    ATMVFI_REQUIRE(hd <= (NT >= 13 ? 64 : 128), ATMVFI_EINVAL, "window_attention: head dim %d too large for a %d-token window", hd, N);
     ATMVFI_REQUIRE(lds <= 160 * 1024, ATMVFI_EINVAL,
                    "window_attention: K/V tile of %zu bytes exceeds the 160 KiB LDS (ws %d, hd %d)", lds, ws, hd);
     auto kern = window_attn_kernel<NT>;
@@ -196,7 +238,7 @@ int launch_attn(const float* qkv, const RowSink out, float* motion, const int* l
         ATMVFI_REQUIRE(e == hipSuccess, ATMVFI_ELAUNCH, "window_attention: hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
     const float scale = 1.0f / sqrtf((float)hd);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(Bw * heads)), dim3(64 * NT), lds, s, qkv, out, motion, labels, N, nW, ws,
+    hipLaunchKernelGGL(kern, dim3((unsigned)((Bw + 7) / 8 * 8 * heads)), dim3(64 * NT), lds, s, qkv, out, motion, labels, N, nW, ws,
                        heads, hd, heads * hd, Bw, kv_shift, scale);
     return atmvfi::check_launch("window_attention");
 }
@@ -212,10 +254,10 @@ extern "C" int atmvfi_window_attention(const float* qkv, float* out, float* moti
     const RowSink sink{out, heads * hd, (_Float16*)out_hi, (_Float16*)out_lo, plane_ld};
     ATMVFI_REQUIRE(Bw > 0 && nW > 0 && Bw % nW == 0, ATMVFI_EINVAL, "window_attention: Bw %d must be a positive multiple of nW %d", Bw, nW);
     ATMVFI_REQUIRE(ws >= 1 && ws <= 16, ATMVFI_EINVAL, "window_attention: window size %d outside 1..16", ws);
-    ATMVFI_REQUIRE(heads > 0 && hd > 0 && hd % 4 == 0, ATMVFI_EINVAL, "window_attention: head dim %d must be a multiple of 4", hd);
+    ATMVFI_REQUIRE(heads > 0 && hd > 0 && hd % 4 == 0 && hd <= 128, ATMVFI_EINVAL, "window_attention: head dim %d must be a multiple of 4, at most 128", hd);
     ATMVFI_REQUIRE(kv_shift >= 0 && kv_shift < Bw, ATMVFI_EINVAL, "window_attention: kv_shift out of range");
     ATMVFI_REQUIRE(atmvfi::aligned16(qkv), ATMVFI_EALIGN, "window_attention: qkv must be 16-byte aligned");
-    ATMVFI_REQUIRE((long long)Bw * heads < (1ll << 31), ATMVFI_EINVAL, "window_attention: grid too large");
+    ATMVFI_REQUIRE(((long long)Bw + 8) * heads < (1ll << 31), ATMVFI_EINVAL, "window_attention: grid too large");
     const int N = ws * ws;
     const int nt = (N + 15) / 16;
     hipStream_t s = (hipStream_t)stream;

@@ -1,12 +1,15 @@
+# One gpurun call = one evidence set (same box): bench line, rocprofv3 kernel stats, HBM traffic (two PMC passes).
+#   bash tools/collect_profiles.sh <tag>        -> gpurun_out/<tag>_{bench.json,kernel_stats.csv,pmc_hbm_traffic.json}
 set -e
+TAG=${1:-r02}
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-python bench.py > gpurun_out/v12_bench.json 2> gpurun_out/v12_bench_err.txt
-rm -rf gpurun_out/v12_stats gpurun_out/v12_fetch gpurun_out/v12_write
-rocprofv3 --kernel-trace --stats -d gpurun_out/v12_stats --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-profile --no-host-io > gpurun_out/v12_stats.log 2>&1
-python tools/pmc_summary.py stats gpurun_out/v12_stats 7 gpurun_out/v12_kernel_stats.csv > gpurun_out/v12_stats_summary.txt 2>&1
-rocprofv3 --pmc FETCH_SIZE -d gpurun_out/v12_fetch --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-host-io > gpurun_out/v12_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d gpurun_out/v12_write --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-host-io > gpurun_out/v12_write.log 2>&1
-python tools/pmc_summary.py traffic gpurun_out/v12_fetch gpurun_out/v12_write 2 gpurun_out/v12_pmc_traffic.json > gpurun_out/v12_pmc_summary.txt 2>&1
+python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench_err.txt
+rm -rf gpurun_out/${TAG}_stats gpurun_out/${TAG}_fetch gpurun_out/${TAG}_write
+rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_stats --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-profile --no-host-io > gpurun_out/${TAG}_stats.log 2>&1
+python tools/pmc_summary.py stats gpurun_out/${TAG}_stats 7 gpurun_out/${TAG}_kernel_stats.csv > gpurun_out/${TAG}_stats_summary.txt 2>&1
+rocprofv3 --pmc FETCH_SIZE -d gpurun_out/${TAG}_fetch --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-host-io > gpurun_out/${TAG}_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d gpurun_out/${TAG}_write --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-host-io > gpurun_out/${TAG}_write.log 2>&1
+python tools/pmc_summary.py traffic gpurun_out/${TAG}_fetch gpurun_out/${TAG}_write 2 gpurun_out/${TAG}_pmc_hbm_traffic.json > gpurun_out/${TAG}_pmc_summary.txt 2>&1
 # keep only the summaries (raw traces are large)
-rm -rf gpurun_out/v12_stats gpurun_out/v12_fetch gpurun_out/v12_write
+rm -rf gpurun_out/${TAG}_stats gpurun_out/${TAG}_fetch gpurun_out/${TAG}_write
