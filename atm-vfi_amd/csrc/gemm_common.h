@@ -41,6 +41,10 @@ struct GemmDev {
     int ktot32;       // halves per split weight row = taps * cin_pad32
     const _Float16* a_hi;   // split-plane activations (gemm_split.hip), else null
     const _Float16* a_lo;
+    const _Float16* a_hi2;  // CONV mode: input chunks >= split_chunks come from a second plane buffer with in_ld2 rows per chunk
+    const _Float16* a_lo2;
+    int in_ld2, split_chunks;
+    int in_N;               // images (CONV with planes: the zero row is row N*H*W)
     unsigned long long* stamp;   // diagnostic builds only (ATMVFI_STAMP)
     int dbg;          // diagnostic ablations (gemm_split.hip, env ATMVFI_SPLIT_DEBUG): 1 = no stores, 2 = one k-step
     int mchunk;       // row tiles per XCD = ceil(row tiles / 8)

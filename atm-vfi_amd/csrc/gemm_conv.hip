@@ -263,13 +263,20 @@ extern "C" int atmvfi_gemm(const atmvfi_gemm_params* p, void* stream) {
         ATMVFI_REQUIRE(p->out_plane_rows > 0, ATMVFI_EINVAL, "gemm: plane sink needs out_plane_rows");
     }
     if (planes) {
-        ATMVFI_REQUIRE(p->in_hi && p->in_lo && p->precision == ATMVFI_PREC_F16X3 && p->mode != ATMVFI_GEMM_CONV && !p->in_prelu,
-                       ATMVFI_EINVAL, "gemm: split-plane input needs both planes, precision f16x3, LINEAR or DECONV mode and no in_prelu");
+        ATMVFI_REQUIRE(p->in_hi && p->in_lo && p->precision == ATMVFI_PREC_F16X3 && !p->in_prelu,
+                       ATMVFI_EINVAL, "gemm: split-plane input needs both planes, precision f16x3 and no in_prelu");
         ATMVFI_REQUIRE(atmvfi::aligned16(p->in_hi) && atmvfi::aligned16(p->in_lo) && p->in_rpg == 0, ATMVFI_EALIGN,
                        "gemm: split planes need 16-byte aligned pointers and plain rows");
         const long long mrows = p->mode == ATMVFI_GEMM_LINEAR ? (long long)p->M : (long long)p->N * p->H * p->W;
-        ATMVFI_REQUIRE(p->in_ld >= mrows, ATMVFI_EALIGN, "gemm: with split planes in_ld is the plane row count and must cover M (%lld > %d)",
+        // CONV reads the row behind the last pixel for taps that fall outside the image: it must exist (and be zero)
+        ATMVFI_REQUIRE(p->in_ld >= mrows + (p->mode == ATMVFI_GEMM_CONV ? 1 : 0), ATMVFI_EALIGN,
+                       "gemm: with split planes in_ld is the plane row count and must cover the rows (+ the zero row in CONV mode): %lld > %d",
                        mrows, p->in_ld);
+        if (p->in_hi2 || p->in_lo2) {
+            ATMVFI_REQUIRE(p->mode == ATMVFI_GEMM_CONV && p->in_hi2 && p->in_lo2 && atmvfi::aligned16(p->in_hi2) && atmvfi::aligned16(p->in_lo2) &&
+                               p->in_ld2 >= mrows + 1 && p->in_split_chunks > 0 && p->in_split_chunks * 32 < p->Cin, ATMVFI_EINVAL,
+                           "gemm: a second plane source needs CONV mode, both planes, in_ld2 > N*H*W and 0 < 32 * in_split_chunks < Cin");
+        }
     }
     ATMVFI_REQUIRE(p->mode >= 0 && p->mode <= 2, ATMVFI_EINVAL, "gemm: bad mode %d", p->mode);
     ATMVFI_REQUIRE(p->Cin > 0 && p->Cout > 0, ATMVFI_EINVAL, "gemm: bad channel counts");
@@ -330,6 +337,11 @@ extern "C" int atmvfi_gemm(const atmvfi_gemm_params* p, void* stream) {
     ATMVFI_REQUIRE(d.M < (1ll << 40), ATMVFI_EINVAL, "gemm: M too large");
     d.a_hi = (const _Float16*)p->in_hi;
     d.a_lo = (const _Float16*)p->in_lo;
+    d.a_hi2 = (const _Float16*)p->in_hi2;
+    d.a_lo2 = (const _Float16*)p->in_lo2;
+    d.in_ld2 = p->in_ld2;
+    d.split_chunks = p->in_hi2 ? p->in_split_chunks : (1 << 30);
+    d.in_N = p->N;
     d.out_hi = (_Float16*)p->out_hi;
     d.out_lo = (_Float16*)p->out_lo;
     d.out_plane_rows = p->out_plane_rows;

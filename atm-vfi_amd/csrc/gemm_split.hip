@@ -63,7 +63,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 #define SABL(bit) false
 #endif
 
-template <int WGM, int WGN>
+template <int WGM, int WGN, bool CONVM>
 __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_split_kernel(const GemmDev a) {
     constexpr int NW = WGM * WGN;
     constexpr int NT = 64 * NW;
@@ -97,6 +97,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_split_kernel(const Gem
     //      the LDS image is linear in P (hi plane then lo plane), i.e. wave-uniform base + lane*16 B as LDS-DMA requires.
     const _Float16* asrc[APT];
     int adst[APT];
+    // CONV mode (strided / dilated / 1x1 convolutions on split-plane input): k-step = (tap, 32-channel chunk); GEMM row m is output
+    // pixel (n, oy, ox) and its operand row at tap (ky, kx) is input pixel (n, oy*stride - pad + ky*dil, ox*stride - pad + kx*dil),
+    // or the planes' zero row N*H*W when that falls outside the image -- the same LDS-DMA with a per-lane source row.  Pieces i
+    // and i + APT/2 are the hi / lo plane of the same rows.
+    int ciy[APT / 2], cix[APT / 2];
+    long long crow[APT / 2];
 #pragma unroll
     for (int i = 0; i < APT; ++i) {
         const int P = (i * NW + wave) * 64 + lane;
@@ -107,7 +113,35 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_split_kernel(const Gem
         if (m >= a.M) m = a.M - 1;                                  // tail rows: valid address, result never stored
         asrc[i] = (plane ? a.a_lo : a.a_hi) + m * 32 + ls * 8;      // chunk kc adds kc * plane_rows * 32
         adst[i] = (i * NW + wave) * 64 * 8;
+        if (CONVM && i < APT / 2) {
+            const int hw = a.Ho * a.Wo;
+            const int n = (int)(m / hw);
+            const int rem = (int)(m - (long long)n * hw);
+            const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+            ciy[i] = oy * a.stride - a.pad;
+            cix[i] = ox * a.stride - a.pad;
+            crow[i] = ((long long)n * a.H + ciy[i]) * a.W + cix[i];
+        }
     }
+    static_assert(APT == 4, "CONV mode assumes pieces 0,1 = hi plane and 2,3 = lo plane of the same rows");
+    int c_tap = 0, c_chunk = 0;                                       // (tap, chunk) of the k-step whose pieces are issued next
+    auto next_k = [&]() {
+        if constexpr (CONVM) { if (++c_chunk == a.cpt32) { c_chunk = 0; ++c_tap; } }
+    };
+    const long long zero_row = (long long)a.in_N * a.H * a.W;
+    auto a_src = [&](int i, int kc) -> const _Float16* {
+        if constexpr (!CONVM) return asrc[i] + kc * ((long long)a.in_ld * 32);
+        const int j = i & 1;
+        const int ky = c_tap / a.kw, kx = c_tap - ky * a.kw;
+        const int iy = ciy[j] + ky * a.dil, ix = cix[j] + kx * a.dil;
+        const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        const long long row = ok ? crow[j] + (long long)(ky * a.dil) * a.W + kx * a.dil : zero_row;
+        const int ls8 = (((lane & 3) ^ swz64((((i * NW + wave) * 64 + lane) >> 2) % BM))) * 8;
+        const bool second = c_chunk >= a.split_chunks;               // input channels from a second plane buffer (concat-free)
+        const _Float16* base = second ? (i >= 2 ? a.a_lo2 : a.a_hi2) + (long long)(c_chunk - a.split_chunks) * a.in_ld2 * 32
+                                      : (i >= 2 ? a.a_lo : a.a_hi) + (long long)c_chunk * a.in_ld * 32;
+        return base + row * 32 + ls8;
+    };
     const _Float16* wsrc[WPT];
     int wdst[WPT];
 #pragma unroll
@@ -121,19 +155,19 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_split_kernel(const Gem
         wsrc[i] = (plane ? a.w_lo : a.w_hi) + (long long)n * 32 + ls * 8;       // k-step kc adds kc * wrows * 32
         wdst[i] = W_HI_OFF + (i * NW + wave) * 64 * 8;
     }
-    const long long astep = (long long)a.in_ld * 32, wstep = (long long)a.wrows * 32;      // halves per k-step of a plane (in_ld = plane rows)
+    const long long wstep = (long long)a.wrows * 32;      // halves per k-step of a weight plane
     auto issue = [&](int kc, int buf) {
         _Float16* st = smem + buf * STAGE_HALVES;
 #pragma unroll
-        for (int i = 0; i < APT; ++i) dma16(asrc[i] + kc * astep, st + adst[i]);
+        for (int i = 0; i < APT; ++i) dma16(a_src(i, kc), st + adst[i]);
 #pragma unroll
         for (int i = 0; i < WPT; ++i) dma16(wsrc[i] + kc * wstep, st + wdst[i]);
     };
     // one third of a stage's pieces (PIECES == 6: A pieces 0-3, W pieces 0-1)
     auto issue_pair = [&](int kc, int buf, int p) {
         _Float16* st = smem + buf * STAGE_HALVES;
-        if (p == 0 && !SABL(8)) { dma16(asrc[0] + kc * astep, st + adst[0]); dma16(asrc[1] + kc * astep, st + adst[1]); }
-        if (p == 1 && !SABL(8)) { dma16(asrc[2] + kc * astep, st + adst[2]); dma16(asrc[3] + kc * astep, st + adst[3]); }
+        if (p == 0 && !SABL(8)) { dma16(a_src(0, kc), st + adst[0]); dma16(a_src(1, kc), st + adst[1]); }
+        if (p == 1 && !SABL(8)) { dma16(a_src(2, kc), st + adst[2]); dma16(a_src(3, kc), st + adst[3]); }
         if (p == 2) { dma16(wsrc[0] + kc * wstep, st + wdst[0]); dma16(wsrc[1] + kc * wstep, st + wdst[1]); }
     };
     // The DMA of one stage is spread over three items (an LDS-DMA instruction holds the wave's issue for 60-180 cycles)
@@ -179,8 +213,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_split_kernel(const Gem
     const int nk = (a.dbg & 2) ? 1 : a.nchunks32;
     atmvfi::gemm_dma_consts<BN>(a, n0, cst, wave, lane);      // oldest DMA of the wave: landed whenever stage 0 has
     issue(0, 0);
+    next_k();
     if (nk > 1) issue(1, 1);
+    next_k();
     if (nk > 2) issue(2, 2);
+    next_k();                                   // (tap, chunk) of k-step 3, the first one issued inside the loop
     if (nk > 2) wait_vmcnt<2 * PIECES>();
     else if (nk > 1) wait_vmcnt<PIECES>();
     else wait_vmcnt<0>();
@@ -219,6 +256,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_split_kernel(const Gem
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
+            if (kc > 0) next_k();               // every A piece of stage kc + 2 has been issued (items 0, 1 above)
             ikc = kc + 3;
             ibuf = buf;
             if (!SABL(4)) load_x(sn, 0);
@@ -325,12 +363,12 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
     *reinterpret_cast<f16x8*>(lo + off) = l;
 }
 
-template <int WGM, int WGN>
+template <int WGM, int WGN, bool CONVM>
 int launch_split(const GemmDev& d, int ngemm, hipStream_t s) {
     constexpr int BM = 64 * WGM, BN = 64 * WGN;
     const size_t lds = (size_t)3 * (2 * BM + 2 * BN) * 32 * sizeof(_Float16) + atmvfi::gemm_const_floats(BN) * sizeof(float);
-    auto kern = gemm_split_kernel<WGM, WGN>;
-    const hipError_t attr_err = atmvfi::allow_dynamic_lds<gemm_split_kernel<WGM, WGN>>(lds);
+    auto kern = gemm_split_kernel<WGM, WGN, CONVM>;
+    const hipError_t attr_err = atmvfi::allow_dynamic_lds<gemm_split_kernel<WGM, WGN, CONVM>>(lds);
     ATMVFI_REQUIRE(attr_err == hipSuccess, ATMVFI_ELAUNCH, "gemm_split: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
     GemmDev dd = d;
 #if defined(ATMVFI_ABLATE) || defined(ATMVFI_STAMP)
@@ -352,7 +390,7 @@ int launch_split(const GemmDev& d, int ngemm, hipStream_t s) {
 }  // namespace
 
 int atmvfi::launch_gemm_split(const GemmDev& d, int ngemm, hipStream_t s) {
-    return launch_split<4, 2>(d, ngemm, s);
+    return d.mode == ATMVFI_GEMM_CONV ? launch_split<4, 2, true>(d, ngemm, s) : launch_split<4, 2, false>(d, ngemm, s);
 }
 
 extern "C" int atmvfi_split_planes_at(const float* in, int in_ld, int64_t M, int C, const float* prelu, void* hi, void* lo, int plane_rows,

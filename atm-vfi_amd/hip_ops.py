@@ -53,6 +53,7 @@ class GemmParams(ctypes.Structure):
         ("in_hi", c_f), ("in_lo", c_f),
         ("out_hi", c_f), ("out_lo", c_f), ("out_plane_rows", ctypes.c_int64), ("out_plane_c0", ctypes.c_int32),
         ("out_plane_gc", ctypes.c_int32), ("tile_wn", ctypes.c_int32),
+        ("in_hi2", c_f), ("in_lo2", c_f), ("in_ld2", ctypes.c_int32), ("in_split_chunks", ctypes.c_int32),
     ]
 
 
@@ -404,6 +405,47 @@ class HipOps:
                   planes.t[0].data_ptr() if planes is not None else None, planes.t[1].data_ptr() if planes is not None else None,
                   planes.ld_rows if planes is not None else 0, planes_c0, _ptr(planes_prelu) if planes is not None else None, out_cmin, wn,
                   self._stream())
+
+    def conv_planes(self, x: Planes, n: int, h: int, wd: int, w: PackedWeight, out=None, stride=1, pad=1, dil=1, bias=None, prelu=None,
+                    sink: Optional[Planes] = None, sink_c0: int = 0, in_chunk0: int = 0, x2: Optional[Planes] = None, x2_chunk0: int = 0,
+                    split_chunks: int = 0):
+        """Conv2d (k 1 or 3, any stride / dilation; + bias, PReLU) on split-plane input through the LDS-DMA GEMM's CONV mode: rows of
+        ``x`` = pixels of an [n,h,wd] map, channels from 32-channel chunk ``in_chunk0`` on.  With ``x2`` the first ``split_chunks``
+        chunks come from ``x`` and the rest from ``x2`` (chunk ``x2_chunk0`` on): a channel concat that never materialises.
+        ``out``: fp32 NHWC view or None; ``sink``: plane sink at channel ``sink_c0``.  Needs the spare zero row of ``Planes.alloc``."""
+        if self.precision != "f16x3" or w.hi is None or w.mode != GEMM_CONV:
+            raise ValueError("conv_planes: needs the f16x3 engine and split conv weights")
+        cin, cout = w.cin, w.cout
+        oh = (h + 2 * pad - dil * (w.kh - 1) - 1) // stride + 1
+        ow = (wd + 2 * pad - dil * (w.kw - 1) - 1) // stride + 1
+        c1 = 32 * split_chunks if x2 is not None else cin
+        for t, c0, cc, what in ((x, in_chunk0, c1, "x"),) + (((x2, x2_chunk0, cin - c1, "x2"),) if x2 is not None else ()):
+            if t.rows != n * h * wd or t.ld_rows <= t.rows or 32 * c0 + cc > t.chunks * 32:
+                raise ValueError(f"conv_planes: {what} [{t.rows} (+{t.ld_rows - t.rows} spare), {t.c}] does not hold {n}x{h}x{wd} pixels x "
+                                 f"{cc} channels from chunk {c0} (one spare zero row is required)")
+        if x2 is not None and not 0 < 32 * split_chunks < cin:
+            raise ValueError("conv_planes: split_chunks must cut the input channels at a 32-channel boundary inside (0, Cin)")
+        old = 0
+        if out is not None:
+            old, on, ooh, oow, oc = nhwc_view(out, "conv_planes.out")
+            if (on, ooh, oow, oc) != (n, oh, ow, cout):
+                raise ValueError(f"conv_planes: out {tuple(out.shape)} != [{n},{oh},{ow},{cout}]")
+        elif sink is None:
+            raise ValueError("conv_planes: no output")
+        p = GemmParams(mode=GEMM_CONV, in_=None, in_ld=x.ld_rows, N=n, H=h, W=wd, Cin=cin, in_gstride=0, in_rpg=0,
+                       weight=w.packed.data_ptr(), Cout=cout, kh=w.kh, kw=w.kw, stride=stride, pad=pad, dil=dil,
+                       Ho=oh, Wo=ow, M=n * oh * ow, out=None if out is None else out.data_ptr(), out_ld=old, out_gstride=0, out_rpg=0,
+                       out_row_map=None, bias=_ptr(bias), prelu=_ptr(prelu), in_prelu=None, residual=None, res_ld=0)
+        p.precision, p.weight_hi, p.weight_lo = 1, w.hi.data_ptr(), w.lo.data_ptr()
+        off = in_chunk0 * x.ld_rows * 64
+        p.in_hi, p.in_lo = x.t[0].data_ptr() + off, x.t[1].data_ptr() + off
+        if x2 is not None:
+            off2 = x2_chunk0 * x2.ld_rows * 64
+            p.in_hi2, p.in_lo2, p.in_ld2, p.in_split_chunks = x2.t[0].data_ptr() + off2, x2.t[1].data_ptr() + off2, x2.ld_rows, split_chunks
+        self._gemm_sink(p, sink, n * oh * ow, cout, sink_c0, 0, 1, "conv_planes")
+        meta = {"flops": 2.0 * n * oh * ow * cout * cin * w.kh * w.kw, "bytes": 4.0 * (n * h * wd * cin + n * oh * ow * cout + cout * cin * w.kh * w.kw),
+                "shape": f"M{n * oh * ow} N{cout} K{cin * w.kh * w.kw}"}
+        self._run("conv2d_split", meta, self.lib.atmvfi_conv2d, ctypes.byref(p), self._stream())
 
     def deconv(self, x, w: PackedWeight, out, bias=None, prelu=None, in_prelu=None, planes: Optional[Planes] = None,
                sink: Optional[Planes] = None, sink_c0: int = 0, in_shape=None):

@@ -41,6 +41,14 @@ def _r4(c: int) -> int:
     return (c + 3) // 4 * 4
 
 
+class _PMap:
+    """A feature map that lives in split planes only: channels [32 * chunk0, 32 * chunk0 + c) of ``p``, rows = pixels of [n, h, w]."""
+    __slots__ = ("p", "n", "h", "w", "chunk0", "c")
+
+    def __init__(self, p, n, h, w, chunk0, c):
+        self.p, self.n, self.h, self.w, self.chunk0, self.c = p, n, h, w, chunk0, c
+
+
 class Network(nn.Module):
     VARIANT = "base"
 
@@ -324,6 +332,15 @@ class Network(nn.Module):
         ops.conv(x, P[f"pk:{p}.0.weight"], out, stride=2, pad=1, dil=1, bias=P[f"{p}.0.bias"], prelu=P[f"{p}.1.weight"],
                  planes=sink, planes_c0=sink_c0, out_shape=shape)
 
+    def _conv_p(self, ops, P, p, src: "_PMap", stride=1, pad=1, dil=1, act=True, out=None, sink=None, sink_c0=0):
+        """conv() / nn.Conv2d of the reference (any stride / dilation, k 1 or 3) on a split-plane map through the LDS-DMA GEMM."""
+        if act:
+            wk, bias, prelu = f"pk:{p}.0.weight", P[f"{p}.0.bias"], P[f"{p}.1.weight"]
+        else:
+            wk, bias, prelu = f"pk:{p}.weight", P[f"{p}.bias"], None
+        ops.conv_planes(src.p, src.n, src.h, src.w, P[wk], out=out, stride=stride, pad=pad, dil=dil, bias=bias, prelu=prelu, sink=sink,
+                        sink_c0=sink_c0, in_chunk0=src.chunk0)
+
     def _plane_deconvs(self, ops) -> bool:
         """Decoder deconvs on the LDS-DMA GEMM (operands as split planes) instead of the fp32-input engine."""
         return (getattr(ops, "precision", None) == "f16x3" and getattr(ops, "split_planes_ok", False) and self.use_split_planes
@@ -351,20 +368,34 @@ class Network(nn.Module):
         d = self._v.hidden_dims
         f, h, w, _ = x0.shape
         a = self.buf(f"{tag}e0a", f, h, w, d[0]); self._conv_act(ops, P, "feat_extracts.0.0", x0[..., :3], a)
-        e0 = self.buf(f"{tag}e0", f, h, w, d[0]); self._conv_act(ops, P, "feat_extracts.0.1", a, e0)
-        if self._plane_convs(ops) and min(d[1:]) >= 32:
-            # stages 1-3: the stride-2 conv hands its result to the 3x3 / stride-1 conv as split planes only
-            fuse = self.buf(f"{tag}fuse_l", f, h // 8, w // 8, self._v.local_dim)
-            src, outs = e0, []
+        e0 = self.buf(f"{tag}e0", f, h, w, d[0])
+        if self._plane_convs(ops) and min(d[1:]) >= 32 and (self._v.local_dim - d[3]) % 32 == 0:
+            # Stages 1-3 entirely in split planes: stride-2 conv (LDS-DMA GEMM, CONV mode) -> planes -> 3x3 conv (plane kernel) ->
+            # planes; the last one writes s3 straight into the fusion buffer's planes.  No fp32 copy of e1, e2, s3 exists: their
+            # only readers are contractions.
+            # (The first stride-2 conv, 24 -> 48 channels at full resolution, stays on the fp32-input engine: the LDS-DMA GEMM's
+            # 128-column tile is 62 % padding at N = 48 -- 0.40 ms against 0.33 -- and e0 exists in fp32 anyway.)
+            self._conv_act(ops, P, "feat_extracts.0.1", a, e0)
+            ld = self._v.local_dim
+            fuse_p = self.planes(f"{tag}fuse_l_p", f * (h // 8) * (w // 8), ld)
+            src, outs = None, []
             for st in (1, 2, 3):
                 hs, ws = h >> st, w >> st
                 ap = self.planes(f"{tag}e{st}a_p", f * hs * ws, d[st])
-                self._conv_s2_sink(ops, P, f"feat_extracts.{st}.0", src, ap, (f, hs, ws, d[st]))
-                dst = fuse[..., self._v.local_dim - d[3]:] if st == 3 else self.buf(f"{tag}e{st}", f, hs, ws, d[st])
-                self._c3p(ops, P, f"feat_extracts.{st}.1", ap, f, hs, ws, out=dst)
-                outs.append(dst)
-                src = dst
-            return outs[0], outs[1], fuse
+                if st == 1:
+                    self._conv_s2_sink(ops, P, "feat_extracts.1.0", e0, ap, (f, hs, ws, d[1]))
+                else:
+                    self._conv_p(ops, P, f"feat_extracts.{st}.0", src, stride=2, sink=ap)
+                if st == 3:
+                    self._c3p(ops, P, "feat_extracts.3.1", ap, f, hs, ws, sink=fuse_p, sink_c0=ld - d[3])
+                    outs.append(_PMap(fuse_p, f, hs, ws, 0, ld))
+                else:
+                    ep = self.planes(f"{tag}e{st}_p", f * hs * ws, d[st])
+                    self._c3p(ops, P, f"feat_extracts.{st}.1", ap, f, hs, ws, sink=ep)
+                    outs.append(_PMap(ep, f, hs, ws, 0, d[st]))
+                    src = outs[-1]
+            return outs[0], outs[1], outs[2]
+        self._conv_act(ops, P, "feat_extracts.0.1", a, e0)
         a = self.buf(f"{tag}e1a", f, h // 2, w // 2, d[1]); self._conv_act(ops, P, "feat_extracts.1.0", e0, a, 2)
         e1 = self.buf(f"{tag}e1", f, h // 2, w // 2, d[1]); self._conv_act(ops, P, "feat_extracts.1.1", a, e1)
         a = self.buf(f"{tag}e2a", f, h // 4, w // 4, d[2]); self._conv_act(ops, P, "feat_extracts.2.0", e1, a, 2)
@@ -377,6 +408,18 @@ class Network(nn.Module):
     def _fusion(self, ops, P, p, fine, mid, fuse, c_mid, c_fine, tag):
         """CrossScaleFeatureFusion (network_base.py:73-85); the coarsest scale is already in
         fuse[..., c_mid+2*c_fine:].  Returns LayerNorm'ed tokens [F*h*w, C]."""
+        if isinstance(fuse, _PMap):
+            # the three strided convs sink into the fusion buffer's planes next to the coarsest scale; the 1x1 projection is the
+            # LDS-DMA GEMM on those planes (no fp32 fusion buffer, no fp32 -> fp16-pair conversion per column block)
+            f, h, w, c = fuse.n, fuse.h, fuse.w, fuse.c
+            self._conv_p(ops, P, f"{p}.layers.0", mid, stride=2, pad=1, dil=1, act=False, sink=fuse.p, sink_c0=0)
+            self._conv_p(ops, P, f"{p}.layers.1", fine, stride=4, pad=1, dil=1, act=False, sink=fuse.p, sink_c0=c_mid)
+            self._conv_p(ops, P, f"{p}.layers.2", fine, stride=4, pad=2, dil=2, act=False, sink=fuse.p, sink_c0=c_mid + c_fine)
+            t = self.buf(f"{tag}fproj", f * h * w, c)
+            ops.linear(fuse.p, P[f"pk:{p}.proj.weight"], t, bias=P[f"{p}.proj.bias"])
+            out = self.buf(f"{tag}fnorm", f * h * w, c)
+            ops.layernorm(t, out, P[f"{p}.norm.weight"], P[f"{p}.norm.bias"])
+            return out
         f, h, w, c = fuse.shape
         self._conv_plain(ops, P, f"{p}.layers.0", mid, fuse[..., 0:c_mid], stride=2, pad=1, dil=1)
         self._conv_plain(ops, P, f"{p}.layers.1", fine, fuse[..., c_mid:c_mid + c_fine], stride=4, pad=1, dil=1)
@@ -458,23 +501,37 @@ class Network(nn.Module):
                         out_sink=(mlp_in_p, 8, c) if (pc and blk == 1) else None)
             x = out
         hid = P[f"{mlp}.0.0.bias"].shape[0]
-        t2 = self.buf(f"{tag}mm2", b, h, w, hid)
         if pc:
             # [motion 8 | frame0 C | frame1 C] as split planes: the features come from fc2's plane sink, the eight motion
             # channels (written by the two motion heads) from one small split pass
             ops.split_planes(flat[:, 0:8], mlp_in_p, c0=0)
             t1p = self.planes(f"{tag}mm1_p", b * h * w, hid)
             self._c3p(ops, P, f"{mlp}.0", mlp_in_p, b, h, w, sink=t1p)
-            self._c3p(ops, P, f"{mlp}.1", t1p, b, h, w, out=t2)
-            return mlp_in, t2
+            t2p = self.planes(f"{tag}mm2_p", b * h * w, hid)
+            self._c3p(ops, P, f"{mlp}.1", t1p, b, h, w, sink=t2p)
+            return mlp_in, t2p
         t1 = self.buf(f"{tag}mm1", b, h, w, hid); self._conv_act(ops, P, f"{mlp}.0", mlp_in, t1)
-        self._conv_act(ops, P, f"{mlp}.1", t1, t2)
+        t2 = self.buf(f"{tag}mm2", b, h, w, hid); self._conv_act(ops, P, f"{mlp}.1", t1, t2)
         return mlp_in, t2
 
     def _global_motion(self, ops, P, e2, fuse_l, b, tag):
         """estimate_global_motion (network_base.py:391-415): returns the raw 5-channel map [B,h_,w_,5]."""
         v = self._v
         d = v.hidden_dims
+        if isinstance(fuse_l, _PMap):
+            f, h8, w8 = fuse_l.n, fuse_l.h, fuse_l.w
+            h_, w_ = h8 // 2, w8 // 2
+            s3 = _PMap(fuse_l.p, f, h8, w8, (v.local_dim - d[3]) // 32, d[3])
+            fuse_g = _PMap(self.planes(f"{tag}fuse_g_p", f * h_ * w_, v.global_dim), f, h_, w_, 0, v.global_dim)
+            ap = self.planes(f"{tag}ga_p", f * h_ * w_, v.last_feat_dim)
+            self._conv_p(ops, P, "last_feat_extract.0", s3, stride=2, sink=ap)
+            self._c3p(ops, P, "last_feat_extract.1", ap, f, h_, w_, sink=fuse_g.p, sink_c0=d[3] + 2 * d[2])
+            tokens = self._fusion(ops, P, "global_feature_fusion", e2, s3, fuse_g, d[3], d[2], tag + "g")
+            mlp_in, t2 = self._motion_branch(ops, P, "global_motion_atmformer", "global_motion_mlp", tokens, b, h_, w_,
+                                             self.global_motion_args["window_size"], tag + "g")
+            gout = self.buf(f"{tag}gout", b, h_, w_, 8)
+            self._head1x1(ops, P, "global_motion_mlp.2", t2, b, h_, w_, gout[..., :5])
+            return gout
         f, h8, w8, _ = fuse_l.shape
         h_, w_ = h8 // 2, w8 // 2
         s3 = fuse_l[..., v.local_dim - d[3]:]
@@ -491,8 +548,15 @@ class Network(nn.Module):
         mlp_in, t2 = self._motion_branch(ops, P, "global_motion_atmformer", "global_motion_mlp", tokens, b, h_, w_,
                                          self.global_motion_args["window_size"], tag + "g")
         gout = self.buf(f"{tag}gout", b, h_, w_, 8)
-        self._conv_plain(ops, P, "global_motion_mlp.2", t2, gout[..., :5], pad=0)
+        self._head1x1(ops, P, "global_motion_mlp.2", t2, b, h_, w_, gout[..., :5])
         return gout
+
+    def _head1x1(self, ops, P, p, t2, b, h, w, out):
+        """The 1x1 head of a motion MLP (network_base.py:158,195): on the hidden map's planes when the branch left it there."""
+        if isinstance(t2, Planes):
+            ops.conv_planes(t2, b, h, w, P[f"pk:{p}.weight"], out=out, stride=1, pad=0, dil=1, bias=P[f"{p}.bias"])
+        else:
+            self._conv_plain(ops, P, p, t2, out, pad=0)
 
     def _ensemble_flows(self, ops, P, im0, im1):
         """multiscale_global_motion_ensemble (network_base.py:564-605): global flows from the x1, x1/2
@@ -679,7 +743,7 @@ class Network(nn.Module):
             mlp_in, t2 = self._motion_branch(ops, P, "local_motion_atmformer", "local_motion_mlp", x_tokens, b, h, w,
                                              self.local_motion_args["window_size"], "l")
             motion8 = dec_in[..., 2 * C:2 * C + 5]
-            self._conv_plain(ops, P, "local_motion_mlp.2", t2, motion8, pad=0)
+            self._head1x1(ops, P, "local_motion_mlp.2", t2, b, h, w, motion8)
             # feature enhancement (:493-494)
             x = self._stacked(mlp_in, 8, C)
             e_mid = self.buf("enh0", 2 * b * h * w, C)
@@ -776,6 +840,7 @@ class Network(nn.Module):
                 feat0 = bufA[..., rh:2 * rh]
                 self._c3p(ops, P, "proj", rin_p, b, H, W, out=feat0, sink=bufA_p, sink_c0=rh, wkey="pk:proj.0.weight:planes")
                 feat1 = bufB[..., rh:2 * rh]
+                # (64 -> 64 at full resolution: too narrow for the LDS-DMA GEMM's 128-column tile, see _encoder)
                 self._conv_s2_sink(ops, P, "down1.0", feat0, bufB_p, (b, h2, w2, rh), out=feat1, sink_c0=rh)
                 d2a_p = self.planes("d2a_p", b * h4 * w4, 2 * rh)
                 self._conv_s2_sink(ops, P, "down2.0", bufB[..., rh:2 * rh + w2d], d2a_p, (b, h4, w4, 2 * rh))

@@ -86,7 +86,7 @@ typedef struct atmvfi_gemm_params {
     int32_t precision;
     const void* weight_hi;
     const void* weight_lo;
-    /* Split-plane input (F16X3, LINEAR and DECONV modes): when in_hi/in_lo are set the activations are read by LDS-DMA from two
+    /* Split-plane input (F16X3; every mode, CONV: see in_hi2 below): when in_hi/in_lo are set the activations are read by LDS-DMA from two
        fp16 planes in the chunk-major layout [Cin/32 chunks][plane rows][32] written by a producer kernel's sink or by
        atmvfi_split_planes; `in_ld` is then the plane row count (>= M), `in` is ignored, the pad channels of the last chunk must be
        finite (they meet zero weights). */
@@ -104,6 +104,13 @@ typedef struct atmvfi_gemm_params {
     int32_t out_plane_c0, out_plane_gc;
     /* F16X3, fp32 input: n-tiles of 16 columns per 256-row workgroup tile, 0 = cost model (default), 1..8 = forced (sweeps). */
     int32_t tile_wn;
+    /* CONV mode on split-plane input (in_hi / in_lo): rows are input pixels n*H*W + y*W + x, in_ld > N*H*W and row N*H*W of every chunk
+       is zero (taps outside the image read it).  Optionally the input channels come from TWO plane buffers (a torch.cat of the
+       reference that never materialises): chunks 0 .. in_split_chunks-1 from in_hi / in_lo, the rest from in_hi2 / in_lo2 (in_ld2 rows
+       per chunk, same pixel rows, same zero-row contract); both parts are whole 32-channel chunks. */
+    const void* in_hi2;
+    const void* in_lo2;
+    int32_t in_ld2, in_split_chunks;
 } atmvfi_gemm_params;
 
 #define ATMVFI_PREC_F32   0

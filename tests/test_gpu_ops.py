@@ -755,3 +755,74 @@ def test_conv3x3_planes_chunk_offset_and_auto_width(hip, dev):
     hip.conv3x3_planes(xp, N, H, W, pw, out=y1[..., :cout], bias=bias, in_chunk0=1, cin=cin)
     torch.cuda.synchronize()
     assert torch.equal(y0[..., :cout], y1[..., :cout])
+
+
+PLANE_CONV_CASES = [
+    # cin, cout, k, stride, pad, dil, H, W, N
+    (24, 48, 3, 2, 1, 1, 20, 28, 2),           # encoder stride 2
+    (48, 48, 3, 4, 1, 1, 24, 40, 2),           # fusion conv, stride 4
+    (48, 48, 3, 4, 2, 2, 24, 40, 2),           # stride 4, dilation 2
+    (64, 5, 1, 1, 0, 1, 10, 14, 2),            # 1x1 motion head
+    (40, 24, 3, 2, 1, 1, 11, 13, 1),           # ragged channels and sizes
+    (192, 288, 3, 2, 1, 1, 9, 15, 2),          # last_feat_extract.0
+    (96, 37, 3, 1, 1, 1, 7, 9, 1),             # stride 1 through the GEMM path as well
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", PLANE_CONV_CASES, ids=lambda c: f"cin{c[0]}_cout{c[1]}_k{c[2]}_s{c[3]}_d{c[5]}")
+def test_conv_from_split_planes(case, hip, dev):
+    """CONV mode of the LDS-DMA GEMM (per-tap source rows, zero row for the padding): bit-identical to the fp32-input f16x3
+    engine on the same values, fp32 output and plane sink (at a channel offset) alike; input view at a chunk offset."""
+    cin, cout, k, stride, pad, dil, H, W, N = case
+    g = torch.Generator().manual_seed(sum(case))
+    r4 = lambda c: (c + 3) // 4 * 4
+    xb = rnd(g, N, H, W, 32 + r4(cin), scale=1.5).to(dev)
+    x = xb[..., 32:32 + cin]
+    wt = rnd(g, cout, cin, k, k, scale=1.0 / np.sqrt(k * k * cin)).to(dev)
+    bias, slope = rnd(g, cout, scale=0.2).to(dev), (torch.rand(cout, generator=g) * 0.4).to(dev)
+    pw = hip.pack_weight(GEMM_CONV, wt)
+    oh = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    ow = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    y0 = torch.full((N, oh, ow, r4(cout)), 7.0, device=dev)
+    forced = hip.conv3_instance
+    hip.conv(x, pw, y0[..., :cout], stride, pad, dil, bias, slope)
+    xp = hip_ops.Planes.alloc(N * H * W, 32 + cin, dev)
+    hip.split_planes(xb[..., :32 + cin].flatten(0, 2), xp)
+    y1 = torch.full((N, oh, ow, r4(cout)), 7.0, device=dev)
+    c0 = 8
+    sink = hip_ops.Planes.alloc(N * oh * ow, c0 + cout, dev)
+    hip.conv_planes(xp, N, H, W, pw, out=y1[..., :cout], stride=stride, pad=pad, dil=dil, bias=bias, prelu=slope, sink=sink, sink_c0=c0,
+                    in_chunk0=1)
+    q = hip_ops.Planes.alloc(N * oh * ow, cout, dev)
+    hip.split_planes(y0[..., :cout].flatten(0, 2), q)
+    torch.cuda.synchronize()
+    if not (k == 3 and stride == 1):           # (the 3x3 / stride-1 fp32 path is the halo kernel: other k order, compare to tolerance)
+        assert torch.equal(y0, y1), maxdiff(y0, y1)
+    assert maxdiff(y0[..., :cout], y1[..., :cout]) <= 2e-5
+    if not (k == 3 and stride == 1):
+        assert torch.equal(sink.to_rows()[:, :, c0:c0 + cout], q.to_rows()[:, :, :cout])
+    assert hip.conv3_instance is forced
+
+
+@pytest.mark.gpu
+def test_conv_from_two_plane_sources(hip, dev):
+    """down2.0 of the refiner reads cat(feat1, dec1[:, :192]) (network_base.py:421-422): as two plane buffers, no concat."""
+    g = torch.Generator().manual_seed(8123)
+    N, H, W = 1, 14, 18
+    a = rnd(g, N, H, W, 64, scale=1.2).to(dev)
+    bfull = rnd(g, N, H, W, 200, scale=1.2).to(dev)
+    wt = rnd(g, 128, 256, 3, 3, scale=1.0 / np.sqrt(9 * 256)).to(dev)
+    bias, slope = rnd(g, 128, scale=0.2).to(dev), (torch.rand(128, generator=g) * 0.4).to(dev)
+    pw = hip.pack_weight(GEMM_CONV, wt)
+    cat = torch.cat([a, bfull[..., :192]], -1).contiguous()
+    y0 = torch.empty(N, H // 2, W // 2, 128, device=dev)
+    hip.conv(cat, pw, y0, 2, 1, 1, bias, slope)
+    pa = hip_ops.Planes.alloc(N * H * W, 128, dev)                   # feat1 lives in channels 64..127 of its buffer
+    hip.split_planes(torch.cat([torch.zeros_like(a), a], -1).flatten(0, 2), pa)
+    pb = hip_ops.Planes.alloc(N * H * W, 197, dev)
+    hip.split_planes(bfull[..., :197].flatten(0, 2), pb)
+    y1 = torch.empty_like(y0)
+    hip.conv_planes(pa, N, H, W, pw, out=y1, stride=2, pad=1, dil=1, bias=bias, prelu=slope, in_chunk0=2, x2=pb, split_chunks=2)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1), maxdiff(y0, y1)
