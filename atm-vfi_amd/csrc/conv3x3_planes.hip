@@ -252,7 +252,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
         constexpr int T = decltype(tc)::value;
         constexpr bool TAIL = decltype(tailc)::value;
         // ---------------- read phase ----------------
-        if constexpr (!TAIL) {
+        if (PDBG(16)) {
+            // (diagnostic: no fragment reads at all -- prices what the partner's LDS traffic costs the MFMA phase)
+        } else if constexpr (!TAIL) {
             constexpr int C0 = (T / 3) * HW_ + T % 3, C1 = C0 + HW_;       // tap offsets of the wave's two pixel rows
             lds_read16<64 * C0>(xh[0], xa[C0 & 7]);
             lds_read16<64 * C0 + HALO_LO>(xl[0], xa[C0 & 7]);
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
             }
         }
         const unsigned wa = wfrag + (unsigned)rd_off;
-        static_for<0, WN>([&](auto jc) {
+        if (!PDBG(16)) static_for<0, WN>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             lds_read16<j * 1024>(wh[j], wa);
             lds_read16<j * 1024 + BN * 64>(wl[j], wa);
@@ -363,10 +365,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             f32x4 v = acc[i][j] + cor[i][j] * LO_UNSCALE + bv;
-            v.x = v.x > 0.f ? v.x : pv.x * v.x;
-            v.y = v.y > 0.f ? v.y : pv.y * v.y;
-            v.z = v.z > 0.f ? v.z : pv.z * v.z;
-            v.w = v.w > 0.f ? v.w : pv.w * v.w;
+            if (a.prelu) {                 // (uniform: the epilogue is VALU-bound, ~45 instructions per 4 values with both activations)
+                v.x = v.x > 0.f ? v.x : pv.x * v.x;
+                v.y = v.y > 0.f ? v.y : pv.y * v.y;
+                v.z = v.z > 0.f ? v.z : pv.z * v.z;
+                v.w = v.w > 0.f ? v.w : pv.w * v.w;
+            }
             vv[i][j] = v;
         }
     }
@@ -411,10 +415,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 f32x4 u0 = vv[i][j0], u1 = vv[i][j1];
-                u0.x = u0.x > 0.f ? u0.x : s0.x * u0.x;  u0.y = u0.y > 0.f ? u0.y : s0.y * u0.y;
-                u0.z = u0.z > 0.f ? u0.z : s0.z * u0.z;  u0.w = u0.w > 0.f ? u0.w : s0.w * u0.w;
-                u1.x = u1.x > 0.f ? u1.x : s1.x * u1.x;  u1.y = u1.y > 0.f ? u1.y : s1.y * u1.y;
-                u1.z = u1.z > 0.f ? u1.z : s1.z * u1.z;  u1.w = u1.w > 0.f ? u1.w : s1.w * u1.w;
+                if (a.plane_prelu) {
+                    u0.x = u0.x > 0.f ? u0.x : s0.x * u0.x;  u0.y = u0.y > 0.f ? u0.y : s0.y * u0.y;
+                    u0.z = u0.z > 0.f ? u0.z : s0.z * u0.z;  u0.w = u0.w > 0.f ? u0.w : s0.w * u0.w;
+                    u1.x = u1.x > 0.f ? u1.x : s1.x * u1.x;  u1.y = u1.y > 0.f ? u1.y : s1.y * u1.y;
+                    u1.z = u1.z > 0.f ? u1.z : s1.z * u1.z;  u1.w = u1.w > 0.f ? u1.w : s1.w * u1.w;
+                }
                 f16x2 h00, l00, h01, l01, h10, l10, h11, l11;
                 split_pair((f32x2){u0.x, u0.y}, h00, l00);
                 split_pair((f32x2){u0.z, u0.w}, h01, l01);

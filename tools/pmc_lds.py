@@ -9,7 +9,7 @@ for d in sys.argv[1:]:
         for r in csv.DictReader(open(f)):
             tot[short(r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"])
 names = sorted({c for v in tot.values() for c in v})
-for k, v in sorted(tot.items(), key=lambda kv: -sum(kv[1].values()))[:4]:
+for k, v in sorted(tot.items(), key=lambda kv: -sum(kv[1].values()))[:int(os.environ.get('PMC_TOP', '24'))]:
     print(k)
     for n in names:
         print(f"    {n:32s} {v.get(n, 0):14.5g}")
