@@ -305,6 +305,22 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
         PSTAMP(5)
         // ---------------- MFMA phase ----------------
         if (!PDBG(8)) __builtin_amdgcn_s_setprio(1);
+#ifdef ATMVFI_ASM_MFMA
+        // Experiment (not the product): MFMAs as inline asm with the accumulator tied in place (hipcc renames the accumulators
+        // through dead fragment registers).  Same-box A/B of two product builds on nine layer shapes: no difference (1.059 vs
+        // 1.057 ms on the 101-wide layer); and the compiler cannot see an asm MFMA's result latency.  The builtin stays.
+#define MF(accv, av, bv) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(accv) : "v"(av), "v"(bv))
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            MF(cor[0][j], wl[j], xh[0]);
+            MF(cor[1][j], wl[j], xh[1]);
+            MF(acc[0][j], wh[j], xh[0]);
+            MF(acc[1][j], wh[j], xh[1]);
+            MF(cor[0][j], wh[j], xl[0]);
+            MF(cor[1][j], wh[j], xl[1]);
+        }
+#undef MF
+#else
         static_for<0, WN>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             cor[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j], xh[0], cor[0][j], 0, 0, 0);
@@ -314,6 +330,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
             cor[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xl[0], cor[0][j], 0, 0, 0);
             cor[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xl[1], cor[1][j], 0, 0, 0);
         });
+#endif
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         PSTAMP(6)
