@@ -695,11 +695,18 @@ class Network(BlockRunner, nn.Module):
             P = self._prepare(ops)
             h, w = H // 8, W // 8
             # image pyramids (network_base.py:444-448)
+            # Levels >= 1 of both frames live stacked along the batch axis ([:b] = frame 0, [b:] = frame 1): one launch per level
+            # instead of two (the same kernels on 2b images); level 0 are the caller's two tensors.
             pyr0, pyr1 = [im0], [im1]
+            pyr_st = [None]
             for l in range(1, 4):
-                t0 = self.buf(f"pyr0_{l}", b, 3, H >> l, W >> l); ops.resize(pyr0[-1], t0)
-                t1 = self.buf(f"pyr1_{l}", b, 3, H >> l, W >> l); ops.resize(pyr1[-1], t1)
-                pyr0.append(t0); pyr1.append(t1)
+                t = self.buf(f"pyr_{l}", 2 * b, 3, H >> l, W >> l)
+                if l == 1:
+                    ops.resize(im0, t[:b]); ops.resize(im1, t[b:])
+                else:
+                    ops.resize(pyr_st[-1], t)
+                pyr_st.append(t)
+                pyr0.append(t[:b]); pyr1.append(t[b:])
             # encoder + local fusion (:451-455)
             x0 = self.buf("x0", 2 * b, H, W, 4); ops.pack_frames(im0, im1, x0)
             cache_ok = self._frame_cache_on and not self.global_motion
@@ -730,28 +737,28 @@ class Network(BlockRunner, nn.Module):
                     g0, g1 = self._ensemble_flows(ops, P, im0, im1)
                 else:
                     gout = self._global_motion(ops, P, e2, fuse_l, b, "")
-                    i0_16 = self.buf("im0_16", b, 3, h_, w_); ops.resize(pyr0[3], i0_16)
-                    i1_16 = self.buf("im1_16", b, 3, h_, w_); ops.resize(pyr1[3], i1_16)
+                    i_16 = self.buf("im_16", 2 * b, 3, h_, w_); ops.resize(pyr_st[3], i_16)
                     a, c, t = (ops.empty(b, 3, h_, w_) for _ in range(3))
-                    ops.warp_blend(i0_16, i1_16, gout[..., :5], a, c, t)
+                    ops.warp_blend(i_16[:b], i_16[b:], gout[..., :5], a, c, t)
                     w0_list.insert(0, a); w1_list.insert(0, c); it_list.insert(0, t)
                     g0 = gout[..., 0:2].permute(0, 3, 1, 2)
                     g1 = gout[..., 2:4].permute(0, 3, 1, 2)
-                gf0 = self.buf("gf0_3", b, 2, h, w); ops.resize(g0, gf0, 2.0)
-                gf1 = self.buf("gf1_3", b, 2, h, w); ops.resize(g1, gf1, 2.0)
+                # the two global flows stacked like the frames: every warp / x2 up-sampling below is one launch for both
+                gf = self.buf("gf_3", 2 * b, 2, h, w)
+                ops.resize(g0, gf[:b], 2.0); ops.resize(g1, gf[b:], 2.0)
                 featw = self.buf("featw", 2 * b, h, w, C)
-                f4 = feat.reshape(2 * b, h, w, C)
-                ops.flow_warp_nhwc(f4[:b], gf0, featw[:b])
-                ops.flow_warp_nhwc(f4[b:], gf1, featw[b:])
+                ops.flow_warp_nhwc(feat.reshape(2 * b, h, w, C), gf, featw)
                 x_tokens = featw.reshape(2 * b * h * w, C)
                 for i in (3, 2, 1, 0):
-                    n0 = self.buf(f"pw0_{i}", b, 3, H >> i, W >> i); ops.flow_warp(pyr0[i], gf0, n0)
-                    n1 = self.buf(f"pw1_{i}", b, 3, H >> i, W >> i); ops.flow_warp(pyr1[i], gf1, n1)
-                    pyr0[i], pyr1[i] = n0, n1
+                    nw = self.buf(f"pw_{i}", 2 * b, 3, H >> i, W >> i)
                     if i:
-                        u0 = self.buf(f"gf0_{i - 1}", b, 2, H >> (i - 1), W >> (i - 1)); ops.resize(gf0, u0, 2.0)
-                        u1 = self.buf(f"gf1_{i - 1}", b, 2, H >> (i - 1), W >> (i - 1)); ops.resize(gf1, u1, 2.0)
-                        gf0, gf1 = u0, u1
+                        ops.flow_warp(pyr_st[i], gf, nw)
+                    else:
+                        ops.flow_warp(im0, gf[:b], nw[:b]); ops.flow_warp(im1, gf[b:], nw[b:])
+                    pyr0[i], pyr1[i] = nw[:b], nw[b:]
+                    if i:
+                        u = self.buf(f"gf_{i - 1}", 2 * b, 2, H >> (i - 1), W >> (i - 1)); ops.resize(gf, u, 2.0)
+                        gf = u
             # local motion (:490) -> raw motion map goes straight into the decoder input
             cdec = 2 * C + S.MOTION_OUT
             dec_in = self.buf("dec_in", b, h, w, _r4(cdec))
