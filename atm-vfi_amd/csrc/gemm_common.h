@@ -92,6 +92,30 @@ __device__ __forceinline__ bool gemm_out_row(const GemmDev& a, long long m, floa
     rrow = a.residual ? a.residual + m * (long long)a.res_ld : nullptr;
     return true;
 }
+// The same with the row-map entry already fetched (`ro`: mapped row, or m when there is no map; >= 0): lets a kernel batch the map
+// loads of several rows and rebuild the pointers only when it stores (gemm_split.hip's epilogue keeps one int per row).
+__device__ __forceinline__ void gemm_out_row_at(const GemmDev& a, long long m, long long ro, float*& orow, long long& prow, int& pc0) {
+    pc0 = a.out_c0;
+    if (a.mode == ATMVFI_GEMM_DECONV) {
+        const int hw = a.H * a.W;
+        const int n = (m >> 31) ? (int)(m / hw) : (int)((unsigned)m / (unsigned)hw);
+        const int rem = (int)(m - (long long)n * hw);
+        const int y = rem / a.W;
+        const int x = rem - y * a.W;
+        prow = ((long long)n * a.Ho + 2 * y) * a.Wo + 2 * x;
+        orow = a.out + prow * a.out_ld;
+    } else {
+        prow = ro;
+        long long off = ro * (long long)a.out_ld;
+        if (a.out_rpg > 0) {
+            const long long grp = ro / a.out_rpg;
+            prow = ro - grp * a.out_rpg;
+            off = grp * a.out_gstride + prow * (long long)a.out_ld;
+            pc0 += (int)grp * a.out_gc;
+        }
+        orow = a.out + off;
+    }
+}
 __device__ __forceinline__ bool gemm_out_row(const GemmDev& a, long long m, float*& orow, const float*& rrow) {
     long long prow;
     int pc0;
@@ -243,5 +267,7 @@ int launch_gemm_f16x3(const GemmDev& d, int ngemm, hipStream_t stream);
 bool try_launch_conv3x3_small(const GemmDev& d, int kh, int* rc, hipStream_t stream);
 // gemm_split.hip (LINEAR rows read from fp16 hi/lo planes by LDS-DMA)
 int launch_gemm_split(const GemmDev& d, int ngemm, hipStream_t stream);
+// gemm_pp.hip (the same for LINEAR / DECONV rows, ping-pong wave groups)
+int launch_gemm_pp(const GemmDev& d, int ngemm, hipStream_t stream);
 
 }  // namespace atmvfi

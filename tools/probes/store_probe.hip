@@ -22,6 +22,11 @@ __global__ __launch_bounds__(512) void probe(float* out, int ld, int tiles, unsi
                 p = base + (long long)(16 * i + r) * ld + 16 * j + 4 * g;
             } else if (PAT == 1) {   // 2 rows x 512 B per instruction: row 2k + (lane>>5), columns 4*(lane&31)
                 p = base + (long long)(2 * k + (lane >> 5)) * ld + 4 * (lane & 31);
+            } else if (PAT == 3) {   // 8 rows x 128 B per instruction: k = (i, jp): row 16i + 8h + (r & 7), columns 32jp + 16(r >> 3) + 4g  (i < 2, jp < 4, h < 2)
+                const int i = k >> 3, jp = (k >> 1) & 3, h = k & 1;
+                p = base + (long long)(16 * i + 8 * h + (r & 7)) * ld + 32 * jp + 16 * (r >> 3) + 4 * g;
+            } else if (PAT == 4) {   // 4 rows x 256 B per instruction: row 4k + (lane >> 4), columns 4 * (lane & 15) + 64 * (k >> 3)  (two column halves)
+                p = base + (long long)(4 * (k & 7) + (lane >> 4)) * ld + 4 * (lane & 15) + 64 * (k >> 3);
             } else {                 // fully contiguous 1 KiB per instruction (ld ignored)
                 p = out + ((long long)(blockIdx.x * tiles + t) * 256 * 128) + (wave * 16 + k) * 256 + lane * 4;
             }
@@ -38,13 +43,15 @@ int main() {
     const size_t n = (size_t)256 * tiles * 256 * ld;
     hipMalloc(&out, n * 4); hipMalloc(&cyc, 256 * 8 * 8);
     for (int nwg : {256, 64, 16})
-    for (int pat = 0; pat < 3; ++pat) {
+    for (int pat = 0; pat < 5; ++pat) {
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         float ms = 0;
         for (int rep = 0; rep < 3; ++rep) {
             hipEventRecord(e0);
             if (pat == 0) hipLaunchKernelGGL(probe<0>, dim3(nwg), dim3(512), 0, 0, out, ld, tiles, cyc);
             if (pat == 1) hipLaunchKernelGGL(probe<1>, dim3(nwg), dim3(512), 0, 0, out, ld, tiles, cyc);
+            if (pat == 3) hipLaunchKernelGGL(probe<3>, dim3(nwg), dim3(512), 0, 0, out, ld, tiles, cyc);
+            if (pat == 4) hipLaunchKernelGGL(probe<4>, dim3(nwg), dim3(512), 0, 0, out, ld, tiles, cyc);
             if (pat == 2) hipLaunchKernelGGL(probe<2>, dim3(nwg), dim3(512), 0, 0, out, ld, tiles, cyc);
             hipEventRecord(e1); hipEventSynchronize(e1);
             hipEventElapsedTime(&ms, e0, e1);
@@ -52,7 +59,7 @@ int main() {
         unsigned long long h[2048]; hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
         double mean = 0; for (int i = 0; i < nwg * 8; ++i) mean += h[i]; mean /= nwg * 8;
         const double bytes = (double)nwg * tiles * 256 * 128 * 4;
-        printf("%3d workgroups, pattern %d: %.3f ms, %.2f TB/s, %.0f ticks per tile per wave (issue), %.1f B/tick/CU\n", pat, nwg, pat, ms, bytes / ms / 1e9, mean / tiles,
+        printf("%3d workgroups, pattern %d: %.3f ms, %.2f TB/s, %.0f ticks per tile per wave (issue), %.1f B/tick/CU\n", nwg, pat, ms, bytes / ms / 1e9, mean / tiles,
                256.0 * 128 * 4 / (mean / tiles));
     }
     return 0;

@@ -18,8 +18,8 @@ for m, n, k in [(65280, 1536, 384), (65280, 384, 1536), (16320, 2688, 672)]:
     ops.split_planes(x, pl)
     nblk = ((m + 255) // 256 + 7) // 8 * 8 * ((n + 127) // 128)
     buf = torch.zeros(nblk * 8 * 8, dtype=torch.int64, device=dev)
-    ops.lib.atmvfi_debug_set_split_stamp_buffer.argtypes = [ctypes.c_void_p]
-    ops.lib.atmvfi_debug_set_split_stamp_buffer(ctypes.c_void_p(buf.data_ptr()))
+    ops.lib.atmvfi_debug_set_pp_stamp_buffer.argtypes = [ctypes.c_void_p]
+    ops.lib.atmvfi_debug_set_pp_stamp_buffer(ctypes.c_void_p(buf.data_ptr()))
     for _ in range(200):           # keep the chip loaded so the clock settles
         ops.linear(pl, pw, y)
     torch.cuda.synchronize()
