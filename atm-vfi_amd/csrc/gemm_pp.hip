@@ -61,38 +61,57 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmDev a) {
     const int g = lane >> 4;
     const int wm = wave >> 1, wn = wave & 1;
 
-    // XCD-aware tile order: blocks b and b+8 share an XCD, so the column blocks of one row tile go to one L2
-    const int xcd = blockIdx.x & 7;
-    const int slot = blockIdx.x >> 3;
-    const int mgrp = slot / a.nblocks;
-    const int nblk = slot - mgrp * a.nblocks;
-    const long long m0 = ((long long)mgrp * 8 + xcd) * BM;
-    if (m0 >= a.M) return;
-    const int n0 = nblk * BN;
-    float* cst = reinterpret_cast<float*>(smem + 3 * STAGE);
+    // PERSISTENT GRID over an XCD-aware tile order.  Virtual block v: xcd = v & 7, slot = v >> 3, row tile = (slot / nblocks) * 8 + xcd,
+    // column block = slot % nblocks (blocks v and v+8 share an XCD, so the column blocks of one row tile go to one L2).  Workgroup b
+    // walks v = b, b + grid, ... (grid a multiple of 8: it stays on its XCD) and the DMA ring KEEPS FLOWING ACROSS TILES: the last two
+    // k-steps of a tile put stages 0 and 1 of the workgroup's next tile in flight, so a tile's first DMA round trip (7-8 k cycles of
+    // a 42 k-cycle K = 384 tile, tools/stamp_split.py) runs under the previous tile's last k-steps and epilogue.
+    // (The launcher makes the grid persistent only for nk >= 2: the look-ahead of two stages then spans one tile boundary at most.)
+    const int grid = gridDim.x;
+    auto tile_of = [&](int v, int& tm0, int& tn0) {
+        const int xcd = v & 7;
+        const int slot = v >> 3;
+        const int mgrp = slot / a.nblocks;
+        const int nblk = slot - mgrp * a.nblocks;
+        tm0 = (mgrp * 8 + xcd) * BM;
+        tn0 = nblk * BN;
+    };
+    const int M = (int)a.M;                    // rows < 2^26 (launcher): 32-bit row arithmetic throughout
+    int vb = blockIdx.x;
+    int m0;
+    int n0;
+    tile_of(vb, m0, n0);
+    if (m0 >= M) return;
+    float* cst_base = reinterpret_cast<float*>(smem + 3 * STAGE);       // two buffers of per-tile constants
 
     // ---- DMA pieces of this wave.  A: rows (i * 8 + wave) * 16 + lane / 4 (i = 0, 1) of the hi and of the lo plane; W: rows
     // wave * 16 + lane / 4 of both planes.  The LDS image of a piece is wave-uniform base + lane * 16 B; the 16-byte slot swizzle
     // goes on the SOURCE address.  Per lane: three 32-bit byte offsets from wave-uniform plane pointers that advance by one
-    // 32-channel chunk (A: in_ld rows, W: wrows rows) per k-step.
+    // 32-channel chunk (A: in_ld rows, W: wrows rows) per k-step.  They belong to the ISSUER's tile: the tile whose stages are being
+    // put in flight -- the tile of the MFMAs or, in its last two k-steps, the next one.
     const unsigned ls16 = (unsigned)(((lane & 3) ^ swz64(lane >> 2)) << 4);       // swz64(16 k + row) == swz64(row)
     unsigned aoff[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        long long m = m0 + (i * 8 + wave) * 16 + (lane >> 2);
-        if (m >= a.M) m = a.M - 1;                                  // tail rows: valid address, result never stored
-        aoff[i] = (unsigned)m * 64u + ls16;
-    }
     unsigned wsoff;
-    {
-        int n = n0 + wave * 16 + (lane >> 2);
+    const unsigned char* pa_hi;
+    const unsigned char* pa_lo;
+    const unsigned char* pw_hi;
+    const unsigned char* pw_lo;
+    auto setup_issue = [&](int tm0, int tn0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int m = tm0 + (i * 8 + wave) * 16 + (lane >> 2);
+            if (m >= M) m = M - 1;                                  // tail rows: valid address, result never stored
+            aoff[i] = (unsigned)m * 64u + ls16;
+        }
+        int n = tn0 + wave * 16 + (lane >> 2);
         if (n >= a.wrows) n = a.wrows - 1;                          // columns past the packed rows: never stored
         wsoff = (unsigned)n * 64u + ls16;
-    }
-    const unsigned char* pa_hi = reinterpret_cast<const unsigned char*>(a.a_hi);
-    const unsigned char* pa_lo = reinterpret_cast<const unsigned char*>(a.a_lo);
-    const unsigned char* pw_hi = reinterpret_cast<const unsigned char*>(a.w_hi);
-    const unsigned char* pw_lo = reinterpret_cast<const unsigned char*>(a.w_lo);
+        pa_hi = reinterpret_cast<const unsigned char*>(a.a_hi);
+        pa_lo = reinterpret_cast<const unsigned char*>(a.a_lo);
+        pw_hi = reinterpret_cast<const unsigned char*>(a.w_hi);
+        pw_lo = reinterpret_cast<const unsigned char*>(a.w_lo);
+    };
+    setup_issue(m0, n0);
     const long long a_step = (long long)a.in_ld * 64, w_step = (long long)a.wrows * 64;
     int wr_off = 0;                                                 // stage buffer (byte offset) the next issue goes to
     auto issue_stage = [&]() {
@@ -109,30 +128,32 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmDev a) {
         pw_lo += w_step;
         wr_off = wr_off == 2 * STAGE ? 0 : wr_off + STAGE;
     };
+    // Per-tile constants by LDS-DMA, two pieces per wave: bias / slope of the column block, and the tile's BM row-map entries (LINEAR
+    // with an out_row_map: the window-reverse scatter of proj; a global load of the map in the epilogue would cost a memory latency
+    // per tile).  Without a map the second piece repeats the first (same bytes, same place): the counted waits stay uniform.
+    auto dma_tile_consts = [&](int tm0, int tn0, float* dst) {
+        atmvfi::gemm_dma_consts<BN>(a, tn0, dst, wave, lane);
+        if (a.out_row_map && a.mode == ATMVFI_GEMM_LINEAR) {
+            int m = tm0 + (wave & 3) * 64 + lane;
+            if (m >= M) m = M - 1;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.out_row_map + m),
+                                             (__attribute__((address_space(3))) void*)(dst + atmvfi::gemm_const_floats(BN) + (wave & 3) * 64), 4, 0, 0);
+        } else {
+            atmvfi::gemm_dma_consts<BN>(a, tn0, dst, wave, lane);
+        }
+    };
 
     f32x4 acc[4][4], cor[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            cor[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
 
 #ifdef ATMVFI_STAMP
     unsigned long long tstamp[4], rstamp[4];
+    unsigned long long t_loop = 0, t_epi = 0, r_loop = 0, r_epi = 0, t_pro = 0, r_pro = 0;
+    int ntile = 0;
 #endif
     PP_STAMP(0);
     const int nk = a.nchunks32;
-    // ---- prologue: per-tile constants (bias / slope of the column block, and the tile's row-map entries: a global load of the map
-    // in the epilogue would cost a memory latency per tile), stages 0 and 1
-    atmvfi::gemm_dma_consts<BN>(a, n0, cst, wave, lane);
-    if (a.out_row_map && a.mode == ATMVFI_GEMM_LINEAR) {
-        long long m = m0 + (wave & 3) * 64 + lane;
-        if (m >= a.M) m = a.M - 1;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.out_row_map + m),
-                                         (__attribute__((address_space(3))) void*)(cst + atmvfi::gemm_const_floats(BN) + (wave & 3) * 64), 4, 0, 0);
-    }
+    // ---- prologue of the first tile: constants, stages 0 and 1
+    dma_tile_consts(m0, n0, cst_base);
     issue_stage();
     if (nk > 1) {
         issue_stage();
@@ -142,18 +163,24 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmDev a) {
     }
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();          // the second group runs one phase behind
-    PP_STAMP(1);
 
     f16x8 xh[4], xl[4], wh[4], wl[4];
     const unsigned xfrag = lds_offset(smem) + (unsigned)((64 * wm + r) * 64 + ((g ^ swz64(r)) << 4));
     const unsigned wfrag = lds_offset(smem) + (unsigned)(W_HI + (64 * wn + r) * 64 + ((g ^ swz64(r)) << 4));
     int rd_off = 0;                                      // stage buffer (byte offset) of the k-step being read
+    int seq = 0;                                         // tiles done by this workgroup
+    // this workgroup's next tile (row tiles only grow along a workgroup's walk: the first empty one ends it)
+    int nm0 = 0;
+    int nn0 = 0;
+    bool has_next = false;
 
-    // One k-step of one wave.  ISSUE: put the stage two k-steps ahead in flight; WAIT: vmcnt to wait for before the next stage is
-    // read (-1: there is no next stage).
-    auto kstep = [&](auto issue_c, auto wait_c) {
-        constexpr bool ISSUE = decltype(issue_c)::value;
-        constexpr int WAIT = decltype(wait_c)::value;
+    // One k-step of one wave.  KIND 0: a k-step with two more k-steps of its tile behind it -- the stage two k-steps ahead goes out,
+    // six pieces stay in flight at the wait.  KIND 1: the tile's last k-step but one -- the ring moves on to the next tile (its
+    // constants and stage 0; eight pieces in flight), or nothing goes out (wait for everything).  KIND 2: the last k-step --
+    // stage 1 of the next tile, or nothing (and no wait: there is no next stage).  g1wait: false in the first k-step of a later
+    // tile for the second group, which waited before its epilogue (its stores would otherwise sit in front of the counted wait).
+    auto kstep = [&](auto kind_c, bool g1wait) {
+        constexpr int KIND = decltype(kind_c)::value;
         // ---------------- read phase ----------------
         const unsigned xa = xfrag + (unsigned)rd_off, wa = wfrag + (unsigned)rd_off;
         static_for<0, 4>([&](auto ic) {
@@ -167,10 +194,28 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmDev a) {
             lds_read16<j * 1024 + BN * 64>(wl[j], wa);
         });
         rd_off = rd_off == 2 * STAGE ? 0 : rd_off + STAGE;
-        if constexpr (ISSUE) issue_stage();
-        if constexpr (WAIT >= 0) {
-            if (grp == 1) wait_vm<WAIT>();
+        if constexpr (KIND == 0) {
+            issue_stage();
+        } else if constexpr (KIND == 1) {
+            if (has_next) {
+                setup_issue(nm0, nn0);
+                dma_tile_consts(nm0, nn0, cst_base + ((seq + 1) & 1) * CST_FLOATS);
+                issue_stage();
+            }
+        } else {
+            if (has_next) issue_stage();
         }
+        auto wait_next = [&]() {
+            if constexpr (KIND == 0) {
+                wait_vm<PIECES>();
+            } else if constexpr (KIND == 1) {
+                if (has_next) wait_vm<PIECES + 2>();
+                else wait_vm<0>();
+            } else {
+                if (has_next) wait_vm<PIECES>();
+            }
+        };
+        if (grp == 1 && g1wait) wait_next();
         asm volatile("s_waitcnt lgkmcnt(0)"
                      : "+v"(xh[0]), "+v"(xh[1]), "+v"(xh[2]), "+v"(xh[3]), "+v"(xl[0]), "+v"(xl[1]), "+v"(xl[2]), "+v"(xl[3]));
 #pragma unroll
@@ -192,18 +237,47 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmDev a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) cor[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xl[i], cor[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
-        if constexpr (WAIT >= 0) {
-            if (grp == 0) wait_vm<WAIT>();
-        }
+        if (grp == 0) wait_next();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     };
-    for (int kc = 0; kc + 2 < nk; ++kc) kstep(std::true_type{}, std::integral_constant<int, PIECES>{});
-    if (nk >= 2) kstep(std::false_type{}, std::integral_constant<int, 0>{});
-    kstep(std::false_type{}, std::integral_constant<int, -1>{});
-    if (grp == 0) __builtin_amdgcn_s_barrier();          // same number of barriers for both groups
-    PP_STAMP(2);
+
+    for (;;) {
+        const int nxt = vb + grid;
+        has_next = false;
+        if (nxt < a.vblocks) {
+            tile_of(nxt, nm0, nn0);
+            has_next = nm0 < M;
+        }
+        const float* cst = cst_base + (seq & 1) * CST_FLOATS;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                cor[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                // pinned: hipcc otherwise folds the zeros into the first MFMAs' C operand and uses the (then dead) accumulator
+                // registers as temporaries of the first read phase, guarded by s_waitcnt vmcnt(0)
+                asm volatile("" : "+v"(acc[i][j]), "+v"(cor[i][j]));
+            }
+        PP_STAMP(1);
+        {
+            bool g1wait = seq == 0;
+            for (int kc = 0; kc + 2 < nk; ++kc) {
+                kstep(std::integral_constant<int, 0>{}, g1wait);
+                g1wait = true;
+            }
+            if (nk >= 2) {
+                kstep(std::integral_constant<int, 1>{}, g1wait);
+                g1wait = true;
+            }
+            kstep(std::integral_constant<int, 2>{}, g1wait);
+        }
+        PP_STAMP(2);
+        // The second group's pieces of the next tile's stage 1 (all that is in flight) are waited for HERE, before its stores join
+        // the queue; its first k-step of the next tile then skips the counted wait (g1wait).
+        if (grp == 1 && has_next) wait_vm<0>();
 
     // ---- epilogue.  Lane (r, g) holds, of its 16 MFMA tiles (i, j), GEMM row 64 wm + 16 i + r and columns 64 wn + 16 j + 4 g .. + 3.
     // Correction accumulators folded in first (their registers then hold the residual batch); the row-map entries come from LDS;
@@ -221,11 +295,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmDev a) {
     int ro[4];                 // output row of each group's row: the row map's entry or (unmapped) 0; < 0: nothing to store
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const long long m = m0 + 64 * wm + 16 * i + r;
-        ro[i] = m < a.M ? 0 : -1;
+        const int m = m0 + 64 * wm + 16 * i + r;
+        ro[i] = m < M ? 0 : -1;
         if (mapped) {
             const int e = reinterpret_cast<const int*>(cst + atmvfi::gemm_const_floats(BN))[64 * wm + 16 * i + r];
-            ro[i] = m < a.M ? e : -1;
+            ro[i] = m < M ? e : -1;
         }
 #ifdef ATMVFI_ABLATE
         if ((a.dbg & 1) && acc[i][0].x != 12345.678f) ro[i] = -1;
@@ -240,7 +314,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmDev a) {
     if (vec_res) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const long long m = m0 + 64 * wm + 16 * i + r;
+            const int m = m0 + 64 * wm + 16 * i + r;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int nb = n0 + 64 * wn + 16 * j + 4 * g;
@@ -260,7 +334,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmDev a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (ro[i] >= 0) {
-                const long long m = m0 + 64 * wm + 16 * i + r;
+                const int m = m0 + 64 * wm + 16 * i + r;
                 float* orow;
                 long long prow;
                 int pc0;
@@ -280,12 +354,32 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmDev a) {
     };
     if (a.residual && !vec_res) store_rows(std::true_type{});
     else store_rows(std::false_type{});
+        PP_STAMP(3);
 #ifdef ATMVFI_STAMP
-    PP_STAMP(3);
+        if (a.stamp) {
+            if (seq == 0) { t_pro = tstamp[1] - tstamp[0]; r_pro = rstamp[1] - rstamp[0]; }
+            t_loop += tstamp[2] - tstamp[1]; r_loop += rstamp[2] - rstamp[1];
+            t_epi += tstamp[3] - tstamp[2]; r_epi += rstamp[3] - rstamp[2];
+            ++ntile;
+        }
+#endif
+        // the barrier that closes the other group's current phase (the first group's epilogue ran beside the second group's last
+        // MFMA phase, the second group's beside the first k-step's read phase of the next tile); after the last tile only the
+        // first group still owes one
+        if (has_next || grp == 0) __builtin_amdgcn_s_barrier();
+        if (!has_next) break;
+        vb = nxt;
+        m0 = nm0;
+        n0 = nn0;
+        ++seq;
+    }
+#ifdef ATMVFI_STAMP
     if (a.stamp && lane == 0) {
         unsigned long long* o = a.stamp + ((long long)blockIdx.x * 8 + wave) * 8;
-        for (int k = 0; k < 3; ++k) { o[k] = tstamp[k + 1] - tstamp[k]; o[4 + k] = rstamp[k + 1] - rstamp[k]; }
+        o[0] = t_pro; o[1] = t_loop / ntile; o[2] = t_epi / ntile;
         o[3] = (unsigned long long)nk;
+        o[4] = r_pro; o[5] = r_loop / ntile; o[6] = r_epi / ntile;
+        o[7] = (unsigned long long)ntile;
     }
 #endif
 }
@@ -293,7 +387,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmDev a) {
 }  // namespace
 
 int atmvfi::launch_gemm_pp(const GemmDev& d, int ngemm, hipStream_t s) {
-    const size_t lds = (size_t)3 * STAGE + CST_FLOATS * sizeof(float);
+    const size_t lds = (size_t)3 * STAGE + 2 * CST_FLOATS * sizeof(float);
     const hipError_t attr_err = atmvfi::allow_dynamic_lds<gemm_pp_kernel>(lds);
     ATMVFI_REQUIRE(attr_err == hipSuccess, ATMVFI_ELAUNCH, "gemm_pp: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
     ATMVFI_REQUIRE((long long)d.in_ld * 64 < (1ll << 32) && (long long)d.wrows * 64 < (1ll << 32), ATMVFI_EINVAL,
@@ -306,6 +400,10 @@ int atmvfi::launch_gemm_pp(const GemmDev& d, int ngemm, hipStream_t s) {
     dd.nblocks = (ngemm + BN - 1) / BN;
     const long long mgroups = (atmvfi::ceil_div64(d.M, BM) + 7) / 8;
     ATMVFI_REQUIRE(mgroups * 8 * dd.nblocks < (1LL << 31), ATMVFI_EINVAL, "gemm_pp: grid too large");
-    hipLaunchKernelGGL(gemm_pp_kernel, dim3((unsigned)(mgroups * 8 * dd.nblocks)), dim3(512), lds, s, dd);
+    dd.vblocks = (int)(mgroups * 8 * dd.nblocks);
+    // persistent from two k-steps up (the ring's look-ahead of two stages then spans at most one tile boundary): one workgroup per
+    // CU (147 KiB of LDS) walking its XCD's tiles; K <= 32: one workgroup per tile
+    const int grid = d.nchunks32 >= 2 ? std::min(dd.vblocks, atmvfi::cu_count()) : dd.vblocks;
+    hipLaunchKernelGGL(gemm_pp_kernel, dim3((unsigned)grid), dim3(512), lds, s, dd);
     return atmvfi::check_launch("gemm_pp");
 }
