@@ -48,6 +48,13 @@ __device__ __forceinline__ void dma16(const unsigned char* src, unsigned char* l
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+__device__ __forceinline__ void lds_write16f(unsigned addr, const f32x4& v) {
+    asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read16f(f32x4& d, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -279,81 +286,221 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmDev a) {
         // the queue; its first k-step of the next tile then skips the counted wait (g1wait).
         if (grp == 1 && has_next) wait_vm<0>();
 
-    // ---- epilogue.  Lane (r, g) holds, of its 16 MFMA tiles (i, j), GEMM row 64 wm + 16 i + r and columns 64 wn + 16 j + 4 g .. + 3.
-    // Correction accumulators folded in first (their registers then hold the residual batch); the row-map entries come from LDS;
-    // (LINEAR with a residual whose width is a multiple of 4: every case of the network) ALL sixteen residual vectors in one batch
-    // of unconditional loads -- dead rows and columns read the residual's first vector -- so there is one wait per tile and it comes
-    // before the first store (vmcnt counts stores on gfx9: a wait per row group would drain the previous group's stores).
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            acc[i][j] = acc[i][j] + cor[i][j] * LO_UNSCALE;
-            asm volatile("" : "+v"(acc[i][j]));
-        }
-    const bool mapped = a.out_row_map && a.mode == ATMVFI_GEMM_LINEAR;
-    int ro[4];                 // output row of each group's row: the row map's entry or (unmapped) 0; < 0: nothing to store
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + 64 * wm + 16 * i + r;
-        ro[i] = m < M ? 0 : -1;
-        if (mapped) {
-            const int e = reinterpret_cast<const int*>(cst + atmvfi::gemm_const_floats(BN))[64 * wm + 16 * i + r];
-            ro[i] = m < M ? e : -1;
-        }
-#ifdef ATMVFI_ABLATE
-        if ((a.dbg & 1) && acc[i][0].x != 12345.678f) ro[i] = -1;
-#endif
-    }
-    const bool vec_res = a.residual && (a.Cout & 3) == 0 && a.mode != ATMVFI_GEMM_DECONV;
-    f32x4 res[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) res[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (vec_res) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + 64 * wm + 16 * i + r;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int nb = n0 + 64 * wn + 16 * j + 4 * g;
-                const float* p = (ro[i] >= 0 && nb < a.Cout) ? a.residual + m * (long long)a.res_ld + nb : a.residual;
-                res[i][j] = *reinterpret_cast<const f32x4*>(p);
-            }
-        }
+        // ---- epilogue.  After the k-loop lane (r, g) holds, of its 16 MFMA tiles (i, j), GEMM row 64 wm + 16 i + r and columns
+        // 64 wn + 16 j + 4 g .. + 3: a 16-byte store per lane in that layout touches 16 rows x 64 B per instruction, and the store
+        // path then takes 52 cycles per instruction where 256 contiguous bytes per 16 lanes take 15 (tools/probes/store_probe.hip:
+        // 19.6 against 67.5 B/clk/CU; 8 rows x 128 B is no better than 16 x 64 B) -- 8 k of a 42 k-cycle K = 384 tile.  So every
+        // 16-row slab i is TRANSPOSED THROUGH LDS, in place: four ds_write_b128 (lane (r, g): row r, 16-byte slot 4 j + g) and four
+        // ds_read_b128 (lane (r, g): row 4 q + g, slot r) leave lane (r, g) with GEMM rows 64 wm + 16 i + 4 q + g, q = 0..3, and
+        // columns 64 wn + 4 r .. + 3 -- the 16 lanes of a row cover 256 contiguous bytes, residual loads included.  The 4 KiB a wave
+        // needs are ITS OWN four A pieces of the stage buffer the last k-step was read from: nobody reads that buffer any more (this
+        // group's epilogue starts a barrier after the other group's last read), and the only DMA that can land there before this wave
+        // is done is the wave's own next issue.  Slot XOR-swizzle (physical slot = slot ^ row): conflict-free for the 8-lane
+        // groups of ds_write_b128 (banks mod 32) and the 16-lane groups of ds_read_b128 (MI355X_MICROARCH.md, LDS).
+        // Per-tile constants: bias / slope of the lane's four columns (two LDS reads per tile instead of two per vector); row-map
+        // entries from LDS; (LINEAR with a residual whose width is a multiple of 4: every case of the network) all sixteen
+        // residual vectors in one batch of unconditional loads before the first store (one wait per tile; vmcnt counts stores on
+        // gfx9, so a wait per row would drain the previous row's stores).
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(res[i][j]));
-    }
-    // (two copies of the store loop under a uniform branch: with the ragged-width residual loads as a conditional inside one loop,
-    // hipcc puts their s_waitcnt vmcnt(0) into the shared block, i.e. in front of every store group of the common case too)
-    auto store_rows = [&](auto ragged_tag) {
-        constexpr bool RAGGED = decltype(ragged_tag)::value;
+            for (int j = 0; j < 4; ++j) {
+                acc[i][j] = acc[i][j] + cor[i][j] * LO_UNSCALE;
+                asm volatile("" : "+v"(acc[i][j]));
+            }
+        {
+            const unsigned xb = (unsigned)(rd_off == 0 ? 2 * STAGE : rd_off - STAGE);          // buffer of the last k-step
+            const unsigned tb = lds_offset(smem) + xb + (unsigned)(wave * 1024);
+            const unsigned wbase = tb + (unsigned)((r >> 2) * 8192 + (r & 3) * 256 + ((g ^ (r & 3)) << 4));
+            const unsigned rq6 = (unsigned)((r >> 2) << 6);
+            const unsigned rbase = tb + (unsigned)(g * 256);
+            const unsigned rg4 = (unsigned)((r ^ g) << 4);
+            unsigned wad[4], rad[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (ro[i] >= 0) {
-                const int m = m0 + 64 * wm + 16 * i + r;
-                float* orow;
-                long long prow;
-                int pc0;
-                atmvfi::gemm_out_row_at(a, m, mapped ? (long long)ro[i] : m, orow, prow, pc0);
+            for (int k = 0; k < 4; ++k) {
+                wad[k] = wbase + (rq6 ^ (unsigned)(k << 6));                    // slot (4 j + g) ^ r of row r
+                rad[k] = rbase + (rg4 ^ (unsigned)(k << 6));                    // slot r ^ (4 q + g) of row 4 q + g (+ q * 8192 below)
+            }
+            static_for<0, 4>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                static_for<0, 4>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    lds_write16f(wad[j], acc[i][j]);
+                });
+                static_for<0, 4>([&](auto qc) {
+                    constexpr int q = decltype(qc)::value;
+                    lds_read16f<q * 8192>(acc[i][q], rad[q]);
+                });
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int cl = 64 * wn + 16 * j + 4 * g;
-                    const atmvfi::ChanPos cp = atmvfi::gemm_chan_pos(a, n0 + cl);
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(cst + cl);
-                    const f32x4 p = *reinterpret_cast<const f32x4*>(cst + BN + cl);
-                    f32x4 rv = res[i][j];
-                    if constexpr (RAGGED) rv = atmvfi::gemm_load_residual4(a.residual + m * (long long)a.res_ld, cp);
-                    atmvfi::gemm_finish_store4(a, orow, prow, pc0, cp, acc[i][j], b, p, rv);
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(acc[i][q]));
+        }
+        const bool mapped = a.out_row_map && a.mode == ATMVFI_GEMM_LINEAR;
+        const int cl = 64 * wn + 4 * r;                          // the lane's four columns inside the column block
+        const int nb = n0 + cl;
+        const atmvfi::ChanPos cp = atmvfi::gemm_chan_pos(a, nb);
+        const f32x4 bvec = *reinterpret_cast<const f32x4*>(cst + cl);
+        const f32x4 pvec = *reinterpret_cast<const f32x4*>(cst + BN + cl);
+        const int mrow = m0 + 64 * wm + g;                       // row of (i, q) = (0, 0); (i, q) adds 16 i + 4 q
+        int ro[4][4];              // output row: the row map's entry, or (unmapped) the row itself; < 0: nothing to store
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = mrow + 16 * i + 4 * q;
+                ro[i][q] = m < M ? m : -1;
+                if (mapped) {
+                    const int e = reinterpret_cast<const int*>(cst + atmvfi::gemm_const_floats(BN))[64 * wm + g + 16 * i + 4 * q];
+                    ro[i][q] = m < M ? e : -1;
                 }
             }
+        const bool vec_res = a.residual && (a.Cout & 3) == 0 && a.mode != ATMVFI_GEMM_DECONV;
+        f32x4 res[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) res[i][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (vec_res) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int m = mrow + 16 * i + 4 * q;
+                    const float* p = (ro[i][q] >= 0 && nb < a.Cout) ? a.residual + m * (long long)a.res_ld + nb : a.residual;
+                    res[i][q] = *reinterpret_cast<const f32x4*>(p);
+                }
+            // every vector is "used" here, dead rows' too: a load left pending on some path makes hipcc guard the next tile's first
+            // write to its register with s_waitcnt vmcnt(0), which would also wait for this tile's stores
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(res[i][q]));
         }
-    };
-    if (a.residual && !vec_res) store_rows(std::true_type{});
-    else store_rows(std::false_type{});
+        // DECONV: the lane's rows are 4 apart: (image, y, x) of the first one by division, the others by stepping
+        int dn = 0, dy = 0, dx = 0;
+        if (a.mode == ATMVFI_GEMM_DECONV) {
+            const int hw = a.H * a.W;
+            dn = (int)((unsigned)mrow / (unsigned)hw);
+            const int rem = mrow - dn * hw;
+            dy = rem / a.W;
+            dx = rem - dy * a.W;
+        }
+        // (two copies of the store loop under a uniform branch: with the ragged-width residual loads as a conditional inside one
+        // loop, hipcc puts their s_waitcnt vmcnt(0) into the shared block, i.e. in front of every store of the common case too)
+        auto store_rows = [&](auto ragged_tag) {
+            constexpr bool RAGGED = decltype(ragged_tag)::value;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int m = mrow + 16 * i + 4 * q;
+                    float* orow = nullptr;
+                    long long prow = 0;
+                    int pc0 = a.out_c0;
+                    if (a.mode == ATMVFI_GEMM_DECONV) {
+                        prow = ((long long)dn * a.Ho + 2 * dy) * a.Wo + 2 * dx;
+                        orow = a.out + prow * a.out_ld;
+                        dx += 4;                                  // next row of this lane
+                        while (dx >= a.W) { dx -= a.W; if (++dy == a.H) { dy = 0; ++dn; } }
+                    } else {
+                        const int rr = ro[i][q] < 0 ? 0 : ro[i][q];
+                        prow = rr;
+                        long long off = (long long)rr * a.out_ld;
+                        if (a.out_rpg > 0) {
+                            const int gi = (int)((unsigned)rr / (unsigned)a.out_rpg);
+                            prow = rr - gi * a.out_rpg;
+                            off = gi * a.out_gstride + prow * (long long)a.out_ld;
+                            pc0 += gi * a.out_gc;
+                        }
+                        orow = a.out + off;
+                    }
+                    if (ro[i][q] >= 0) {
+                        f32x4 rv = res[i][q];
+                        if constexpr (RAGGED) rv = atmvfi::gemm_load_residual4(a.residual + m * (long long)a.res_ld, cp);
+                        atmvfi::gemm_finish_store4(a, orow, prow, pc0, cp, acc[i][q], bvec, pvec, rv);
+                    }
+                }
+        };
+        // Fast variants for the network's three output shapes, chosen once per tile: inside them nothing is decided per row (the
+        // generic loop above spends ~10 scalar / exec branches per row on mode, groups, sinks and ragged widths: 11 k cycles per
+        // tile for 16 rows per lane).  All have full 4-channel vectors (Cout % 4 == 0, or DECONV whose position blocks are padded
+        // to 4) and do the arithmetic of gemm_finish_store4 in its order: + bias, PReLU (slope 1 when absent), + residual.
+        auto finish = [&](int i, int q) -> f32x4 {
+            f32x4 v = acc[i][q] + bvec;
+            v.x = v.x > 0.f ? v.x : pvec.x * v.x;
+            v.y = v.y > 0.f ? v.y : pvec.y * v.y;
+            v.z = v.z > 0.f ? v.z : pvec.z * v.z;
+            v.w = v.w > 0.f ? v.w : pvec.w * v.w;
+            return v + res[i][q];
+        };
+        const bool c4 = (a.Cout & 3) == 0;
+        if (a.mode == ATMVFI_GEMM_LINEAR && a.out && !a.out_hi && a.out_rpg == 0 && c4) {
+            // fp32 rows (qkv, fc1, proj with its row map and residual, fc2, fusion projections)
+            float* obase = a.out + nb;
+            const bool col_ok = nb < a.Cout;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = finish(i, q);
+                    if (ro[i][q] >= 0 && col_ok) *reinterpret_cast<f32x4*>(obase + (long long)ro[i][q] * a.out_ld) = v;
+                }
+        } else if (a.mode == ATMVFI_GEMM_LINEAR && a.out && a.out_hi && c4) {
+            // fp32 rows (optionally a grouped [G, R, C] view) + plane sink (the last fc2 of a motion branch)
+            const unsigned rpg = a.out_rpg > 0 ? (unsigned)a.out_rpg : 0x7fffffffu;
+            const RowSink sink{nullptr, 0, a.out_hi, a.out_lo, a.out_plane_rows};
+            const bool col_ok = nb < a.Cout;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = finish(i, q);
+                    const unsigned rr = ro[i][q] < 0 ? 0u : (unsigned)ro[i][q];
+                    const unsigned gi = rr / rpg;
+                    const long long prow = rr - gi * rpg;
+                    const long long off = gi * a.out_gstride + prow * (long long)a.out_ld;
+                    if (ro[i][q] >= 0 && col_ok) {
+                        *reinterpret_cast<f32x4*>(a.out + off + nb) = v;
+                        sink_store4(sink, prow, a.out_c0 + (int)gi * a.out_gc + nb, v);
+                    }
+                }
+        } else if (a.mode == ATMVFI_GEMM_DECONV && !a.out && a.out_hi && a.W >= 4 && !a.residual) {
+            // ConvTranspose2d 2x2 / stride 2 into a plane sink (decoder and U-Net stages): column -> (position, channel) is a lane
+            // constant; the lane's rows are 4 input pixels apart: (image, y, x) of the first by division, the others by stepping
+            const RowSink sink{nullptr, 0, a.out_hi, a.out_lo, a.out_plane_rows};
+            const int hw = a.H * a.W;
+            int dn = (int)((unsigned)mrow / (unsigned)hw);
+            const int rem = mrow - dn * hw;
+            int dy = rem / a.W;
+            int dx = rem - dy * a.W;
+            const int qoff = (cp.q >> 1) * a.Wo + (cp.q & 1);
+            const int pc = a.out_c0 + cp.co;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v = finish(i, q);
+                    v.y = cp.nvalid > 1 ? v.y : 0.f;            // channels past Cout inside the group of 4: the planes' pad channels
+                    v.z = cp.nvalid > 2 ? v.z : 0.f;
+                    v.w = cp.nvalid > 3 ? v.w : 0.f;
+                    const long long prow = ((long long)dn * a.Ho + 2 * dy) * a.Wo + 2 * dx + qoff;
+                    if (ro[i][q] >= 0 && cp.nvalid > 0) sink_store4(sink, prow, pc, v);
+                    dx += 4;                                      // next row of this lane (W >= 4: one wrap at most)
+                    const bool wrap = dx >= a.W;
+                    dx = wrap ? dx - a.W : dx;
+                    dy = wrap ? dy + 1 : dy;
+                    const bool wrap2 = dy >= a.H;
+                    dy = wrap2 ? 0 : dy;
+                    dn = wrap2 ? dn + 1 : dn;
+                }
+        } else if (a.residual && !vec_res) {
+            store_rows(std::true_type{});
+        } else {
+            store_rows(std::false_type{});
+        }
         PP_STAMP(3);
 #ifdef ATMVFI_STAMP
         if (a.stamp) {
