@@ -28,8 +28,10 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 static unsigned long long* g_pp_stamp = nullptr;
 extern "C" void atmvfi_debug_set_pp_stamp_buffer(void* p) { g_pp_stamp = (unsigned long long*)p; }
 #define PP_STAMP(i) do { if (a.stamp) { tstamp[i] = __builtin_amdgcn_s_memtime(); rstamp[i] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#define PP_SUB(k) do { if (a.stamp) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); sub[k] += t_ - sub_t; sub_t = t_; __builtin_amdgcn_sched_barrier(0); } } while (0)
 #else
 #define PP_STAMP(i) do { } while (0)
+#define PP_SUB(k) do { } while (0)
 #endif
 
 namespace {
@@ -156,6 +158,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmDev a) {
     unsigned long long tstamp[4], rstamp[4];
     unsigned long long t_loop = 0, t_epi = 0, r_loop = 0, r_epi = 0, t_pro = 0, r_pro = 0;
     int ntile = 0;
+    unsigned long long sub[3] = {0, 0, 0}, sub_t = 0;
 #endif
     PP_STAMP(0);
     const int nk = a.nchunks32;
@@ -282,6 +285,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmDev a) {
             kstep(std::integral_constant<int, 2>{}, g1wait);
         }
         PP_STAMP(2);
+#ifdef ATMVFI_STAMP
+        sub_t = __builtin_amdgcn_s_memtime();
+#endif
         // The second group's pieces of the next tile's stage 1 (all that is in flight) are waited for HERE, before its stores join
         // the queue; its first k-step of the next tile then skips the counted wait (g1wait).
         if (grp == 1 && has_next) wait_vm<0>();
@@ -338,6 +344,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmDev a) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(acc[i][q]));
         }
+        PP_SUB(0);
         const bool mapped = a.out_row_map && a.mode == ATMVFI_GEMM_LINEAR;
         const int cl = 64 * wn + 4 * r;                          // the lane's four columns inside the column block
         const int nb = n0 + cl;
@@ -424,83 +431,100 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmDev a) {
                     }
                 }
         };
+        PP_SUB(1);
         // Fast variants for the network's three output shapes, chosen once per tile: inside them nothing is decided per row (the
         // generic loop above spends ~10 scalar / exec branches per row on mode, groups, sinks and ragged widths: 11 k cycles per
         // tile for 16 rows per lane).  All have full 4-channel vectors (Cout % 4 == 0, or DECONV whose position blocks are padded
         // to 4) and do the arithmetic of gemm_finish_store4 in its order: + bias, PReLU (slope 1 when absent), + residual.
-        auto finish = [&](int i, int q) -> f32x4 {
-            f32x4 v = acc[i][q] + bvec;
-            v.x = v.x > 0.f ? v.x : pvec.x * v.x;
-            v.y = v.y > 0.f ? v.y : pvec.y * v.y;
-            v.z = v.z > 0.f ? v.z : pvec.z * v.z;
-            v.w = v.w > 0.f ? v.w : pvec.w * v.w;
-            return v + res[i][q];
+        // (the fast loops exist twice, with and without a PReLU: the select costs 14 of a row's ~30 VALU instructions, and the
+        // epilogue of a group is VALU-bound -- one wave per SIMD beside the other group's MFMAs)
+        auto fast_rows = [&](auto prelu_tag) {
+            constexpr bool PRELU = decltype(prelu_tag)::value;
+            auto finish = [&](int i, int q) -> f32x4 {
+                f32x4 v = acc[i][q] + bvec;
+                if constexpr (PRELU) {
+                    v.x = v.x > 0.f ? v.x : pvec.x * v.x;
+                    v.y = v.y > 0.f ? v.y : pvec.y * v.y;
+                    v.z = v.z > 0.f ? v.z : pvec.z * v.z;
+                    v.w = v.w > 0.f ? v.w : pvec.w * v.w;
+                }
+                return v + res[i][q];
+            };
+            if (a.mode == ATMVFI_GEMM_LINEAR && !a.out_hi) {
+                // fp32 rows (qkv, fc1, proj with its row map and residual, fc2, fusion projections)
+                float* obase = a.out + nb;
+                const bool col_ok = nb < a.Cout;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v = finish(i, q);
+                        const unsigned long long off = (unsigned long long)(unsigned)ro[i][q] * (unsigned)a.out_ld;
+                        if (ro[i][q] >= 0 && col_ok) *reinterpret_cast<f32x4*>(obase + off) = v;
+                    }
+            } else if (a.mode == ATMVFI_GEMM_LINEAR) {
+                // fp32 rows (optionally a grouped [G, R, C] view) + plane sink (the last fc2 of a motion branch)
+                const unsigned rpg = a.out_rpg > 0 ? (unsigned)a.out_rpg : 0x7fffffffu;
+                const RowSink sink{nullptr, 0, a.out_hi, a.out_lo, a.out_plane_rows};
+                const bool col_ok = nb < a.Cout;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v = finish(i, q);
+                        const unsigned rr = ro[i][q] < 0 ? 0u : (unsigned)ro[i][q];
+                        const unsigned gi = rr / rpg;
+                        const long long prow = rr - gi * rpg;
+                        const long long off = gi * a.out_gstride + prow * (long long)a.out_ld;
+                        if (ro[i][q] >= 0 && col_ok) {
+                            *reinterpret_cast<f32x4*>(a.out + off + nb) = v;
+                            sink_store4(sink, prow, a.out_c0 + (int)gi * a.out_gc + nb, v);
+                        }
+                    }
+            } else {
+                // ConvTranspose2d 2x2 / stride 2 into a plane sink (decoder and U-Net stages): column -> (position, channel) is a
+                // lane constant; the lane's rows are 4 input pixels apart: (image, y, x) of the first by division, the others by
+                // stepping
+                const RowSink sink{nullptr, 0, a.out_hi, a.out_lo, a.out_plane_rows};
+                const int hw = a.H * a.W;
+                int dn = (int)((unsigned)mrow / (unsigned)hw);
+                const int rem = mrow - dn * hw;
+                int dy = rem / a.W;
+                int dx = rem - dy * a.W;
+                const int qoff = (cp.q >> 1) * a.Wo + (cp.q & 1);
+                const int pc = a.out_c0 + cp.co;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 v = finish(i, q);
+                        v.y = cp.nvalid > 1 ? v.y : 0.f;            // channels past Cout inside the group of 4: the planes' pad channels
+                        v.z = cp.nvalid > 2 ? v.z : 0.f;
+                        v.w = cp.nvalid > 3 ? v.w : 0.f;
+                        const long long prow = ((long long)dn * a.Ho + 2 * dy) * a.Wo + 2 * dx + qoff;
+                        if (ro[i][q] >= 0 && cp.nvalid > 0) sink_store4(sink, prow, pc, v);
+                        dx += 4;                                      // next row of this lane (W >= 4: one wrap at most)
+                        const bool wrap = dx >= a.W;
+                        dx = wrap ? dx - a.W : dx;
+                        dy = wrap ? dy + 1 : dy;
+                        const bool wrap2 = dy >= a.H;
+                        dy = wrap2 ? 0 : dy;
+                        dn = wrap2 ? dn + 1 : dn;
+                    }
+            }
         };
         const bool c4 = (a.Cout & 3) == 0;
-        if (a.mode == ATMVFI_GEMM_LINEAR && a.out && !a.out_hi && a.out_rpg == 0 && c4) {
-            // fp32 rows (qkv, fc1, proj with its row map and residual, fc2, fusion projections)
-            float* obase = a.out + nb;
-            const bool col_ok = nb < a.Cout;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 v = finish(i, q);
-                    if (ro[i][q] >= 0 && col_ok) *reinterpret_cast<f32x4*>(obase + (long long)ro[i][q] * a.out_ld) = v;
-                }
-        } else if (a.mode == ATMVFI_GEMM_LINEAR && a.out && a.out_hi && c4) {
-            // fp32 rows (optionally a grouped [G, R, C] view) + plane sink (the last fc2 of a motion branch)
-            const unsigned rpg = a.out_rpg > 0 ? (unsigned)a.out_rpg : 0x7fffffffu;
-            const RowSink sink{nullptr, 0, a.out_hi, a.out_lo, a.out_plane_rows};
-            const bool col_ok = nb < a.Cout;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 v = finish(i, q);
-                    const unsigned rr = ro[i][q] < 0 ? 0u : (unsigned)ro[i][q];
-                    const unsigned gi = rr / rpg;
-                    const long long prow = rr - gi * rpg;
-                    const long long off = gi * a.out_gstride + prow * (long long)a.out_ld;
-                    if (ro[i][q] >= 0 && col_ok) {
-                        *reinterpret_cast<f32x4*>(a.out + off + nb) = v;
-                        sink_store4(sink, prow, a.out_c0 + (int)gi * a.out_gc + nb, v);
-                    }
-                }
-        } else if (a.mode == ATMVFI_GEMM_DECONV && !a.out && a.out_hi && a.W >= 4 && !a.residual) {
-            // ConvTranspose2d 2x2 / stride 2 into a plane sink (decoder and U-Net stages): column -> (position, channel) is a lane
-            // constant; the lane's rows are 4 input pixels apart: (image, y, x) of the first by division, the others by stepping
-            const RowSink sink{nullptr, 0, a.out_hi, a.out_lo, a.out_plane_rows};
-            const int hw = a.H * a.W;
-            int dn = (int)((unsigned)mrow / (unsigned)hw);
-            const int rem = mrow - dn * hw;
-            int dy = rem / a.W;
-            int dx = rem - dy * a.W;
-            const int qoff = (cp.q >> 1) * a.Wo + (cp.q & 1);
-            const int pc = a.out_c0 + cp.co;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    f32x4 v = finish(i, q);
-                    v.y = cp.nvalid > 1 ? v.y : 0.f;            // channels past Cout inside the group of 4: the planes' pad channels
-                    v.z = cp.nvalid > 2 ? v.z : 0.f;
-                    v.w = cp.nvalid > 3 ? v.w : 0.f;
-                    const long long prow = ((long long)dn * a.Ho + 2 * dy) * a.Wo + 2 * dx + qoff;
-                    if (ro[i][q] >= 0 && cp.nvalid > 0) sink_store4(sink, prow, pc, v);
-                    dx += 4;                                      // next row of this lane (W >= 4: one wrap at most)
-                    const bool wrap = dx >= a.W;
-                    dx = wrap ? dx - a.W : dx;
-                    dy = wrap ? dy + 1 : dy;
-                    const bool wrap2 = dy >= a.H;
-                    dy = wrap2 ? 0 : dy;
-                    dn = wrap2 ? dn + 1 : dn;
-                }
+        const bool fast = (a.mode == ATMVFI_GEMM_LINEAR && a.out && c4 && (a.out_hi || a.out_rpg == 0)) ||
+                          (a.mode == ATMVFI_GEMM_DECONV && !a.out && a.out_hi && a.W >= 4 && !a.residual);
+        if (fast) {
+            if (a.prelu) fast_rows(std::true_type{});
+            else fast_rows(std::false_type{});
         } else if (a.residual && !vec_res) {
             store_rows(std::true_type{});
         } else {
             store_rows(std::false_type{});
         }
+        PP_SUB(2);
         PP_STAMP(3);
 #ifdef ATMVFI_STAMP
         if (a.stamp) {
@@ -525,8 +549,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmDev a) {
         unsigned long long* o = a.stamp + ((long long)blockIdx.x * 8 + wave) * 8;
         o[0] = t_pro; o[1] = t_loop / ntile; o[2] = t_epi / ntile;
         o[3] = (unsigned long long)nk;
-        o[4] = r_pro; o[5] = r_loop / ntile; o[6] = r_epi / ntile;
-        o[7] = (unsigned long long)ntile;
+        o[4] = r_loop / ntile; o[5] = sub[0] / ntile; o[6] = sub[1] / ntile;
+        o[7] = sub[2] / ntile;
     }
 #endif
 }

@@ -24,10 +24,13 @@ for m, n, k in [(65280, 1536, 384), (65280, 384, 1536), (16320, 2688, 672)]:
         ops.linear(pl, pw, y)
     torch.cuda.synchronize()
     t = buf.reshape(-1, 8).double()
-    t = t[t[:, 3] > 0]
-    nk = t[0, 3].item()
-    pro, loop, epi = (t[:, i].median().item() for i in range(3))
-    rpro, rloop, repi = (t[:, 4 + i].median().item() for i in range(3))
+    tv = t[t[:, 3] > 0]
+    nk = tv[0, 3].item()
+    pro, loop, epi = (tv[:, i].median().item() for i in range(3))
+    rloop = tv[:, 4].median().item()
     clk = loop / rloop * 100.0 if rloop else float("nan")     # s_memrealtime ticks at 100 MHz
-    print(f"M{m} N{n} K{k}: k-steps {nk:.0f}; cycles prologue {pro:.0f}  loop {loop:.0f} ({loop / nk:.0f}/step)  epilogue {epi:.0f};"
-          f" in-kernel clock {clk:.0f} MHz; loop {rloop / 100:.2f} us", flush=True)
+    for grp, rows in (("group 0", t.reshape(-1, 8, 8)[:, :4].reshape(-1, 8)), ("group 1", t.reshape(-1, 8, 8)[:, 4:].reshape(-1, 8))):
+        rows = rows[rows[:, 3] > 0]
+        lp, ep, s0, s1, s2 = (rows[:, i].median().item() for i in (1, 2, 5, 6, 7))
+        print(f"M{m} N{n} K{k} {grp}: k-steps {nk:.0f}; cycles per tile: prologue (first tile) {pro:.0f}  loop {lp:.0f} ({lp / nk:.0f}/step)  epilogue {ep:.0f}"
+              f" = fold + transpose {s0:.0f} + constants / rows / residual {s1:.0f} + stores {s2:.0f}; in-kernel clock {clk:.0f} MHz", flush=True)
