@@ -60,6 +60,7 @@ __device__ __forceinline__ void lds_read16f(f32x4& d, unsigned addr) {
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+template <bool CONVM>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmDev a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -105,12 +106,30 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmDev a) {
     const unsigned char* pa_lo;
     const unsigned char* pw_hi;
     const unsigned char* pw_lo;
+    // CONV mode (strided / dilated / 1x1 convolutions, network_base.py:20-25, 73-85): k-step = (tap, 32-channel chunk); GEMM row m is
+    // output pixel (n, oy, ox) and its operand row at tap (ky, kx) is input pixel (n, oy*stride - pad + ky*dil, ox*stride - pad +
+    // kx*dil), or the planes' zero row N*H*W when that falls outside the image -- the same DMA with a per-lane source row.  Per
+    // lane and row: the input row of tap (0, 0) and its (y, x) packed into one register; wave-uniform: tap and chunk of the
+    // stage that goes out next (aoff is not used).
+    int crow[2], cyx[2];
+    int c_ky = 0, c_kx = 0, c_chunk = 0;
+    const int zero_row = a.in_N * a.H * a.W;
     auto setup_issue = [&](int tm0, int tn0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             int m = tm0 + (i * 8 + wave) * 16 + (lane >> 2);
             if (m >= M) m = M - 1;                                  // tail rows: valid address, result never stored
-            aoff[i] = (unsigned)m * 64u + ls16;
+            if constexpr (CONVM) {
+                const int hw = a.Ho * a.Wo;
+                const int n = (int)((unsigned)m / (unsigned)hw);
+                const int rem = m - n * hw;
+                const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+                const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+                cyx[i] = (iy0 << 16) | (ix0 & 0xffff);
+                crow[i] = (n * a.H + iy0) * a.W + ix0;
+            } else {
+                aoff[i] = (unsigned)m * 64u + ls16;
+            }
         }
         int n = tn0 + wave * 16 + (lane >> 2);
         if (n >= a.wrows) n = a.wrows - 1;                          // columns past the packed rows: never stored
@@ -119,20 +138,49 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmDev a) {
         pa_lo = reinterpret_cast<const unsigned char*>(a.a_lo);
         pw_hi = reinterpret_cast<const unsigned char*>(a.w_hi);
         pw_lo = reinterpret_cast<const unsigned char*>(a.w_lo);
+        c_ky = 0;
+        c_kx = 0;
+        c_chunk = 0;
     };
     setup_issue(m0, n0);
     const long long a_step = (long long)a.in_ld * 64, w_step = (long long)a.wrows * 64;
     int wr_off = 0;                                                 // stage buffer (byte offset) the next issue goes to
     auto issue_stage = [&]() {
         unsigned char* dst = smem + wr_off + wave * 1024;
-        dma16(pa_hi + aoff[0], dst);
-        dma16(pa_hi + aoff[1], dst + 8 * 1024);
-        dma16(pa_lo + aoff[0], dst + A_LO);
-        dma16(pa_lo + aoff[1], dst + A_LO + 8 * 1024);
+        if constexpr (CONVM) {
+            // plane pointers of this stage's chunk: the first source, or (channels >= 32 * split_chunks) the second one
+            const bool second = c_chunk >= a.split_chunks;
+            const unsigned char* bh = second ? reinterpret_cast<const unsigned char*>(a.a_hi2) + (long long)(c_chunk - a.split_chunks) * a.in_ld2 * 64
+                                             : pa_hi + (long long)c_chunk * a_step;
+            const unsigned char* bl = second ? reinterpret_cast<const unsigned char*>(a.a_lo2) + (long long)(c_chunk - a.split_chunks) * a.in_ld2 * 64
+                                             : pa_lo + (long long)c_chunk * a_step;
+            const int dyo = c_ky * a.dil, dxo = c_kx * a.dil;
+            unsigned off[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int iy = (cyx[i] >> 16) + dyo, ix = (int)(short)cyx[i] + dxo;
+                const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                const int row = ok ? crow[i] + dyo * a.W + dxo : zero_row;
+                off[i] = (unsigned)row * 64u + ls16;
+            }
+            dma16(bh + off[0], dst);
+            dma16(bh + off[1], dst + 8 * 1024);
+            dma16(bl + off[0], dst + A_LO);
+            dma16(bl + off[1], dst + A_LO + 8 * 1024);
+            if (++c_chunk == a.cpt32) {
+                c_chunk = 0;
+                if (++c_kx == a.kw) { c_kx = 0; ++c_ky; }
+            }
+        } else {
+            dma16(pa_hi + aoff[0], dst);
+            dma16(pa_hi + aoff[1], dst + 8 * 1024);
+            dma16(pa_lo + aoff[0], dst + A_LO);
+            dma16(pa_lo + aoff[1], dst + A_LO + 8 * 1024);
+            pa_hi += a_step;
+            pa_lo += a_step;
+        }
         dma16(pw_hi + wsoff, dst + W_HI);
         dma16(pw_lo + wsoff, dst + W_LO);
-        pa_hi += a_step;
-        pa_lo += a_step;
         pw_hi += w_step;
         pw_lo += w_step;
         wr_off = wr_off == 2 * STAGE ? 0 : wr_off + STAGE;
@@ -450,8 +498,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmDev a) {
                 }
                 return v + res[i][q];
             };
-            if (a.mode == ATMVFI_GEMM_LINEAR && !a.out_hi) {
-                // fp32 rows (qkv, fc1, proj with its row map and residual, fc2, fusion projections)
+            if (a.mode != ATMVFI_GEMM_DECONV && !a.out_hi) {
+                // fp32 rows (qkv, fc1, proj with its row map and residual, fc2, fusion projections; convolutions)
                 float* obase = a.out + nb;
                 const bool col_ok = nb < a.Cout;
 #pragma unroll
@@ -462,11 +510,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmDev a) {
                         const unsigned long long off = (unsigned long long)(unsigned)ro[i][q] * (unsigned)a.out_ld;
                         if (ro[i][q] >= 0 && col_ok) *reinterpret_cast<f32x4*>(obase + off) = v;
                     }
-            } else if (a.mode == ATMVFI_GEMM_LINEAR) {
-                // fp32 rows (optionally a grouped [G, R, C] view) + plane sink (the last fc2 of a motion branch)
+            } else if (a.mode != ATMVFI_GEMM_DECONV) {
+                // plane sink, with or without fp32 rows (optionally a grouped [G, R, C] view): the last fc2 of a motion branch,
+                // strided / 1x1 convolutions between plane maps
                 const unsigned rpg = a.out_rpg > 0 ? (unsigned)a.out_rpg : 0x7fffffffu;
                 const RowSink sink{nullptr, 0, a.out_hi, a.out_lo, a.out_plane_rows};
                 const bool col_ok = nb < a.Cout;
+                const bool f32_too = a.out != nullptr;
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -477,7 +527,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmDev a) {
                         const long long prow = rr - gi * rpg;
                         const long long off = gi * a.out_gstride + prow * (long long)a.out_ld;
                         if (ro[i][q] >= 0 && col_ok) {
-                            *reinterpret_cast<f32x4*>(a.out + off + nb) = v;
+                            if (f32_too) *reinterpret_cast<f32x4*>(a.out + off + nb) = v;
                             sink_store4(sink, prow, a.out_c0 + (int)gi * a.out_gc + nb, v);
                         }
                     }
@@ -514,7 +564,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmDev a) {
             }
         };
         const bool c4 = (a.Cout & 3) == 0;
-        const bool fast = (a.mode == ATMVFI_GEMM_LINEAR && a.out && c4 && (a.out_hi || a.out_rpg == 0)) ||
+        const bool fast = (a.mode != ATMVFI_GEMM_DECONV && c4 && (a.out_hi || (a.out && a.out_rpg == 0))) ||
                           (a.mode == ATMVFI_GEMM_DECONV && !a.out && a.out_hi && a.W >= 4 && !a.residual);
         if (fast) {
             if (a.prelu) fast_rows(std::true_type{});
@@ -557,12 +607,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmDev a) {
 
 }  // namespace
 
-int atmvfi::launch_gemm_pp(const GemmDev& d, int ngemm, hipStream_t s) {
+template <bool CONVM>
+static int launch_pp(const GemmDev& d, int ngemm, hipStream_t s) {
     const size_t lds = (size_t)3 * STAGE + 2 * CST_FLOATS * sizeof(float);
-    const hipError_t attr_err = atmvfi::allow_dynamic_lds<gemm_pp_kernel>(lds);
+    const hipError_t attr_err = atmvfi::allow_dynamic_lds<gemm_pp_kernel<CONVM>>(lds);
     ATMVFI_REQUIRE(attr_err == hipSuccess, ATMVFI_ELAUNCH, "gemm_pp: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
-    ATMVFI_REQUIRE((long long)d.in_ld * 64 < (1ll << 32) && (long long)d.wrows * 64 < (1ll << 32), ATMVFI_EINVAL,
+    ATMVFI_REQUIRE((long long)d.in_ld * 64 < (1ll << 32) && (long long)d.wrows * 64 < (1ll << 32) &&
+                       (!d.a_hi2 || (long long)d.in_ld2 * 64 < (1ll << 32)) && d.M < (1ll << 26), ATMVFI_EINVAL,
                    "gemm_pp: plane rows x 64 bytes must fit 32 bits (got %d rows)", d.in_ld);
+    if (CONVM) ATMVFI_REQUIRE(d.H < 32768 && d.W < 32768, ATMVFI_EINVAL, "gemm_pp: CONV mode packs (y, x) into 16 bits each");
     GemmDev dd = d;
     dd.dbg = 0;
 #ifdef ATMVFI_STAMP
@@ -575,6 +628,10 @@ int atmvfi::launch_gemm_pp(const GemmDev& d, int ngemm, hipStream_t s) {
     // persistent from two k-steps up (the ring's look-ahead of two stages then spans at most one tile boundary): one workgroup per
     // CU (147 KiB of LDS) walking its XCD's tiles; K <= 32: one workgroup per tile
     const int grid = d.nchunks32 >= 2 ? std::min(dd.vblocks, atmvfi::cu_count()) : dd.vblocks;
-    hipLaunchKernelGGL(gemm_pp_kernel, dim3((unsigned)grid), dim3(512), lds, s, dd);
+    hipLaunchKernelGGL(gemm_pp_kernel<CONVM>, dim3((unsigned)grid), dim3(512), lds, s, dd);
     return atmvfi::check_launch("gemm_pp");
+}
+
+int atmvfi::launch_gemm_pp(const GemmDev& d, int ngemm, hipStream_t s) {
+    return d.mode == ATMVFI_GEMM_CONV ? launch_pp<true>(d, ngemm, s) : launch_pp<false>(d, ngemm, s);
 }

@@ -390,8 +390,9 @@ int launch_split(const GemmDev& d, int ngemm, hipStream_t s) {
 }  // namespace
 
 int atmvfi::launch_gemm_split(const GemmDev& d, int ngemm, hipStream_t s) {
-    // LINEAR / DECONV rows: the ping-pong kernel (gemm_pp.hip); CONV (per-tap source rows) stays on this one
-    return d.mode == ATMVFI_GEMM_CONV ? launch_split<4, 2, true>(d, ngemm, s) : launch_gemm_pp(d, ngemm, s);
+    // the ping-pong kernel (gemm_pp.hip); this one is kept as the reference schedule (force_wn == -1: tools / A-B only)
+    if (d.force_wn != -1) return launch_gemm_pp(d, ngemm, s);
+    return d.mode == ATMVFI_GEMM_CONV ? launch_split<4, 2, true>(d, ngemm, s) : launch_split<4, 2, false>(d, ngemm, s);
 }
 
 extern "C" int atmvfi_split_planes_at(const float* in, int in_ld, int64_t M, int C, const float* prelu, void* hi, void* lo, int plane_rows,

@@ -442,6 +442,7 @@ class HipOps:
         if x2 is not None:
             off2 = x2_chunk0 * x2.ld_rows * 64
             p.in_hi2, p.in_lo2, p.in_ld2, p.in_split_chunks = x2.t[0].data_ptr() + off2, x2.t[1].data_ptr() + off2, x2.ld_rows, split_chunks
+        p.tile_wn = self.gemm_tile_wn if self.gemm_tile_wn < 0 else 0        # -1: the reference schedule (gemm_split.hip)
         self._gemm_sink(p, sink, n * oh * ow, cout, sink_c0, 0, 1, "conv_planes")
         meta = {"flops": 2.0 * n * oh * ow * cout * cin * w.kh * w.kw, "bytes": 4.0 * (n * h * wd * cin + n * oh * ow * cout + cout * cin * w.kh * w.kw),
                 "shape": f"M{n * oh * ow} N{cout} K{cin * w.kh * w.kw}"}

@@ -829,6 +829,98 @@ def test_conv_from_two_plane_sources(hip, dev):
     assert torch.equal(y0, y1), maxdiff(y0, y1)
 
 
+PP_CASES = [
+    # kind, rows / geometry, Cin, Cout, extras -- every one with several tiles per workgroup of the persistent grid (> 256 tiles)
+    ("linear", 70001, 96, 384, dict(bias=True, res=True)),            # 3 k-steps, ragged last row tile, 3 column blocks
+    ("linear", 66000, 64, 200, dict(bias=True, res=False)),           # 2 k-steps (the shortest persistent K), ragged columns
+    ("linear", 40000, 160, 1152, dict(bias=False, res=False)),        # 5 k-steps, 9 column blocks
+    ("linear_map", 2 * 150 * 150, 96, 384, dict(bias=True, res=True)),   # window-reverse scatter with dropped (padded) rows
+    ("linear_groups", 2 * 20000, 128, 128, dict()),                   # grouped [2, R, C] output view + plane sink at a group offset
+    ("deconv", (1, 150, 220), 101, 101, dict()),                      # plane sink, ragged position blocks (104-wide), 4 k-steps
+    ("deconv", (2, 96, 130), 64, 32, dict()),                         # 2 k-steps
+    ("conv", (2, 300, 400), 48, 96, dict(stride=2, k=3, dil=1)),      # strided 3x3, 18 k-steps, taps outside the image
+    ("conv", (1, 270, 480), 64, 160, dict(stride=1, k=1, dil=1)),     # 1x1 (2 k-steps), fp32 out + sink
+    ("conv", (2, 260, 300), 32, 96, dict(stride=4, k=3, dil=2)),      # stride 4, dilation 2
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", PP_CASES, ids=lambda c: f"{c[0]}_{c[2]}to{c[3]}")
+def test_gemm_pp_matches_reference_schedule(case, dev):
+    """gemm_pp.hip (ping-pong wave groups, persistent grid with the DMA ring flowing across tiles, LDS-transposed epilogue) against
+    the reference schedule gemm_split.hip (atmvfi_gemm_params.tile_wn = -1): same arithmetic, so bit-identical outputs, on shapes
+    with several tiles per workgroup (the op tests above fit one round of 256 workgroups)."""
+    kind, geom, cin, cout, ex = case
+    hp, hr = hip_ops.HipOps(dev), hip_ops.HipOps(dev)
+    hr.gemm_tile_wn = -1
+    g = torch.Generator().manual_seed(cin * 1000 + cout)
+    outs = []
+    if kind.startswith("linear"):
+        m = geom
+        x = rnd(g, m, cin, scale=2.0).to(dev)
+        w = rnd(g, cout, cin, scale=1.0 / cin ** 0.5).to(dev)
+        b = rnd(g, cout, scale=0.5).to(dev) if ex.get("bias") else None
+        r = rnd(g, m, cout, scale=0.5).to(dev) if ex.get("res") else None
+        pw = hp.pack_weight(GEMM_LINEAR, w)
+        pl = hip_ops.Planes.alloc(m, cin, dev)
+        hp.split_planes(x, pl)
+        for h in (hp, hr):
+            if kind == "linear_map":
+                geo = windows.build_window_geometry(2, 150, 150, 8, 4)
+                mw = geo.row_map.numel()
+                assert mw >= m
+                rmap = geo.row_map.contiguous().to(dev)
+                plw = hip_ops.Planes.alloc(mw, cin, dev)
+                h.split_planes(torch.cat([x, x[:mw - m]], 0), plw)
+                rr = torch.cat([r, r[:mw - m]], 0)
+                y = torch.full((m, cout), 7.0, device=dev)
+                h.linear(plw, pw, y, b, rr, rmap)
+                outs.append([y])
+            elif kind == "linear_groups":
+                half = m // 2
+                buf = torch.full((half, 8 + 2 * cout), 3.0, device=dev)
+                y = buf[:, 8:8 + 2 * cout].unflatten(1, (2, cout)).permute(1, 0, 2)          # [2, half, cout] view, group stride cout
+                sk = hip_ops.Planes.alloc(half, 8 + 2 * cout, dev)
+                h.linear(pl, pw, y, sink=sk, sink_c0=8, sink_gc=cout)
+                outs.append([buf, sk.t])
+            else:
+                n4 = (cout + 3) // 4 * 4
+                y = torch.full((m, n4), 5.0, device=dev)[:, :cout]
+                h.linear(pl, pw, y, b, r)
+                outs.append([y])
+    elif kind == "deconv":
+        n, hh, ww = geom
+        x = rnd(g, n * hh * ww, cin, scale=2.0).to(dev)
+        wt = rnd(g, cin, cout, 2, 2, scale=1.0 / cin ** 0.5).to(dev)
+        b, pr = rnd(g, cout, scale=0.5).to(dev), (torch.rand(cout, generator=g) * 0.4).to(dev)
+        pw = hp.pack_weight(GEMM_DECONV, wt)
+        pl = hip_ops.Planes.alloc(n * hh * ww, cin, dev)
+        hp.split_planes(x, pl)
+        for h in (hp, hr):
+            sk = hip_ops.Planes.alloc(n * 4 * hh * ww, cout, dev)
+            h.deconv(None, pw, None, bias=b, prelu=pr, planes=pl, sink=sk, in_shape=(n, hh, ww, cin))
+            outs.append([sk.t])
+    else:
+        n, hh, ww = geom
+        k, st, dil = ex["k"], ex["stride"], ex["dil"]
+        pad = dil * (k // 2)
+        x = rnd(g, n * hh * ww, cin, scale=2.0).to(dev)
+        wt = rnd(g, cout, cin, k, k, scale=1.0 / (k * k * cin) ** 0.5).to(dev)
+        b, pr = rnd(g, cout, scale=0.5).to(dev), (torch.rand(cout, generator=g) * 0.4).to(dev)
+        pw = hp.pack_weight(GEMM_CONV, wt)
+        pl = hip_ops.Planes.alloc(n * hh * ww, cin, dev)
+        hp.split_planes(x, pl)
+        oh, ow = (hh + 2 * pad - dil * (k - 1) - 1) // st + 1, (ww + 2 * pad - dil * (k - 1) - 1) // st + 1
+        for h in (hp, hr):
+            sk = hip_ops.Planes.alloc(n * oh * ow, cout, dev)
+            y = torch.full((n, oh, ow, cout), 9.0, device=dev) if k == 1 else None
+            h.conv_planes(pl, n, hh, ww, pw, out=y, stride=st, pad=pad, dil=dil, bias=b, prelu=pr, sink=sk)
+            outs.append([sk.t] + ([y] if y is not None else []))
+    torch.cuda.synchronize()
+    for a, b_ in zip(outs[0], outs[1]):
+        assert torch.equal(a, b_), maxdiff(a.float(), b_.float())
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("shift", [0, 3])
 def test_atmformer_module_reference_fixture(shift, dev):
