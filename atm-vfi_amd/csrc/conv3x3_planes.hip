@@ -60,6 +60,10 @@ struct Conv3PDev {
     long long plane_rows;
     int out_c0;
     const float* plane_prelu;   // optional PReLU applied to the plane copy only (the next layer's leading activation)
+    _Float16* out_hi2;          // optional SECOND plane sink, raw (no PReLU of its own): a decoder map goes on both through the next
+    _Float16* out_lo2;          // stage's leading PReLU (first sink) and as it is (the U-Net's strided convs read it)
+    long long plane_rows2;
+    int out_c02;
     int out_cmin;               // fp32 output: only channels >= out_cmin (multiple of 4) are stored
     int tiles_x, tiles_y, nblocks, tchunk;
     unsigned long long* stamp;  // diagnostic builds only (ATMVFI_STAMP)
@@ -413,26 +417,26 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
             }
         }
     }
-    if (a.out_hi) {
-        // Plane sink, fully coalesced: n-tiles in pairs (j, j+1); one swap per dword gives the lower half-wave the 8 channels
-        // 16j + 8g .. of n-tile j and the upper half-wave those of n-tile j+1 (T21 of the programming guide), so ONE 16-byte
-        // store per lane and plane writes 16 pixels x 32 channels x 2 bytes = one contiguous KiB of the chunk-major plane.
-        // Channels past Cout inside the last group of 8 are zero (zero weight rows, zero bias); groups beyond are not stored.
+    // Plane sink, fully coalesced: n-tiles in pairs (j, j+1); one swap per dword gives the lower half-wave the 8 channels
+    // 16j + 8g .. of n-tile j and the upper half-wave those of n-tile j+1 (T21 of the programming guide), so ONE 16-byte
+    // store per lane and plane writes 16 pixels x 32 channels x 2 bytes = one contiguous KiB of the chunk-major plane.
+    // Channels past Cout inside the last group of 8 are zero (zero weight rows, zero bias); groups beyond are not stored.
+    auto plane_sink = [&](_Float16* phi, _Float16* plo, long long prows, int pc0, const float* pslope) {
         const int climit = (a.Cout + 7) & ~7;
         constexpr int NP = (WN + 1) / 2;
 #pragma unroll
         for (int jp = 0; jp < NP; ++jp) {
             const int j0 = 2 * jp, j1 = (2 * jp + 1 < WN) ? 2 * jp + 1 : 2 * jp;
             f32x4 s0 = (f32x4){1.f, 1.f, 1.f, 1.f}, s1 = s0;
-            if (a.plane_prelu) {               // padded to a multiple of 32 floats by the host
+            if (pslope) {               // padded to a multiple of 32 floats by the host
                 const int c0 = n0 + 16 * j0 + cb, c1 = n0 + 16 * j1 + cb;
-                s0 = *reinterpret_cast<const f32x4*>(a.plane_prelu + (c0 < a.Cout ? c0 : 0));
-                s1 = *reinterpret_cast<const f32x4*>(a.plane_prelu + (c1 < a.Cout ? c1 : 0));
+                s0 = *reinterpret_cast<const f32x4*>(pslope + (c0 < a.Cout ? c0 : 0));
+                s1 = *reinterpret_cast<const f32x4*>(pslope + (c1 < a.Cout ? c1 : 0));
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 f32x4 u0 = vv[i][j0], u1 = vv[i][j1];
-                if (a.plane_prelu) {
+                if (pslope) {
                     u0.x = u0.x > 0.f ? u0.x : s0.x * u0.x;  u0.y = u0.y > 0.f ? u0.y : s0.y * u0.y;
                     u0.z = u0.z > 0.f ? u0.z : s0.z * u0.z;  u0.w = u0.w > 0.f ? u0.w : s0.w * u0.w;
                     u1.x = u1.x > 0.f ? u1.x : s1.x * u1.x;  u1.y = u1.y > 0.f ? u1.y : s1.y * u1.y;
@@ -456,14 +460,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
                 const int jt = g < 2 ? j0 : 2 * jp + 1;                       // the n-tile this lane stores
                 const int cs = n0 + 16 * jt + 8 * (g & 1);                      // first of its 8 channels
                 if (live[i] && jt < WN && cs < climit) {
-                    const int c = a.out_c0 + cs;
-                    const long long off = ((long long)(c >> 5) * a.plane_rows + prow_o[i]) * 32 + (c & 31);
-                    *reinterpret_cast<u32x4*>(a.out_hi + off) = hv;
-                    *reinterpret_cast<u32x4*>(a.out_lo + off) = lv;
+                    const int c = pc0 + cs;
+                    const long long off = ((long long)(c >> 5) * prows + prow_o[i]) * 32 + (c & 31);
+                    *reinterpret_cast<u32x4*>(phi + off) = hv;
+                    *reinterpret_cast<u32x4*>(plo + off) = lv;
                 }
             }
         }
-    }
+    };
+    if (a.out_hi) plane_sink(a.out_hi, a.out_lo, a.plane_rows, a.out_c0, a.plane_prelu);
+    if (a.out_hi2) plane_sink(a.out_hi2, a.out_lo2, a.plane_rows2, a.out_c02, nullptr);
 #ifdef ATMVFI_STAMP
     if (a.stamp && lane == 0) {
         const unsigned long long t_end = __builtin_amdgcn_s_memtime();
@@ -502,11 +508,17 @@ int launch_planes(const Conv3PDev& d, int ntiles, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int atmvfi_conv3x3_planes(const void* in_hi, const void* in_lo, int64_t in_rows, int N, int H, int W, int Cin, const void* w_hi,
-                                      const void* w_lo, int Cout, float* out, int out_ld, const float* bias, const float* prelu,
-                                      void* out_hi, void* out_lo, int64_t plane_rows, int out_c0, const float* plane_prelu, int out_cmin,
-                                      int wn, void* stream) {
+extern "C" int atmvfi_conv3x3_planes2(const void* in_hi, const void* in_lo, int64_t in_rows, int N, int H, int W, int Cin, const void* w_hi,
+                                       const void* w_lo, int Cout, float* out, int out_ld, const float* bias, const float* prelu,
+                                       void* out_hi, void* out_lo, int64_t plane_rows, int out_c0, const float* plane_prelu, void* out_hi2,
+                                       void* out_lo2, int64_t plane_rows2, int out_c02, int out_cmin, int wn, void* stream) {
     ATMVFI_REQUIRE(in_hi && in_lo && w_hi && w_lo && (out || out_hi), ATMVFI_EINVAL, "conv3x3_planes: null pointer");
+    ATMVFI_REQUIRE((out_hi2 == nullptr) == (out_lo2 == nullptr), ATMVFI_EINVAL, "conv3x3_planes: the second plane sink needs both planes");
+    if (out_hi2)
+        ATMVFI_REQUIRE(out_hi && plane_rows2 >= (int64_t)N * H * W && out_c02 >= 0 && out_c02 % 8 == 0 && atmvfi::aligned16(out_hi2) &&
+                           atmvfi::aligned16(out_lo2), ATMVFI_EINVAL,
+                       "conv3x3_planes: the second plane sink needs the first one, plane_rows2 >= N*H*W, a channel offset that is a multiple "
+                       "of 8 and 16-byte aligned planes");
     ATMVFI_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, ATMVFI_EINVAL, "conv3x3_planes: bad shape");
     ATMVFI_REQUIRE(in_rows > (int64_t)N * H * W && in_rows * 64 < (1ll << 32), ATMVFI_EINVAL,
                    "conv3x3_planes: in_rows %lld must exceed N*H*W (the zero row) and in_rows * 64 must fit 32 bits", (long long)in_rows);
@@ -534,6 +546,7 @@ extern "C" int atmvfi_conv3x3_planes(const void* in_hi, const void* in_lo, int64
     if (t >= 1 && t <= 8) { d.cf = Cin - t; d.tail = t; } else { d.cf = atmvfi::round_up(Cin, 32); d.tail = 0; }
     d.Cout = Cout; d.out = out; d.out_ld = out_ld; d.bias = bias; d.prelu = prelu;
     d.out_hi = (_Float16*)out_hi; d.out_lo = (_Float16*)out_lo; d.plane_rows = plane_rows; d.out_c0 = out_c0; d.plane_prelu = plane_prelu;
+    d.out_hi2 = (_Float16*)out_hi2; d.out_lo2 = (_Float16*)out_lo2; d.plane_rows2 = plane_rows2; d.out_c02 = out_c02;
     d.out_cmin = out_cmin;
     d.tiles_x = (W + TW - 1) / TW;
     d.tiles_y = 0; d.nblocks = 0; d.tchunk = 0;
@@ -561,4 +574,12 @@ extern "C" int atmvfi_conv3x3_planes(const void* in_hi, const void* in_lo, int64
         case 7: return launch_planes<7>(d, ntiles, s);
         default: return launch_planes<8>(d, ntiles, s);
     }
+}
+
+extern "C" int atmvfi_conv3x3_planes(const void* in_hi, const void* in_lo, int64_t in_rows, int N, int H, int W, int Cin, const void* w_hi,
+                                      const void* w_lo, int Cout, float* out, int out_ld, const float* bias, const float* prelu,
+                                      void* out_hi, void* out_lo, int64_t plane_rows, int out_c0, const float* plane_prelu, int out_cmin,
+                                      int wn, void* stream) {
+    return atmvfi_conv3x3_planes2(in_hi, in_lo, in_rows, N, H, W, Cin, w_hi, w_lo, Cout, out, out_ld, bias, prelu, out_hi, out_lo, plane_rows,
+                                  out_c0, plane_prelu, nullptr, nullptr, 0, 0, out_cmin, wn, stream);
 }

@@ -75,6 +75,7 @@ SIGNATURES = {
     "atmvfi_pack_weight_conv3x3": (c_i, [c_f, c_f, c_f, c_i, c_i, c_f]),
     "atmvfi_conv3x3_f16x3": (c_i, [c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_l, c_f, c_i, c_i, c_f]),
     "atmvfi_conv3x3_planes": (c_i, [c_f, c_f, c_l, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_l, c_i, c_f, c_i, c_i, c_f]),
+    "atmvfi_conv3x3_planes2": (c_i, [c_f, c_f, c_l, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_l, c_i, c_f, c_f, c_f, c_l, c_i, c_i, c_i, c_f]),
     "atmvfi_layernorm": (c_i, [c_f, c_i, c_l, c_i, c_f, c_f, c_i, c_f, c_f, c_l, c_i, c_f, c_f, c_i, c_f]),
     "atmvfi_dwconv3x3_gelu": (c_i, [c_f, c_i, c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f]),
     "atmvfi_pack_dw_weight": (c_i, [c_f, c_f, c_i, c_f]),
@@ -371,10 +372,10 @@ class HipOps:
 
     def conv3x3_planes(self, x: Planes, n: int, h: int, wd: int, w: PackedWeight, out=None, bias=None, prelu=None,
                        planes: Optional[Planes] = None, planes_c0: int = 0, planes_prelu=None, in_chunk0: int = 0, cin: Optional[int] = None,
-                       wn: int = 0, out_cmin: int = 0):
+                       wn: int = 0, out_cmin: int = 0, planes2: Optional[Planes] = None, planes2_c0: int = 0):
         """3x3 / stride 1 / pad 1 conv (+bias, PReLU) on split-plane input ``x`` (rows = pixels of an [n,h,wd] map; channels
         ``32*in_chunk0 .. +cin``).  ``out``: fp32 NHWC view or None; ``planes``: plane sink written at channel offset ``planes_c0``
-        (its own ``planes_prelu`` applied to that copy only).  ``out_cmin``: only channels >= it are stored in ``out``.  Needs the spare
+        (its own ``planes_prelu`` applied to that copy only); ``planes2``: a second, raw plane sink.  ``out_cmin``: only channels >= it are stored in ``out``.  Needs the spare
         zero row of ``Planes.alloc``."""
         cin = (x.c - 32 * in_chunk0) if cin is None else cin
         if self.precision != "f16x3" or w.hi3 is None:
@@ -397,14 +398,17 @@ class HipOps:
                 raise ValueError(f"conv3x3_planes: plane sink [{planes.rows},{planes.c}] cannot take {cout} channels at offset {planes_c0}")
             if planes_prelu is not None and planes_prelu.numel() < (cout + 31) // 32 * 32:
                 raise ValueError("conv3x3_planes: planes_prelu must be padded to a multiple of 32 channels")
+        if planes2 is not None and (planes is None or planes2.rows != n * h * wd or planes2_c0 % 8 or planes2_c0 + cout > planes2.chunks * 32):
+            raise ValueError(f"conv3x3_planes: second plane sink [{planes2.rows},{planes2.c}] needs the first one and room for {cout} channels at {planes2_c0}")
         meta = {"flops": 2.0 * n * h * wd * cout * cin * 9, "bytes": 4.0 * (n * h * wd * (cin + cout) + cout * cin * 9),
                 "shape": f"M{n * h * wd} N{cout} K{cin * 9}"}
         coff = in_chunk0 * x.ld_rows * 32 * 2       # bytes
-        self._run("conv3x3_planes", meta, self.lib.atmvfi_conv3x3_planes, x.t[0].data_ptr() + coff, x.t[1].data_ptr() + coff, x.ld_rows,
+        self._run("conv3x3_planes", meta, self.lib.atmvfi_conv3x3_planes2, x.t[0].data_ptr() + coff, x.t[1].data_ptr() + coff, x.ld_rows,
                   n, h, wd, cin, _ptr(w.hi3), _ptr(w.lo3), cout, _ptr(out), old, _ptr(bias), _ptr(prelu),
                   planes.t[0].data_ptr() if planes is not None else None, planes.t[1].data_ptr() if planes is not None else None,
-                  planes.ld_rows if planes is not None else 0, planes_c0, _ptr(planes_prelu) if planes is not None else None, out_cmin, wn,
-                  self._stream())
+                  planes.ld_rows if planes is not None else 0, planes_c0, _ptr(planes_prelu) if planes is not None else None,
+                  planes2.t[0].data_ptr() if planes2 is not None else None, planes2.t[1].data_ptr() if planes2 is not None else None,
+                  planes2.ld_rows if planes2 is not None else 0, planes2_c0, out_cmin, wn, self._stream())
 
     def conv_planes(self, x: Planes, n: int, h: int, wd: int, w: PackedWeight, out=None, stride=1, pad=1, dil=1, bias=None, prelu=None,
                     sink: Optional[Planes] = None, sink_c0: int = 0, in_chunk0: int = 0, x2: Optional[Planes] = None, x2_chunk0: int = 0,

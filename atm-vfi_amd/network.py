@@ -177,6 +177,7 @@ class Network(BlockRunner, nn.Module):
         self._precision = "f16x3"
         self.use_plane_deconvs = os.environ.get("ATMVFI_PLANE_DECONV", "1") != "0"    # A/B switch: decoder deconvs from split planes
         self.use_plane_convs = os.environ.get("ATMVFI_PLANE_CONV", "1") != "0"        # A/B switch: 3x3 convs on split-plane input
+        self.use_unet_planes = os.environ.get("ATMVFI_UNET_PLANES", "1") != "0"       # A/B switch: the refiner's strided convs on split planes
         self._prepared: Dict[str, object] = {}
         self._prepared_sig = None
         # Workspaces: one dict of named buffers per (device, input shape, mode) key, least recently used first.  The reference's
@@ -375,7 +376,7 @@ class Network(BlockRunner, nn.Module):
         split planes by the producing layer's sink, fp32 copies only where something other than a contraction reads them."""
         return self._plane_deconvs(ops) and self.use_plane_convs and self._rows_fit_planes
 
-    def _c3p(self, ops, P, p, xp, n, h, w, out=None, act=True, sink=None, sink_c0=0, sink_prelu=None, wkey=None, out_cmin=0):
+    def _c3p(self, ops, P, p, xp, n, h, w, out=None, act=True, sink=None, sink_c0=0, sink_prelu=None, wkey=None, out_cmin=0, sink2=None):
         """conv()/Conv2d 3x3 s1 p1 of the reference on split-plane input ``xp`` ([n*h*w rows]); ``p`` = parameter prefix
         (``p.0.weight``/``p.0.bias``/``p.1.weight`` with ``act``, ``p.weight``/``p.bias`` without)."""
         if act:
@@ -383,21 +384,22 @@ class Network(BlockRunner, nn.Module):
         else:
             wk, bias, prelu = wkey or f"pk:{p}.weight", P[f"{p}.bias"], None
         ops.conv3x3_planes(xp, n, h, w, P[wk], out=out, bias=bias, prelu=prelu, planes=sink, planes_c0=sink_c0, planes_prelu=sink_prelu,
-                           out_cmin=out_cmin)
+                           out_cmin=out_cmin, **({} if sink2 is None else {"planes2": sink2}))
 
     def _conv_s2_sink(self, ops, P, p, x, sink, shape, out=None, sink_c0=0):
         """conv() 3x3 stride 2 (+PReLU) on the fp32-input GEMM engine, result to a plane sink (and ``out`` if given)."""
         ops.conv(x, P[f"pk:{p}.0.weight"], out, stride=2, pad=1, dil=1, bias=P[f"{p}.0.bias"], prelu=P[f"{p}.1.weight"],
                  planes=sink, planes_c0=sink_c0, out_shape=shape)
 
-    def _conv_p(self, ops, P, p, src: "_PMap", stride=1, pad=1, dil=1, act=True, out=None, sink=None, sink_c0=0):
+    def _conv_p(self, ops, P, p, src: "_PMap", stride=1, pad=1, dil=1, act=True, out=None, sink=None, sink_c0=0, src2: "Optional[_PMap]" = None):
         """conv() / nn.Conv2d of the reference (any stride / dilation, k 1 or 3) on a split-plane map through the LDS-DMA GEMM."""
         if act:
             wk, bias, prelu = f"pk:{p}.0.weight", P[f"{p}.0.bias"], P[f"{p}.1.weight"]
         else:
             wk, bias, prelu = f"pk:{p}.weight", P[f"{p}.bias"], None
+        two = {} if src2 is None else {"x2": src2.p, "x2_chunk0": src2.chunk0, "split_chunks": src.c // 32}
         ops.conv_planes(src.p, src.n, src.h, src.w, P[wk], out=out, stride=stride, pad=pad, dil=dil, bias=bias, prelu=prelu, sink=sink,
-                        sink_c0=sink_c0, in_chunk0=src.chunk0)
+                        sink_c0=sink_c0, in_chunk0=src.chunk0, **two)
 
     def _plane_deconvs(self, ops) -> bool:
         """Decoder deconvs on the LDS-DMA GEMM (operands as split planes) instead of the fp32-input engine."""
@@ -792,6 +794,9 @@ class Network(BlockRunner, nn.Module):
             flow0 = flow1 = m1 = m2 = None
             pd = self._plane_deconvs(ops)
             pc = self._plane_convs(ops) and rh >= 32
+            # the refiner's strided convs on split planes too (ping-pong GEMM, CONV mode, two plane sources for the concats):
+            # needs whole 32-channel chunks on both sides of every concat
+            unet_p = pc and self.use_unet_planes and rh % 32 == 0 and w1d % 32 == 0 and w2d % 32 == 0
             xp_next = None
             pack_c0 = (w3d + 5 + 7) // 8 * 8                                       # the 15 image channels inside the refiner's input planes
             rin_p = self.planes("refine_in_p", b * H * W, pack_c0 + 15) if pc else None
@@ -814,8 +819,16 @@ class Network(BlockRunner, nn.Module):
                     self._c3p(ops, P, f"{pfx}.{o + 1}", t1p, b, hs, wsz, sink=t2p)
                     if st < 2:
                         xp_next = self.planes(f"dec_xp_{st + 1}", b * hs * wsz, cout)
-                        self._c3p(ops, P, f"{pfx}.{o + 2}", t2p, b, hs, wsz, out=dsts[st], act=False, sink=xp_next,
-                                  sink_prelu=P[f"inprelu:{st + 1}"])
+                        if unet_p:
+                            # the map goes on twice as planes -- through the next stage's leading PReLU (its deconv) and raw (the
+                            # U-Net's strided conv reads cat(feat, dec[:, :w]) from two plane buffers); fp32 only for the five
+                            # flow / mask channels that warp_blend reads
+                            raw = self.planes(f"dec_raw_{st}", b * hs * wsz, cout)
+                            self._c3p(ops, P, f"{pfx}.{o + 2}", t2p, b, hs, wsz, out=dsts[st], act=False, sink=xp_next,
+                                      sink_prelu=P[f"inprelu:{st + 1}"], sink2=raw, out_cmin=(cout - 5) // 4 * 4)
+                        else:
+                            self._c3p(ops, P, f"{pfx}.{o + 2}", t2p, b, hs, wsz, out=dsts[st], act=False, sink=xp_next,
+                                      sink_prelu=P[f"inprelu:{st + 1}"])
                     else:
                         # finest level: only the five flow / mask channels are read in fp32 (by warp_blend); the features go on
                         # to the refiner as planes
@@ -859,17 +872,28 @@ class Network(BlockRunner, nn.Module):
                 bufA_p = self.planes("bufA_p", b * H * W, 2 * rh)                  # [up3 out | feat0]
                 bufB_p = self.planes("bufB_p", b * h2 * w2, 2 * rh)                # [up2 out | feat1]
                 bufC_p = self.planes("bufC_p", b * h4 * w4, 4 * rh)                # [up1 out | feat2]
-                feat0 = bufA[..., rh:2 * rh]
-                self._c3p(ops, P, "proj", rin_p, b, H, W, out=feat0, sink=bufA_p, sink_c0=rh, wkey="pk:proj.0.weight:planes")
-                feat1 = bufB[..., rh:2 * rh]
-                # (64 -> 64 at full resolution: too narrow for the LDS-DMA GEMM's 128-column tile, see _encoder)
-                self._conv_s2_sink(ops, P, "down1.0", feat0, bufB_p, (b, h2, w2, rh), out=feat1, sink_c0=rh)
                 d2a_p = self.planes("d2a_p", b * h4 * w4, 2 * rh)
-                self._conv_s2_sink(ops, P, "down2.0", bufB[..., rh:2 * rh + w2d], d2a_p, (b, h4, w4, 2 * rh))
-                feat2 = bufC[..., 2 * rh:4 * rh]
-                self._c3p(ops, P, "down2.1", d2a_p, b, h4, w4, out=feat2, sink=bufC_p, sink_c0=2 * rh)
                 d3a_p = self.planes("d3a_p", b * h * w, 4 * rh)
-                self._conv_s2_sink(ops, P, "down3.0", bufC[..., 2 * rh:4 * rh + w1d], d3a_p, (b, h, w, 4 * rh))
+                if unet_p:
+                    # feat0 / feat1 / feat2 exist as planes only (chunks of bufA_p / bufB_p / bufC_p): their readers are the strided
+                    # convs (CONV mode of the ping-pong GEMM) and the up-path's 3x3 convs
+                    self._c3p(ops, P, "proj", rin_p, b, H, W, sink=bufA_p, sink_c0=rh, wkey="pk:proj.0.weight:planes")
+                    self._conv_p(ops, P, "down1.0", _PMap(bufA_p, b, H, W, rh // 32, rh), stride=2, sink=bufB_p, sink_c0=rh)
+                    self._conv_p(ops, P, "down2.0", _PMap(bufB_p, b, h2, w2, rh // 32, rh), stride=2, sink=d2a_p,
+                                 src2=_PMap(self.planes("dec_raw_1", b * h2 * w2, w2d + 5), b, h2, w2, 0, w2d))
+                    self._c3p(ops, P, "down2.1", d2a_p, b, h4, w4, sink=bufC_p, sink_c0=2 * rh)
+                    self._conv_p(ops, P, "down3.0", _PMap(bufC_p, b, h4, w4, 2 * rh // 32, 2 * rh), stride=2, sink=d3a_p,
+                                 src2=_PMap(self.planes("dec_raw_0", b * h4 * w4, w1d + 5), b, h4, w4, 0, w1d))
+                else:
+                    feat0 = bufA[..., rh:2 * rh]
+                    self._c3p(ops, P, "proj", rin_p, b, H, W, out=feat0, sink=bufA_p, sink_c0=rh, wkey="pk:proj.0.weight:planes")
+                    feat1 = bufB[..., rh:2 * rh]
+                    # (64 -> 64 at full resolution: too narrow for the LDS-DMA GEMM's 128-column tile, see _encoder)
+                    self._conv_s2_sink(ops, P, "down1.0", feat0, bufB_p, (b, h2, w2, rh), out=feat1, sink_c0=rh)
+                    self._conv_s2_sink(ops, P, "down2.0", bufB[..., rh:2 * rh + w2d], d2a_p, (b, h4, w4, 2 * rh))
+                    feat2 = bufC[..., 2 * rh:4 * rh]
+                    self._c3p(ops, P, "down2.1", d2a_p, b, h4, w4, out=feat2, sink=bufC_p, sink_c0=2 * rh)
+                    self._conv_s2_sink(ops, P, "down3.0", bufC[..., 2 * rh:4 * rh + w1d], d3a_p, (b, h, w, 4 * rh))
                 d3b_p = self.planes("d3b_p", b * h * w, 4 * rh)
                 self._c3p(ops, P, "down3.1", d3a_p, b, h, w, sink=d3b_p)
                 d3c_p = self.planes("d3c_p", b * h * w, 4 * rh)

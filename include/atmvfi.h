@@ -189,6 +189,14 @@ int atmvfi_conv3x3_f16x3(const float* in, int in_ld, int N, int H, int W, int Ci
 int atmvfi_conv3x3_planes(const void* in_hi, const void* in_lo, int64_t in_rows, int N, int H, int W, int Cin, const void* w_hi,
                           const void* w_lo, int Cout, float* out, int out_ld, const float* bias, const float* prelu, void* out_hi,
                           void* out_lo, int64_t plane_rows, int out_c0, const float* plane_prelu, int out_cmin, int wn, void* stream);
+/* The same with a SECOND, raw plane sink (out_hi2 / out_lo2, plane_rows2 rows per chunk, channel offset out_c02, a multiple of 8; needs
+ * the first sink): a decoder map of the reference goes on twice -- through the next stage's leading nn.PReLU into that stage's deconv
+ * (network_base.py:209,215: the first sink with plane_prelu) and as it is into the refiner's strided convs (network_base.py:421-424,
+ * torch.cat([feat, dec], 1): atmvfi_gemm CONV mode with in_hi2 / in_lo2 reads it). */
+int atmvfi_conv3x3_planes2(const void* in_hi, const void* in_lo, int64_t in_rows, int N, int H, int W, int Cin, const void* w_hi,
+                           const void* w_lo, int Cout, float* out, int out_ld, const float* bias, const float* prelu, void* out_hi,
+                           void* out_lo, int64_t plane_rows, int out_c0, const float* plane_prelu, void* out_hi2, void* out_lo2,
+                           int64_t plane_rows2, int out_c02, int out_cmin, int wn, void* stream);
 /* ------------------------------------------------------------------------------------
  * LayerNorm over the channel axis of token rows (eps 1e-5, affine), optional gather.
  * Replaces nn.LayerNorm at attention.py:316 (norm1 on windowed tokens), :333 (norm2) and
