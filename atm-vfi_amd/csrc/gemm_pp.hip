@@ -120,10 +120,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmDev a) {
             int m = tm0 + (i * 8 + wave) * 16 + (lane >> 2);
             if (m >= M) m = M - 1;                                  // tail rows: valid address, result never stored
             if constexpr (CONVM) {
-                const int hw = a.Ho * a.Wo;
+                // (divisors laundered through an empty asm: otherwise hipcc hoists their reciprocals out of the tile loop and keeps
+                // them in vector registers across the k-loop, which is at the 256-register limit)
+                int hw = a.Ho * a.Wo, wo = a.Wo;
+                asm volatile("" : "+s"(hw), "+s"(wo));
                 const int n = (int)((unsigned)m / (unsigned)hw);
                 const int rem = m - n * hw;
-                const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+                const int oy = rem / wo, ox = rem - oy * wo;
                 const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
                 cyx[i] = (iy0 << 16) | (ix0 & 0xffff);
                 crow[i] = (n * a.H + iy0) * a.W + ix0;
@@ -336,6 +339,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmDev a) {
 #ifdef ATMVFI_STAMP
         sub_t = __builtin_amdgcn_s_memtime();
 #endif
+        // Both groups run the epilogue AT THE SAME TIME: the first group waits here for the second one's last MFMA phase (one phase,
+        // ~900 cycles), and two epilogue waves per SIMD fill each other's VALU latencies.  (One group's epilogue beside the other
+        // group's last MFMA phase / first read phase of the next tile, i.e. one after the other, cost 15 k cycles per tile boundary
+        // against 22 k of k-loop at K = 384: a lone epilogue wave per SIMD runs its dependent VALU chains at ~7 cycles an instruction.)
+        if (grp == 0) __builtin_amdgcn_s_barrier();
         // The second group's pieces of the next tile's stage 1 (all that is in flight) are waited for HERE, before its stores join
         // the queue; its first k-step of the next tile then skips the counted wait (g1wait).
         if (grp == 1 && has_next) wait_vm<0>();
@@ -401,18 +409,22 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmDev a) {
         const f32x4 pvec = *reinterpret_cast<const f32x4*>(cst + BN + cl);
         const int mrow = m0 + 64 * wm + g;                       // row of (i, q) = (0, 0); (i, q) adds 16 i + 4 q
         int ro[4][4];              // output row: the row map's entry, or (unmapped) the row itself; < 0: nothing to store
+        if (mapped) {                 // (the test outside the loops: inside, hipcc makes it a scalar branch per row)
+            const int* mp = reinterpret_cast<const int*>(cst + atmvfi::gemm_const_floats(BN)) + 64 * wm + g;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int m = mrow + 16 * i + 4 * q;
-                ro[i][q] = m < M ? m : -1;
-                if (mapped) {
-                    const int e = reinterpret_cast<const int*>(cst + atmvfi::gemm_const_floats(BN))[64 * wm + g + 16 * i + 4 * q];
-                    ro[i][q] = m < M ? e : -1;
+                for (int q = 0; q < 4; ++q) ro[i][q] = (mrow + 16 * i + 4 * q) < M ? mp[16 * i + 4 * q] : -1;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int m = mrow + 16 * i + 4 * q;
+                    ro[i][q] = m < M ? m : -1;
                 }
-            }
-        const bool vec_res = a.residual && (a.Cout & 3) == 0 && a.mode != ATMVFI_GEMM_DECONV;
+        }
+        const bool vec_res = !CONVM && a.residual && (a.Cout & 3) == 0 && a.mode != ATMVFI_GEMM_DECONV;
         f32x4 res[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -496,7 +508,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmDev a) {
                     v.z = v.z > 0.f ? v.z : pvec.z * v.z;
                     v.w = v.w > 0.f ? v.w : pvec.w * v.w;
                 }
-                return v + res[i][q];
+                if constexpr (CONVM) return v;           // convolutions have no residual operand
+                else return v + res[i][q];
             };
             if (a.mode != ATMVFI_GEMM_DECONV && !a.out_hi) {
                 // fp32 rows (qkv, fc1, proj with its row map and residual, fc2, fusion projections; convolutions)
@@ -516,21 +529,24 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmDev a) {
                 const unsigned rpg = a.out_rpg > 0 ? (unsigned)a.out_rpg : 0x7fffffffu;
                 const RowSink sink{nullptr, 0, a.out_hi, a.out_lo, a.out_plane_rows};
                 const bool col_ok = nb < a.Cout;
-                const bool f32_too = a.out != nullptr;
+                auto rows = [&](auto f32_tag) {
+                    constexpr bool F32 = decltype(f32_tag)::value;
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f32x4 v = finish(i, q);
-                        const unsigned rr = ro[i][q] < 0 ? 0u : (unsigned)ro[i][q];
-                        const unsigned gi = rr / rpg;
-                        const long long prow = rr - gi * rpg;
-                        const long long off = gi * a.out_gstride + prow * (long long)a.out_ld;
-                        if (ro[i][q] >= 0 && col_ok) {
-                            if (f32_too) *reinterpret_cast<f32x4*>(a.out + off + nb) = v;
-                            sink_store4(sink, prow, a.out_c0 + (int)gi * a.out_gc + nb, v);
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4 v = finish(i, q);
+                            const unsigned rr = ro[i][q] < 0 ? 0u : (unsigned)ro[i][q];
+                            const unsigned gi = rr / rpg;
+                            const long long prow = rr - gi * rpg;
+                            if (ro[i][q] >= 0 && col_ok) {
+                                if constexpr (F32) *reinterpret_cast<f32x4*>(a.out + gi * a.out_gstride + prow * (long long)a.out_ld + nb) = v;
+                                sink_store4(sink, prow, a.out_c0 + (int)gi * a.out_gc + nb, v);
+                            }
                         }
-                    }
+                };
+                if (a.out) rows(std::true_type{});
+                else rows(std::false_type{});
             } else {
                 // ConvTranspose2d 2x2 / stride 2 into a plane sink (decoder and U-Net stages): column -> (position, channel) is a
                 // lane constant; the lane's rows are 4 input pixels apart: (image, y, x) of the first by division, the others by
@@ -584,11 +600,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmDev a) {
             ++ntile;
         }
 #endif
-        // the barrier that closes the other group's current phase (the first group's epilogue ran beside the second group's last
-        // MFMA phase, the second group's beside the first k-step's read phase of the next tile); after the last tile only the
-        // first group still owes one
-        if (has_next || grp == 0) __builtin_amdgcn_s_barrier();
         if (!has_next) break;
+        if (grp == 1) __builtin_amdgcn_s_barrier();          // the second group drops one phase behind again
         vb = nxt;
         m0 = nm0;
         n0 = nn0;
