@@ -430,7 +430,23 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmDev a) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int q = 0; q < 4; ++q) res[i][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (vec_res) {
+        if (vec_res && a.fit32 && m0 + BM <= M) {
+            // (all rows live: 32-bit offsets from a scalar base, stepped by 4 rows)
+            const unsigned char* rb = reinterpret_cast<const unsigned char*>(a.residual);
+            unsigned voff = nb < a.Cout ? ((unsigned)mrow * (unsigned)a.res_ld + (unsigned)nb) * 4u : 0u;
+            const unsigned step = nb < a.Cout ? (unsigned)a.res_ld * 16u : 0u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    res[i][q] = *reinterpret_cast<const f32x4*>(rb + voff);
+                    voff += step;
+                }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(res[i][q]));
+        } else if (vec_res) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -511,7 +527,22 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmDev a) {
                 if constexpr (CONVM) return v;           // convolutions have no residual operand
                 else return v + res[i][q];
             };
-            if (a.mode != ATMVFI_GEMM_DECONV && !a.out_hi) {
+            if (a.mode != ATMVFI_GEMM_DECONV && !a.out_hi && a.fit32 && m0 + BM <= M) {
+                // fp32 rows, every row of the tile live, no map: one 32-bit byte offset per lane, stepped by 4 rows -- a row costs
+                // its arithmetic (bias, residual) and one add; stores with a scalar base
+                if (nb < a.Cout) {
+                    unsigned char* ob = reinterpret_cast<unsigned char*>(a.out);
+                    unsigned voff = ((unsigned)mrow * (unsigned)a.out_ld + (unsigned)nb) * 4u;
+                    const unsigned step = (unsigned)a.out_ld * 16u;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            *reinterpret_cast<f32x4*>(ob + voff) = finish(i, q);
+                            voff += step;
+                        }
+                }
+            } else if (a.mode != ATMVFI_GEMM_DECONV && !a.out_hi) {
                 // fp32 rows (qkv, fc1, proj with its row map and residual, fc2, fusion projections; convolutions)
                 float* obase = a.out + nb;
                 const bool col_ok = nb < a.Cout;
@@ -631,6 +662,8 @@ static int launch_pp(const GemmDev& d, int ngemm, hipStream_t s) {
     if (CONVM) ATMVFI_REQUIRE(d.H < 32768 && d.W < 32768, ATMVFI_EINVAL, "gemm_pp: CONV mode packs (y, x) into 16 bits each");
     GemmDev dd = d;
     dd.dbg = 0;
+    dd.fit32 = d.out && !d.out_row_map && d.out_rpg == 0 && d.mode != ATMVFI_GEMM_DECONV && (d.M + 1) * (long long)d.out_ld * 4 < (1ll << 32) &&
+               (!d.residual || (d.M + 1) * (long long)d.res_ld * 4 < (1ll << 32));
 #ifdef ATMVFI_STAMP
     dd.stamp = g_pp_stamp;
 #endif
