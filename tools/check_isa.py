@@ -83,6 +83,48 @@ def check_planes(asm_text):
     return problems
 
 
+def check_pp(asm_text):
+    """gemm_pp_kernel<CONVM>: every MFMA phase (between s_setprio 1 and s_setprio 0) holds exactly 48 MFMAs and nothing that
+    touches memory; every read phase in front of one (back to the previous s_barrier) holds the 16 fragment reads; no register is
+    spilled (a scratch reload brings a compiler-made s_waitcnt vmcnt(0) with it, which would drain the DMA ring); and the only
+    vmcnt waits between the first and the last MFMA phase are the kernel's own (inline asm): vmcnt(6), vmcnt(8), and vmcnt(0) at
+    the places the source puts it (last k-step but one of a last tile; the second group before its epilogue)."""
+    problems = []
+    lines = asm_text.splitlines()
+    for tag in ("Lb0", "Lb1"):
+        starts = [i for i, l in enumerate(lines) if re.match(rf"^_ZN\S*gemm_pp_kernelI{tag}E\S*:", l)]
+        if not starts:
+            problems.append(f"gemm_pp<{tag}>: kernel not found")
+            continue
+        end = next(i for i in range(starts[0], len(lines)) if "s_endpgm" in lines[i])
+        body = [l.split(";")[0] for l in lines[starts[0]:end]]
+        if any("scratch_" in l for l in body):
+            problems.append(f"gemm_pp<{tag}>: register spill (scratch access)")
+        p1 = [i for i, l in enumerate(body) if re.search(r"\bs_setprio 1\b", l)]
+        p0 = [i for i, l in enumerate(body) if re.search(r"\bs_setprio 0\b", l)]
+        if len(p1) != len(p0) or len(p1) < 3:
+            problems.append(f"gemm_pp<{tag}>: expected matching s_setprio pairs around >= 3 MFMA phases, found {len(p1)} / {len(p0)}")
+            continue
+        for a, b in zip(p1, p0):
+            seg = body[a + 1:b]
+            n_mfma = sum("v_mfma_f32_16x16x32_f16" in l for l in seg)
+            mem = [l for l in seg if re.search(r"\b(ds_|global_|buffer_|flat_|scratch_)", l)]
+            if n_mfma != 48 or mem or any(re.search(r"\bs_cbranch|\bs_branch", l) for l in seg):
+                problems.append(f"gemm_pp<{tag}>: MFMA phase at line {a}: {n_mfma} MFMAs, {len(mem)} memory instructions")
+            bar = max(i for i in range(a) if re.search(r"\bs_barrier\b", body[i]))           # the barrier that opens the MFMA phase
+            prev = max([i for i in range(bar) if re.search(r"\bs_barrier\b|\bs_setprio 0\b", body[i])] + [0])
+            rd = body[prev:bar]
+            if sum("ds_read_b128" in l for l in rd) < 16 or not any("lgkmcnt(0)" in l for l in rd):
+                problems.append(f"gemm_pp<{tag}>: read phase before line {a}: fewer than 16 fragment reads or no lgkmcnt(0)")
+        # compiler-made vmcnt waits inside the k-loop region: the kernel's own come from inline asm (marked ASMSTART / ASMEND)
+        raw = lines[starts[0]:end]
+        first, last = p1[0], p0[-1]
+        for i in range(first, last):
+            if re.search(r"s_waitcnt.*vmcnt", raw[i]) and "ASMSTART" not in raw[i - 1]:
+                problems.append(f"gemm_pp<{tag}>: compiler-inserted '{raw[i].strip()}' inside the k-loop region (line {i})")
+    return problems
+
+
 def compile_asm(src, out):
     cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", f"-I{ROOT}/include",
            "-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", out]
@@ -94,6 +136,7 @@ def main():
     with tempfile.TemporaryDirectory() as td:
         problems = check(compile_asm("conv3x3_f16x3_row.hip", os.path.join(td, "row.s")))
         problems += check_planes(compile_asm("conv3x3_planes.hip", os.path.join(td, "planes.s")))
+        problems += check_pp(compile_asm("gemm_pp.hip", os.path.join(td, "pp.s")))
     for p in problems:
         print("ISA check:", p)
     print("ISA check: ok" if not problems else f"ISA check: {len(problems)} problem(s)")
