@@ -363,6 +363,43 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
     *reinterpret_cast<f16x8*>(lo + off) = l;
 }
 
+// 1x1 convolution with at most 8 output channels on split-plane input: the read-out of a motion MLP (nn.Conv2d(hidden, 5, 1),
+// network_base.py:158,195).  On the GEMM a 128-column tile is 96 % padding and the launch costs a whole tile's latency (0.03-0.05 ms
+// for 50 MFLOP); here a lane owns a pixel row, reconstructs x = hi + lo' / 1024 (exact in fp32) from its 64-byte chunk rows --
+// consecutive lanes read consecutive rows: 4 KiB per wave and chunk -- and accumulates against weights that arrive as scalar
+// loads (wave-uniform).  fp32 FMAs on the full fp32 weights: at least as accurate as the f16x3 product it replaces.
+template <int NO>
+__global__ __launch_bounds__(256) void head1x1_planes_kernel(const _Float16* __restrict__ hi, const _Float16* __restrict__ lo, long long plane_rows,
+                                                             long long rows, int cin, const float* __restrict__ w, const float* __restrict__ bias,
+                                                             float* __restrict__ out, int out_ld, int cout) {
+    const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    float acc[NO];
+#pragma unroll
+    for (int n = 0; n < NO; ++n) acc[n] = (bias && n < cout) ? bias[n] : 0.f;
+    const int chunks = (cin + 31) >> 5;
+    for (int ch = 0; ch < chunks; ++ch) {
+        const f16x8* ph = reinterpret_cast<const f16x8*>(hi + ((long long)ch * plane_rows + row) * 32);
+        const f16x8* pl = reinterpret_cast<const f16x8*>(lo + ((long long)ch * plane_rows + row) * 32);
+        f16x8 h[4], l[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { h[v] = ph[v]; l[v] = pl[v]; }
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = ch * 32 + v * 8 + e;
+                const int cw = c < cin ? c : cin - 1;            // pad channels of the last chunk are zero in the planes
+                const float x = __builtin_fmaf((float)l[v][e], LO_UNSCALE, (float)h[v][e]);
+#pragma unroll
+                for (int n = 0; n < NO; ++n) acc[n] = __builtin_fmaf(w[(n < cout ? n : 0) * cin + cw], x, acc[n]);
+            }
+    }
+#pragma unroll
+    for (int n = 0; n < NO; ++n)
+        if (n < cout) out[row * out_ld + n] = acc[n];
+}
+
 template <int WGM, int WGN, bool CONVM>
 int launch_split(const GemmDev& d, int ngemm, hipStream_t s) {
     constexpr int BM = 64 * WGM, BN = 64 * WGN;
@@ -410,4 +447,21 @@ extern "C" int atmvfi_split_planes_at(const float* in, int in_ld, int64_t M, int
 extern "C" int atmvfi_split_planes(const float* in, int in_ld, int64_t M, int C, const float* prelu, void* hi, void* lo, int plane_rows,
                                    void* stream) {
     return atmvfi_split_planes_at(in, in_ld, M, C, prelu, hi, lo, plane_rows, 0, 32, stream);
+}
+
+extern "C" int atmvfi_head1x1_planes(const void* in_hi, const void* in_lo, int64_t plane_rows, int64_t rows, int Cin, const float* weight,
+                                     const float* bias, int Cout, float* out, int out_ld, void* stream) {
+    ATMVFI_REQUIRE(in_hi && in_lo && weight && out, ATMVFI_EINVAL, "head1x1_planes: null pointer");
+    ATMVFI_REQUIRE(rows > 0 && plane_rows >= rows && Cin > 0 && Cout >= 1 && Cout <= 8 && out_ld >= Cout, ATMVFI_EINVAL,
+                   "head1x1_planes: rows %lld (plane rows %lld), Cin %d, 1 <= Cout %d <= 8 <= ... out_ld %d", (long long)rows,
+                   (long long)plane_rows, Cin, Cout, out_ld);
+    ATMVFI_REQUIRE(atmvfi::aligned16(in_hi) && atmvfi::aligned16(in_lo), ATMVFI_EALIGN, "head1x1_planes: planes must be 16-byte aligned");
+    const unsigned blocks = (unsigned)((rows + 255) / 256);
+    if (Cout <= 5)
+        hipLaunchKernelGGL(head1x1_planes_kernel<5>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)in_hi, (const _Float16*)in_lo,
+                           (long long)plane_rows, (long long)rows, Cin, weight, bias, out, out_ld, Cout);
+    else
+        hipLaunchKernelGGL(head1x1_planes_kernel<8>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)in_hi, (const _Float16*)in_lo,
+                           (long long)plane_rows, (long long)rows, Cin, weight, bias, out, out_ld, Cout);
+    return atmvfi::check_launch("head1x1_planes");
 }

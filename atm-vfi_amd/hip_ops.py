@@ -75,6 +75,7 @@ SIGNATURES = {
     "atmvfi_pack_weight_conv3x3": (c_i, [c_f, c_f, c_f, c_i, c_i, c_f]),
     "atmvfi_conv3x3_f16x3": (c_i, [c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_l, c_f, c_i, c_i, c_f]),
     "atmvfi_conv3x3_planes": (c_i, [c_f, c_f, c_l, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_l, c_i, c_f, c_i, c_i, c_f]),
+    "atmvfi_head1x1_planes": (c_i, [c_f, c_f, c_l, c_l, c_i, c_f, c_f, c_i, c_f, c_i, c_f]),
     "atmvfi_conv3x3_planes2": (c_i, [c_f, c_f, c_l, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_l, c_i, c_f, c_f, c_f, c_l, c_i, c_i, c_i, c_f]),
     "atmvfi_layernorm": (c_i, [c_f, c_i, c_l, c_i, c_f, c_f, c_i, c_f, c_f, c_l, c_i, c_f, c_f, c_i, c_f]),
     "atmvfi_dwconv3x3_gelu": (c_i, [c_f, c_i, c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f]),
@@ -409,6 +410,18 @@ class HipOps:
                   planes.ld_rows if planes is not None else 0, planes_c0, _ptr(planes_prelu) if planes is not None else None,
                   planes2.t[0].data_ptr() if planes2 is not None else None, planes2.t[1].data_ptr() if planes2 is not None else None,
                   planes2.ld_rows if planes2 is not None else 0, planes2_c0, out_cmin, wn, self._stream())
+
+    def head1x1_planes(self, x: Planes, n: int, h: int, wd: int, w: PackedWeight, out, bias=None):
+        """nn.Conv2d(Cin, Cout <= 8, 1) on split-plane input (the 5-channel read-out of a motion MLP): one lane per pixel row, fp32 FMAs."""
+        old, on, oh, ow, oc = nhwc_view(out, "head1x1_planes.out")
+        if w.mode != GEMM_CONV or w.kh != 1 or w.cout > 8 or (on, oh, ow, oc) != (n, h, wd, w.cout) or x.rows != n * h * wd or w.cin > x.chunks * 32:
+            raise ValueError(f"head1x1_planes: weight ({w.cout},{w.cin},{w.kh},{w.kw}) / out {tuple(out.shape)} / planes [{x.rows},{x.c}] mismatch")
+        wt = w.orig.detach()
+        if not wt.is_contiguous():
+            wt = wt.contiguous()
+        meta = {"flops": 2.0 * n * h * wd * w.cout * w.cin, "bytes": 4.0 * n * h * wd * (w.cin + w.cout), "shape": f"M{n * h * wd} N{w.cout} K{w.cin}"}
+        self._run("head1x1_planes", meta, self.lib.atmvfi_head1x1_planes, x.t[0].data_ptr(), x.t[1].data_ptr(), x.ld_rows, n * h * wd, w.cin,
+                  wt.data_ptr(), _ptr(bias), w.cout, out.data_ptr(), old, self._stream())
 
     def conv_planes(self, x: Planes, n: int, h: int, wd: int, w: PackedWeight, out=None, stride=1, pad=1, dil=1, bias=None, prelu=None,
                     sink: Optional[Planes] = None, sink_c0: int = 0, in_chunk0: int = 0, x2: Optional[Planes] = None, x2_chunk0: int = 0,

@@ -567,7 +567,9 @@ class Network(BlockRunner, nn.Module):
 
     def _head1x1(self, ops, P, p, t2, b, h, w, out):
         """The 1x1 head of a motion MLP (network_base.py:158,195): on the hidden map's planes when the branch left it there."""
-        if isinstance(t2, Planes):
+        if isinstance(t2, Planes) and P[f"pk:{p}.weight"].cout <= 8 and hasattr(ops, "head1x1_planes"):
+            ops.head1x1_planes(t2, b, h, w, P[f"pk:{p}.weight"], out, bias=P[f"{p}.bias"])       # 5 channels: a lane per pixel, no GEMM tile
+        elif isinstance(t2, Planes):
             ops.conv_planes(t2, b, h, w, P[f"pk:{p}.weight"], out=out, stride=1, pad=0, dil=1, bias=P[f"{p}.bias"])
         else:
             self._conv_plain(ops, P, p, t2, out, pad=0)

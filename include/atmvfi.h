@@ -120,6 +120,13 @@ typedef struct atmvfi_gemm_params {
 
 int atmvfi_gemm(const atmvfi_gemm_params* p, void* stream);
 
+/* 1x1 convolution with 1 <= Cout <= 8 output channels on split-plane input: the read-out nn.Conv2d(hidden, 5, 1) of the motion MLPs
+ * (network_base.py:158,195 local_motion_mlp[2] / global_motion_mlp[2]).  in_hi / in_lo: chunk-major planes of `rows` pixel rows
+ * (plane_rows rows per 32-channel chunk); weight: the layer's fp32 [Cout][Cin] (the nn.Conv2d weight as it is); out: fp32 rows,
+ * out_ld floats apart, Cout written per row.  fp32 FMAs on x = hi + lo'/1024. */
+int atmvfi_head1x1_planes(const void* in_hi, const void* in_lo, int64_t plane_rows, int64_t rows, int Cin, const float* weight,
+                          const float* bias, int Cout, float* out, int out_ld, void* stream);
+
 /* fp32 rows [M, C] (row stride in_ld floats) -> the two fp16 planes of the split-plane format, hi = fp16(x),
    lo = fp16((x - hi) * 1024), both saturating, chunk major: element (row, c) at ((c / 32) * plane_rows + row) * 32 + c % 32
    (each plane holds ceil(C / 32) * plane_rows * 32 halves; the pad channels of the last chunk are written as zero).

@@ -829,6 +829,30 @@ def test_conv_from_two_plane_sources(hip, dev):
     assert torch.equal(y0, y1), maxdiff(y0, y1)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 68, 120, 576, 5), (2, 17, 23, 768, 5), (1, 9, 11, 100, 8), (1, 5, 7, 40, 1)], ids=lambda s: f"{s[3]}to{s[4]}")
+def test_head1x1_planes(shape, hip, dev):
+    """The 5-channel read-out of a motion MLP (network_base.py:158,195) on split-plane input: fp32 FMAs per pixel row against fp64, and
+    against the GEMM path it replaces (which multiplies the same hi / lo' operands on the f16x3 MFMA)."""
+    n, h, w, cin, cout = shape
+    g = torch.Generator().manual_seed(cin + cout)
+    x = rnd(g, n * h * w, cin, scale=2.0).to(dev)
+    wt = rnd(g, cout, cin, 1, 1, scale=1.0 / cin ** 0.5).to(dev)
+    b = rnd(g, cout, scale=0.5).to(dev)
+    pw = hip.pack_weight(GEMM_CONV, wt)
+    pl = hip_ops.Planes.alloc(n * h * w, cin, dev)
+    hip.split_planes(x, pl)
+    buf = torch.full((n, h, w, 8), 3.0, device=dev)
+    hip.head1x1_planes(pl, n, h, w, pw, buf[..., :cout], bias=b)
+    ref_buf = torch.full((n, h, w, 8), 3.0, device=dev)
+    hip.conv_planes(pl, n, h, w, pw, out=ref_buf[..., :cout], stride=1, pad=0, dil=1, bias=b)
+    torch.cuda.synchronize()
+    ref = (x.double() @ wt.reshape(cout, cin).double().t() + b.double()).reshape(n, h, w, cout)
+    assert (buf[..., :cout].double() - ref).abs().max().item() <= 2e-5
+    assert (buf[..., :cout] - ref_buf[..., :cout]).abs().max().item() <= 2e-5
+    assert torch.all(buf[..., cout:] == 3.0)
+
+
 PP_CASES = [
     # kind, rows / geometry, Cin, Cout, extras -- every one with several tiles per workgroup of the persistent grid (> 256 tiles)
     ("linear", 70001, 96, 384, dict(bias=True, res=True)),            # 3 k-steps, ragged last row tile, 3 column blocks
