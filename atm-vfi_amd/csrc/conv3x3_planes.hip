@@ -32,7 +32,7 @@
 static unsigned long long* g_planes_stamp = nullptr;
 extern "C" void atmvfi_debug_set_planes_stamp_buffer(void* p) { g_planes_stamp = (unsigned long long*)p; }
 #define PDBG(bit) ((a.dbg & (bit)) != 0)
-#define PSTAMP_DECL unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
+#define PSTAMP_DECL unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_epi = 0; unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
 #define PSTAMP(k) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); st_[k] += t1_ - st_t0; st_t0 = t1_; __builtin_amdgcn_sched_barrier(0); }
 #else
 #define PDBG(bit) false
@@ -66,6 +66,7 @@ struct Conv3PDev {
     int out_c02;
     int out_cmin;               // fp32 output: only channels >= out_cmin (multiple of 4) are stored
     int tiles_x, tiles_y, nblocks, tchunk;
+    int vblocks;                // virtual blocks (tiles incl. XCD padding) walked by the persistent grid
     unsigned long long* stamp;  // diagnostic builds only (ATMVFI_STAMP)
     int dbg;                    // diagnostic builds only: ATMVFI_P3_DBG bits switch pieces of the loop off (wrong results, timing only)
 };
@@ -77,7 +78,7 @@ constexpr int HALO_BYTES = 2 * HALO_LO;
 
 // weight ring depth: as many k-steps as fit beside the two halo buffers and the epilogue constants in 160 KiB, at most 5
 constexpr int ring_slots(int wn) {
-    const int free_bytes = 160 * 1024 - 2 * HALO_BYTES - 2048;
+    const int free_bytes = 160 * 1024 - 2 * HALO_BYTES - 2 * 1024 - 1024;     // two halo buffers, two buffers of epilogue constants (<= 1 KiB each), 1 KiB slack
     const int n = free_bytes / (2 * 16 * wn * 64);
     return n > 5 ? 5 : n;            // the static vmcnt counts of the k-loop assume a lookahead of at most 4 k-steps
 }
@@ -95,10 +96,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
     constexpr int SW = (2 * WN + 7) / 8;                // weight pieces per wave and k-step (some waves one fewer)
     constexpr int NB = ring_slots(WN);                  // weight ring slots (k-steps)
     constexpr int LA = NB - 1;                          // k-steps between a slot's DMA issue and its first read
+    constexpr int CSTF = epilogue_const_floats(BN);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned halo0 = lds_offset(smem);                        // two halo buffers
     const unsigned ring0 = halo0 + 2 * HALO_BYTES;                  // NB weight slots
-    float* cst = reinterpret_cast<float*>(smem + 2 * HALO_BYTES + NB * WSLOT);
+    float* cst_base = reinterpret_cast<float*>(smem + 2 * HALO_BYTES + NB * WSLOT);     // two buffers of epilogue constants
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -107,71 +109,105 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
     const int r = lane & 15;
     const int g = lane >> 4;
 
-    // XCD-aware tile order (conv3x3_f16x3_row.hip): column blocks of one tile back to back on one XCD, each XCD walking a
-    // contiguous eighth of the tiles in groups of 8 tile rows, column by column
-    const int slot = blockIdx.x >> 3;
-    const int sgrp = slot / a.nblocks;
-    const int nblk = slot - sgrp * a.nblocks;
-    int L = (blockIdx.x & 7) * a.tchunk + sgrp;
+    // PERSISTENT GRID over the XCD-aware tile order (conv3x3_f16x3_row.hip): virtual block v -> column blocks of one tile back to
+    // back on one XCD, each XCD walking a contiguous eighth of the tiles in groups of 8 tile rows, column by column.  Workgroup b
+    // walks v = b, b + grid, ... (grid a multiple of 8: it stays on its XCD; the tile index only grows along the walk, so the first
+    // empty block ends it).  The DMA streams keep flowing across tiles: the slots that re-sent the last weights / the current halo
+    // "into buffers nobody reads" at the end of a tile now carry the NEXT tile's first k-steps and its first halo, so a tile's
+    // prologue (first DMA round trip + address arithmetic, 6.5 % of a 101-wide full-resolution tile) runs under the previous
+    // tile's last k-steps.
+    const int grid = gridDim.x;
     const int per_img = a.tiles_x * a.tiles_y;
-    if (L >= a.N * per_img) return;
-    const int img = L / per_img;
-    L -= img * per_img;
-    const int tgrp = L / (8 * a.tiles_x);
-    const int rem = L - tgrp * 8 * a.tiles_x;
-    const int rows_here = (a.tiles_y - 8 * tgrp) < 8 ? a.tiles_y - 8 * tgrp : 8;
-    const int txb = rem / rows_here;
-    const int tyb = 8 * tgrp + (rem - txb * rows_here);
-    const int ox0 = txb * TW, oy0 = tyb * 16;
-    const int n0 = nblk * BN;
+    auto decode = [&](int v, int& t_img, int& t_ox0, int& t_oy0, int& t_n0) -> bool {
+        const int slot = v >> 3;
+        const int sgrp = slot / a.nblocks;
+        const int nblk = slot - sgrp * a.nblocks;
+        int L = (v & 7) * a.tchunk + sgrp;
+        if (v >= a.vblocks || L >= a.N * per_img) return false;
+        t_img = L / per_img;
+        L -= t_img * per_img;
+        const int tgrp = L / (8 * a.tiles_x);
+        const int rem = L - tgrp * 8 * a.tiles_x;
+        const int rows_here = (a.tiles_y - 8 * tgrp) < 8 ? a.tiles_y - 8 * tgrp : 8;
+        const int txb = rem / rows_here;
+        const int tyb = 8 * tgrp + (rem - txb * rows_here);
+        t_ox0 = txb * TW;
+        t_oy0 = tyb * 16;
+        t_n0 = nblk * BN;
+        return true;
+    };
+    int vb = blockIdx.x;
+    int img, ox0, oy0, n0;                       // the tile of the MFMAs / of the epilogue
+    if (!decode(vb, img, ox0, oy0, n0)) return;
+    int nimg = 0, nox0 = 0, noy0 = 0, nn0 = 0;   // this workgroup's next tile
+    bool has_next = decode(vb + grid, nimg, nox0, noy0, nn0);
 
     // ---- halo pieces of this wave: k = wave + 8 s, s = 0..5 (k < 42): pieces 0..20 = hi plane, 21..41 = lo plane, each plane
     // a linear image of 336 pixel rows x 64 B (324 used).  Lane -> pixel row hp = 16 (k % 21) + lane / 4, physical 16-byte slot
     // lane & 3; the slot swizzle goes on the SOURCE (the DMA destination is lane-linear).  hoff = byte offset from the plane base
-    // of the chunk; pixels outside the image (and the 12 pad rows) read the planes' zero row N*H*W.
+    // of the chunk; pixels outside the image (and the 12 pad rows) read the planes' zero row N*H*W.  hoff belongs to the tile
+    // whose halo is being put in flight: the tile of the MFMAs or, towards its end, the next one.
     unsigned hoff[6];
     const long long zero_row = (long long)a.N * a.H * a.W;
+    auto setup_halo = [&](int t_img, int t_ox0, int t_oy0) {
+        // (the lane index laundered through an empty asm: the per-lane halo coordinates of the six pieces are tile-invariant, and
+        // hipcc otherwise hoists them out of the tile loop -- 30 more live registers across the k-loop, spills at 8 n-tiles)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
 #pragma unroll
-    for (int s = 0; s < 6; ++s) {
-        int k = wave + 8 * s;
-        if (k >= 2 * HALO_PLANE_PIECES) k -= 8;      // waves 2..7 have no sixth piece: they send their fifth twice (see below)
-        const int kp = k >= HALO_PLANE_PIECES ? k - HALO_PLANE_PIECES : k;
-        const int hp = 16 * kp + (lane >> 2);
-        const int hy = hp / HW_, hx = hp - hy * HW_;
-        const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
-        const bool ok = hp < HALO_PIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-        const int ls = (lane & 3) ^ swz64(hp);
-        const long long row = ok ? ((long long)img * a.H + iy) * a.W + ix : zero_row;
-        hoff[s] = (unsigned)(row * 64 + ls * 16);
-    }
+        for (int s = 0; s < 6; ++s) {
+            int k = wave + 8 * s;
+            if (k >= 2 * HALO_PLANE_PIECES) k -= 8;      // waves 2..7 have no sixth piece: they send their fifth twice (see below)
+            const int kp = k >= HALO_PLANE_PIECES ? k - HALO_PLANE_PIECES : k;
+            const int hp = 16 * kp + (ln >> 2);
+            const int hy = hp / HW_, hx = hp - hy * HW_;
+            const int iy = t_oy0 - 1 + hy, ix = t_ox0 - 1 + hx;
+            const bool ok = hp < HALO_PIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const int ls = (ln & 3) ^ swz64(hp);
+            const long long row = ok ? ((long long)t_img * a.H + iy) * a.W + ix : zero_row;
+            hoff[s] = (unsigned)(row * 64 + ls * 16);
+        }
+    };
+    setup_halo(img, ox0, oy0);
     const long long chunk_bytes = a.in_rows * 64;
     // ---- DMA schedule.  Everything in the k-loop is branch-free and the same for every wave, so that the vmcnt waits are plain
     // immediates: a taken scalar branch costs 20-40 cycles and the first version of this loop had ten per read phase (validity
     // of a piece, end of the k-steps, a decision tree around s_waitcnt: 230 ticks of a 900-tick phase, tools/stamp_conv3p.py).
     //   * weights: SW pieces per wave and k-step; piece idx = wave + 8 s -> plane idx / WN, row group idx % WN (16 rows x 64 B =
     //     one contiguous KiB of the k-step-major planes).  A wave without a piece s (idx >= 2 WN) sends its piece s - 1 again:
-    //     same bytes to the same place.  Past the last k-step the source stops advancing: the last k-step's weights are sent again
-    //     into ring slots nobody reads any more.
-    //   * halo of the next chunk: piece wave + 8 t in k-step t = 0..5; without a next chunk the pieces of the current chunk go to
-    //     the other (idle) buffer.
+    //     same bytes to the same place.  Behind a tile's last k-step come the first k-steps of the workgroup's next tile (or,
+    //     after the last tile, the last k-step again into ring slots nobody reads any more).
+    //   * halo of the next chunk: piece wave + 8 t in k-step t = 0..5 (tail k-steps 0 and 1: three pieces each); behind a tile's
+    //     last chunk comes chunk 0 of the next tile (after the last tile: the current chunk again into the idle buffer).
     // LDS row i of a 16-row group <- weight row 8 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3): rows 4g..4g+3 of the MFMA result are
     // then channels {0, 8, 4, 12}[g] .. + 3 (see the epilogue)
     const int wrow = 8 * ((lane >> 4) & 1) + 4 * (lane >> 5) + ((lane >> 2) & 3);
     const unsigned wlane = (unsigned)(wrow * 64 + (((lane & 3) ^ swz64(lane >> 2)) << 4));
     const long long step_bytes = (long long)a.wrows * 64;
     const unsigned char* wsrc[SW];          // wave-uniform source of piece s at the next k-step to issue
+    const unsigned char* wnext[SW];         // the same at k-step 0 of the workgroup's next tile
     int wdst[SW];                           // its byte offset inside a ring slot
-#pragma unroll
-    for (int s = 0; s < SW; ++s) {
+    auto weight_base = [&](int s, int t_n0) -> const unsigned char* {
         int idx = wave + 8 * s;
         if (idx >= 2 * WN) idx -= 8;
         const int ic = idx >= 0 ? idx : 0;                       // (WN < 4: waves >= 2 WN have no piece at all and send piece 0)
         const int icc = ic < 2 * WN ? ic : 0;
         const int plane = icc >= WN ? 1 : 0;
         const int j = icc - plane * WN;
-        int rg = n0 + 16 * j;
+        int rg = t_n0 + 16 * j;
         if (rg >= a.wrows) rg = a.wrows - 16;                    // row groups past the packed rows: columns never stored
-        wsrc[s] = reinterpret_cast<const unsigned char*>(plane ? a.w_lo : a.w_hi) + (long long)rg * 64;
+        return reinterpret_cast<const unsigned char*>(plane ? a.w_lo : a.w_hi) + (long long)rg * 64;
+    };
+#pragma unroll
+    for (int s = 0; s < SW; ++s) {
+        int idx = wave + 8 * s;
+        if (idx >= 2 * WN) idx -= 8;
+        const int ic = idx >= 0 ? idx : 0;
+        const int icc = ic < 2 * WN ? ic : 0;
+        const int plane = icc >= WN ? 1 : 0;
+        const int j = icc - plane * WN;
+        wsrc[s] = weight_base(s, n0);
+        wnext[s] = weight_base(s, nn0);
         wdst[s] = (plane * BN + 16 * j) * 64;
     }
 
@@ -180,16 +216,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
     const int nk = 9 * nfull + (a.tail ? 3 : 0);
 
     int wr_off = 0;                       // ring slot (byte offset) the next weight issue goes to
-    int kleft = nk - 1;                   // k-steps after the one whose weights are issued next
+    int kleft = nk - 1;                   // k-steps of the issuer's tile after the one whose weights are issued next
     auto issue_weights = [&]() {          // weights of the next k-step -> next ring slot
         unsigned char* dst = smem + 2 * HALO_BYTES + wr_off;
-        const long long adv = kleft > 0 ? step_bytes : 0;
+        const bool more = kleft > 0;
 #pragma unroll
         for (int s = 0; s < SW; ++s) {
             dma16(wsrc[s] + wlane, dst + wdst[s]);
-            wsrc[s] += adv;
+            wsrc[s] = more ? wsrc[s] + step_bytes : (has_next ? wnext[s] : wsrc[s]);       // (scalar selects: no branch)
         }
-        --kleft;
+        kleft = more ? kleft - 1 : (has_next ? nk - 1 : 0);
         wr_off = wr_off + WSLOT == NB * WSLOT ? 0 : wr_off + WSLOT;
     };
     const unsigned char* hsrc_hi = reinterpret_cast<const unsigned char*>(a.in_hi);      // plane bases of the chunk whose halo is issued next
@@ -201,15 +237,23 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
         if (S == 5 && k >= 2 * HALO_PLANE_PIECES) k -= 8;
         dma16((k >= HALO_PLANE_PIECES ? hsrc_lo : hsrc_hi) + hoff[S], smem + hbuf + k * 1024);
     };
+    int chunks_left = nchunks - 1;        // chunks of the issuer's tile after the one whose halo is issued next
+    // all six pieces of a chunk are out: on to the tile's next chunk, to chunk 0 of the next tile, or (after the last tile) nowhere
+    auto halo_advance = [&]() {
+        if (chunks_left > 0) {
+            hsrc_hi += chunk_bytes;
+            hsrc_lo += chunk_bytes;
+            --chunks_left;
+        } else if (has_next) {
+            hsrc_hi = reinterpret_cast<const unsigned char*>(a.in_hi);
+            hsrc_lo = reinterpret_cast<const unsigned char*>(a.in_lo);
+            setup_halo(nimg, nox0, noy0);
+            chunks_left = nchunks - 1;
+        }
+        hbuf = HALO_BYTES - hbuf;
+    };
 
     f32x4 acc[2][WN], cor[2][WN];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            cor[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
 
     // tail k-steps: lane group g reads slot 0 of the halo pixel of tap 4t + g (taps 9..11 meet zero weights: tap 8 again)
     int dtail = 0;
@@ -221,20 +265,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
     }
 
     PSTAMP_DECL
-    // ---- prologue: epilogue constants, halo of chunk 0, weights of k-steps 0 .. LA-1 ----
-    dma_epilogue_consts<BN>(a.bias, a.prelu, n0, cst, wave, lane, [&](int col) { return col < a.Cout ? col : -1; });
+    // ---- prologue of the first tile: epilogue constants, halo of chunk 0, weights of k-steps 0 .. LA-1; everything lands before
+    // the first read (later tiles: the wait at the tile boundary), so the first LA - 1 k-steps of a tile wait for nothing ----
+    dma_epilogue_consts<BN>(a.bias, a.prelu, n0, cst_base, wave, lane, [&](int col) { return col < a.Cout ? col : -1; });
     static_for<0, 6>([&](auto sc) { issue_halo(sc); });
-    int chunks_left = nchunks - 1;        // chunks after the one whose halo is issued next
-    {
-        const long long adv = chunks_left > 0 ? chunk_bytes : 0;
-        hsrc_hi += adv;
-        hsrc_lo += adv;
-        --chunks_left;
-        hbuf = HALO_BYTES;
-    }
+    halo_advance();
 #pragma unroll
     for (int u = 0; u < LA; ++u) issue_weights();
-    wait_vm<(LA - 1) * SW>();             // everything up to the weights of k-step 0 has landed
+    wait_vm<0>();
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();          // the second group runs one phase behind
     PSTAMP(0)
@@ -250,11 +288,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
     for (int k = 0; k < 8; ++k) xa[k] = halo0 + (unsigned)(prow * 64 + ((g ^ swz64(prow + k)) << 4));
     int rd_off = 0;                       // ring slot (byte offset) of the k-step being read
     int hcur = 0;                         // halo buffer of the chunk being read
+    int seq = 0;                          // tiles done by this workgroup
 
-    // One k-step of one wave.  T = tap (regular chunk) or tail step.
-    auto kstep = [&](auto tc, auto tailc) {
+    // One k-step of one wave.  T = tap (regular chunk) or tail step; FIRST: the tile's first chunk.
+    auto kstep = [&](auto tc, auto tailc, auto firstc) {
         constexpr int T = decltype(tc)::value;
         constexpr bool TAIL = decltype(tailc)::value;
+        constexpr bool FIRST = decltype(firstc)::value;
         // ---------------- read phase ----------------
         if (PDBG(16)) {
             // (diagnostic: no fragment reads at all -- prices what the partner's LDS traffic costs the MFMA phase)
@@ -281,20 +321,34 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
         });
         rd_off = rd_off + WSLOT == NB * WSLOT ? 0 : rd_off + WSLOT;
         PSTAMP(1)
-        // DMA: weights LA k-steps ahead first, then one halo piece of the next chunk (k-steps 0..5 of a regular chunk): the wait
-        // for a k-step's weights then never covers the halo piece issued in the same phase (vmcnt retires in order, and the halo
-        // comes from HBM while the weights come from L2)
+        // DMA: weights LA k-steps ahead first, then the halo piece(s) of the next chunk (k-steps 0..5 of a regular chunk: one;
+        // tail k-steps 0 and 1: three -- a tile with a tail has no regular chunk left to carry the next tile's first halo): the
+        // wait for a k-step's weights then never covers the halo piece issued in the same phase (vmcnt retires in order, and the
+        // halo comes from HBM while the weights come from L2)
         if (!PDBG(2)) issue_weights();
         if constexpr (!TAIL && T < 6) {
             if (!PDBG(1)) issue_halo(std::integral_constant<int, T>{});
         }
+        if constexpr (TAIL && T < 2) {
+            if (!PDBG(1)) {
+                issue_halo(std::integral_constant<int, 3 * T>{});
+                issue_halo(std::integral_constant<int, 3 * T + 1>{});
+                issue_halo(std::integral_constant<int, 3 * T + 2>{});
+            }
+        }
         PSTAMP(2)
         // Own pieces of the next k-step landed, own fragment reads complete.  The weights of the next k-step were issued LA - 1
-        // read phases ago; behind them went SW weight pieces per phase and one halo piece in each of the phases t' = T+1-LA .. T
-        // of this chunk with 0 <= t' < 6 (phases of the previous chunk that far back carry none: LA <= 4).
-        {
-            constexpr int lo = T + 1 - LA > 0 ? T + 1 - LA : 0, hi = T < 5 ? T : 5;
-            constexpr int halos = (!TAIL && hi >= lo) ? hi - lo + 1 : 0;
+        // read phases ago; behind them went SW weight pieces per phase and the halo pieces of the phases t' = T+1-LA .. T of this
+        // chunk (phases of the previous chunk that far back carry none: LA <= 4; counting fewer than are behind is safe).
+        if constexpr (FIRST && T < LA - 1) {
+            // k-steps 1 .. LA-1 of a tile: their weights were complete before the tile began (prologue / tile boundary).  The first
+            // counted wait of a tile therefore comes LA - 1 k-steps after the previous tile's stores went out -- it counts them too
+            // (vmcnt is one counter on gfx9), and with the wait one k-step earlier the 101-wide full-resolution layers lose the 4 %
+            // the persistent grid gives them.
+        } else {
+            constexpr int lo = T + 1 - LA > 0 ? T + 1 - LA : 0;
+            constexpr int hi = T < 5 ? T : 5;
+            constexpr int halos = !TAIL ? (hi >= lo ? hi - lo + 1 : 0) : (lo <= 0 ? 3 : 0) + ((lo <= 1 && T >= 1) ? 3 : 0);
             if (!PDBG(4)) wait_vm<(LA - 1) * SW + halos>();
         }
         PSTAMP(3)
@@ -309,22 +363,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
         PSTAMP(5)
         // ---------------- MFMA phase ----------------
         if (!PDBG(8)) __builtin_amdgcn_s_setprio(1);
-#ifdef ATMVFI_ASM_MFMA
-        // Experiment (not the product): MFMAs as inline asm with the accumulator tied in place (hipcc renames the accumulators
-        // through dead fragment registers).  Same-box A/B of two product builds on nine layer shapes: no difference (1.059 vs
-        // 1.057 ms on the 101-wide layer); and the compiler cannot see an asm MFMA's result latency.  The builtin stays.
-#define MF(accv, av, bv) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(accv) : "v"(av), "v"(bv))
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            MF(cor[0][j], wl[j], xh[0]);
-            MF(cor[1][j], wl[j], xh[1]);
-            MF(acc[0][j], wh[j], xh[0]);
-            MF(acc[1][j], wh[j], xh[1]);
-            MF(cor[0][j], wh[j], xl[0]);
-            MF(cor[1][j], wh[j], xl[1]);
-        }
-#undef MF
-#else
         static_for<0, WN>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             cor[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j], xh[0], cor[0][j], 0, 0, 0);
@@ -334,7 +372,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
             cor[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xl[0], cor[0][j], 0, 0, 0);
             cor[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xl[1], cor[1][j], 0, 0, 0);
         });
-#endif
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         PSTAMP(6)
@@ -348,20 +385,43 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
 #pragma unroll
         for (int k = 0; k < 8; ++k) xa[k] += d;
         hcur += d;
-        const long long adv = chunks_left > 0 ? chunk_bytes : 0;
-        hsrc_hi += adv;
-        hsrc_lo += adv;
-        --chunks_left;
-        hbuf = HALO_BYTES - hbuf;
+        halo_advance();
     };
 
-    for (int c = 0; c < nfull; ++c) {
-        static_for<0, 9>([&](auto tc) { kstep(tc, std::false_type{}); });
-        next_chunk();
-    }
-    if (a.tail)
-        static_for<0, 3>([&](auto tc) { kstep(tc, std::true_type{}); });
-    if (grp == 0) __builtin_amdgcn_s_barrier();          // same number of barriers for both groups
+    for (;;) {
+        const float* cst = cst_base + (seq & 1) * CSTF;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                cor[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                // pinned: hipcc otherwise folds the zeros into the first MFMAs' C operand and may use the (then dead) accumulator
+                // registers as temporaries of the first read phase, guarded by s_waitcnt vmcnt(0)
+                asm volatile("" : "+v"(acc[i][j]), "+v"(cor[i][j]));
+            }
+        if (nfull > 0) {
+            static_for<0, 9>([&](auto tc) { kstep(tc, std::false_type{}, std::true_type{}); });
+            next_chunk();
+        }
+        for (int c = 1; c < nfull; ++c) {
+            static_for<0, 9>([&](auto tc) { kstep(tc, std::false_type{}, std::false_type{}); });
+            next_chunk();
+        }
+        if (a.tail) {
+            static_for<0, 3>([&](auto tc) { kstep(tc, std::true_type{}, std::false_type{}); });
+            next_chunk();
+        }
+        // ---- tile boundary.  The first group waits for the second one's last MFMA phase; the next tile's epilogue constants go
+        // out; everything else in flight -- the next tile's first LA k-steps of weights and its first halo -- has to be complete
+        // before that tile's first read, and is waited for HERE, before this tile's stores join the queue (vmcnt counts them).
+        if (grp == 0) __builtin_amdgcn_s_barrier();
+        if (has_next) {
+            dma_epilogue_consts<BN>(a.bias, a.prelu, nn0, cst_base + ((seq + 1) & 1) * CSTF, wave, lane, [&](int col) { return col < a.Cout ? col : -1; });
+            wait_vm<1>();             // all but the constants: the next tile's first LA k-steps of weights and its first halo
+        } else {
+            wait_vm<0>();
+        }
 
     // ---- epilogue.  Lane (r, g) holds rows 4g..4g+3 of every 16-row n-tile = channels cb(g)..cb(g)+3 with cb = {0, 8, 4, 12}:
     // the weight rows were permuted that way on their way into LDS (wlane), so that lanes g and g + 2 -- the two halves of the
@@ -471,11 +531,31 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
     if (a.out_hi) plane_sink(a.out_hi, a.out_lo, a.plane_rows, a.out_c0, a.plane_prelu);
     if (a.out_hi2) plane_sink(a.out_hi2, a.out_lo2, a.plane_rows2, a.out_c02, nullptr);
 #ifdef ATMVFI_STAMP
+        if (a.stamp) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+            st_epi += t_end - st_t0;
+            st_t0 = t_end;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
+        if (!has_next) break;
+        // on to the next tile: its first halo and its first LA k-steps of weights are in LDS, the DMA streams are already in it
+        vb += grid;
+        img = nimg; ox0 = nox0; oy0 = noy0; n0 = nn0;
+        ++seq;
+        has_next = decode(vb + grid, nimg, nox0, noy0, nn0);
+#pragma unroll
+        for (int s = 0; s < SW; ++s) wnext[s] = weight_base(s, nn0);
+        if (grp == 1) __builtin_amdgcn_s_barrier();          // the second group drops one phase behind again
+    }
+#ifdef ATMVFI_STAMP
     if (a.stamp && lane == 0) {
-        const unsigned long long t_end = __builtin_amdgcn_s_memtime();
         unsigned long long* o = a.stamp + ((long long)blockIdx.x * 8 + wave) * 10;
-        for (int k = 0; k < 8; ++k) o[k] = st_[k];
-        o[8] = t_end - st_t0;     // epilogue
+        const unsigned long long nt = (unsigned long long)(seq + 1);
+        o[0] = st_[0];                                   // prologue of the first tile
+        for (int k = 1; k < 8; ++k) o[k] = st_[k] / nt;  // per tile
+        o[8] = st_epi / nt;                              // tile boundary + epilogue, per tile
         o[9] = (unsigned long long)nk;
     }
 #endif
@@ -484,7 +564,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
 template <int WN>
 int launch_planes(const Conv3PDev& d, int ntiles, hipStream_t s) {
     constexpr int BN = 16 * WN;
-    const size_t lds = (size_t)2 * HALO_BYTES + (size_t)ring_slots(WN) * 2 * BN * 64 + epilogue_const_floats(BN) * sizeof(float);
+    const size_t lds = (size_t)2 * HALO_BYTES + (size_t)ring_slots(WN) * 2 * BN * 64 + 2 * epilogue_const_floats(BN) * sizeof(float);
     auto kern = conv3x3_planes_kernel<WN>;
     const hipError_t attr_err = atmvfi::allow_dynamic_lds<conv3x3_planes_kernel<WN>>(lds);
     ATMVFI_REQUIRE(attr_err == hipSuccess, ATMVFI_ELAUNCH, "conv3x3_planes: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
@@ -502,7 +582,12 @@ int launch_planes(const Conv3PDev& d, int ntiles, hipStream_t s) {
     ds.dbg = 0;
 #endif
     ATMVFI_REQUIRE(sgroups * 8 * ds.nblocks < (1LL << 31), ATMVFI_EINVAL, "conv3x3_planes: grid too large");
-    hipLaunchKernelGGL(kern, dim3((unsigned)(sgroups * 8 * ds.nblocks)), dim3(512), lds, s, ds);
+    ds.vblocks = (int)(sgroups * 8 * ds.nblocks);
+    // persistent (one workgroup per CU walking its XCD's tiles, DMA streams flowing across tiles) whenever a tile has at least two
+    // 32-channel chunks -- the halo stream moves on to the next tile while the last chunk is consumed; else one workgroup per tile
+    const int nchunks = (d.cf >> 5) + (d.tail ? 1 : 0);
+    const int grid = nchunks >= 2 ? std::min(ds.vblocks, atmvfi::cu_count()) : ds.vblocks;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, s, ds);
     return atmvfi::check_launch("conv3x3_planes");
 }
 

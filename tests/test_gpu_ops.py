@@ -739,6 +739,41 @@ def test_conv3x3_planes_every_width(wn, hip, cpu, dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", [(64, 64, 0), (101, 101, 0), (200, 130, 0), (72, 40, 3), (37, 200, 8), (136, 389, 0)],
+                         ids=lambda c: f"cin{c[0]}_cout{c[1]}_wn{c[2]}")
+def test_conv3x3_planes_persistent_grid(case, hip, dev):
+    """More tiles than CUs: the plane kernel's workgroups walk several tiles each, with the next tile's first halo and weights put in
+    flight by the current tile's last k-steps (regular chunks, and the three-piece halo issue of the tap-packed tail steps), ragged
+    right / bottom tiles, one or several column blocks, both sinks.  Must equal the fp32-input kernel bit for bit."""
+    cin, cout, wn = case
+    g = torch.Generator().manual_seed(7200 + cin + cout)
+    r4 = lambda c: (c + 3) // 4 * 4
+    N, H, W = 2, 150, 250                                    # 2 x 10 x 16 = 320 spatial tiles (x column blocks)
+    x = rnd(g, N, H, W, r4(cin), scale=1.5).to(dev)
+    wt = rnd(g, cout, cin, 3, 3, scale=1.0 / np.sqrt(9 * cin)).to(dev)
+    bias, slope = rnd(g, cout, scale=0.2).to(dev), (torch.rand(cout, generator=g) * 0.4).to(dev)
+    pslope = torch.zeros((cout + 31) // 32 * 32, device=dev)
+    pslope[:cout] = torch.rand(cout, generator=g).to(dev)
+    pw = hip.pack_weight(GEMM_CONV, wt)
+    y0 = torch.full((N, H, W, r4(cout)), 7.0, device=dev)
+    hip.conv(x[..., :cin], pw, y0[..., :cout], 1, 1, 1, bias, slope)
+    xp = hip_ops.Planes.alloc(N * H * W, cin, dev)
+    hip.split_planes(x[..., :cin].flatten(0, 2), xp)
+    y1 = torch.full((N, H, W, r4(cout)), 7.0, device=dev)
+    s1 = hip_ops.Planes.alloc(N * H * W, cout, dev)
+    s2 = hip_ops.Planes.alloc(N * H * W, 8 + cout, dev)
+    hip.conv3x3_planes(xp, N, H, W, pw, out=y1[..., :cout], bias=bias, prelu=slope, planes=s1, planes_prelu=pslope, planes2=s2, planes2_c0=8, wn=wn)
+    q = hip_ops.Planes.alloc(N * H * W, cout, dev)
+    hip.split_planes(y0[..., :cout].flatten(0, 2), q)
+    qp = hip_ops.Planes.alloc(N * H * W, cout, dev)
+    hip.split_planes(y0[..., :cout].flatten(0, 2), qp, prelu=pslope[:cout].contiguous())
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1), maxdiff(y0, y1)
+    assert torch.equal(s1.t, qp.t)
+    assert torch.equal(s2.to_rows()[:, :, 8:8 + cout], q.to_rows()[:, :, :cout])
+
+
+@pytest.mark.gpu
 def test_conv3x3_planes_chunk_offset_and_auto_width(hip, dev):
     """Input view starting at a 32-channel chunk of wider planes, automatic tile width, a large-ish ragged map: equals the fp32 kernel."""
     g = torch.Generator().manual_seed(7100)

@@ -45,41 +45,55 @@ def check(asm_text):
 
 
 def check_planes(asm_text):
-    """conv3x3_planes_kernel<WN>: the k-loop alternates read phases and MFMA phases between raw s_barriers.  Its vmcnt waits are
-    immediates computed for a loop in which every wave issues the same DMA instructions in every phase, so the loop must contain
-    no branch; a read phase must end in a counted vmcnt wait and lgkmcnt(0); an MFMA phase must hold exactly 6*WN MFMAs and
-    nothing that touches memory."""
+    """conv3x3_planes_kernel<WN>: the k-loop alternates read phases and MFMA phases between raw s_barriers; its vmcnt waits are
+    immediates computed for a loop in which every wave issues the same DMA instructions in every phase.  Per instance: 9 (first
+    chunk) + 9 (chunk loop body) + 3 (tail) k-steps = 21 MFMA phases (s_setprio 1 .. s_setprio 0), each with exactly 6*WN MFMAs,
+    nothing that touches memory and no branch; in front of each a read phase (back to the previous barrier) with 4 + 2*WN
+    fragment reads, at least one LDS-DMA, lgkmcnt(0), no branch, and -- except in the first LA - 1 k-steps of a tile, which find
+    their weights complete -- a counted vmcnt wait; 46 barriers in all; no register spill; and between the first and the last
+    MFMA phase no vmcnt wait that the compiler made (the kernel's own come from inline asm)."""
     problems = []
     lines = asm_text.splitlines()
-    found = 0
     for wn in range(1, 9):
         starts = [i for i, l in enumerate(lines) if re.match(rf"^_ZN\S*conv3x3_planes_kernelILi{wn}E\S*:", l)]
         if not starts:
             problems.append(f"planes<{wn}>: kernel not found")
             continue
-        found += 1
         end = next(i for i in range(starts[0], len(lines)) if "s_endpgm" in lines[i])
-        body = [l.split(";")[0] for l in lines[starts[0]:end]]
+        raw = lines[starts[0]:end]
+        body = [l.split(";")[0] for l in raw]
+        if any("scratch_" in l for l in body):
+            problems.append(f"planes<{wn}>: register spill (scratch access)")
         bars = [i for i, l in enumerate(body) if re.search(r"\bs_barrier\b", l)]
-        if len(bars) != 27:          # 2 (prologue) + 2 * 9 (chunk loop body) + 2 * 3 (tail steps) + 1
-            problems.append(f"planes<{wn}>: expected 27 s_barrier, found {len(bars)}")
+        if len(bars) != 46:          # 2 (prologue) + 2 * (9 + 9 + 3) k-steps + 2 (tile boundary: re-align, drop behind)
+            problems.append(f"planes<{wn}>: expected 46 s_barrier, found {len(bars)}")
+        p1 = [i for i, l in enumerate(body) if re.search(r"\bs_setprio 1\b", l)]
+        p0 = [i for i, l in enumerate(body) if re.search(r"\bs_setprio 0\b", l)]
+        if len(p1) != 21 or len(p0) != 21:
+            problems.append(f"planes<{wn}>: expected 21 MFMA phases, found {len(p1)} / {len(p0)}")
             continue
-        loop = bars[2:-1]            # barriers of the twelve k-step bodies
-        for k in range(0, len(loop) - 1):
-            seg = body[loop[k] + 1:loop[k + 1]]
+        nowait = 0
+        for k, (a, b) in enumerate(zip(p1, p0)):
+            seg = body[a + 1:b]
             n_mfma = sum("v_mfma" in l for l in seg)
             mem = [l for l in seg if re.search(r"\b(ds_|global_|buffer_|flat_|scratch_)", l)]
-            if any(re.search(r"\bs_cbranch|\bs_branch", l) for l in seg) and k not in (17,):     # (the chunk loop's back edge sits after k-step 8's last barrier)
-                problems.append(f"planes<{wn}>: branch inside phase {k}")
-            if n_mfma:
-                if n_mfma != 6 * wn or mem:
-                    problems.append(f"planes<{wn}>: MFMA phase {k} has {n_mfma} MFMAs and {len(mem)} memory instructions")
-            else:
-                waits = [l.strip() for l in seg if "s_waitcnt" in l]
-                if not any(re.search(r"vmcnt\([1-9]\d*\)", w) for w in waits) or not any("lgkmcnt(0)" in w for w in waits):
-                    problems.append(f"planes<{wn}>: read phase {k} lacks a counted vmcnt wait or lgkmcnt(0): {waits}")
-                if sum("global_load_lds" in l for l in seg) == 0 or sum("ds_read_b128" in l for l in seg) != 4 + 2 * wn:
-                    problems.append(f"planes<{wn}>: read phase {k}: unexpected DMA / fragment read count")
+            if n_mfma != 6 * wn or mem or any(re.search(r"\bs_cbranch|\bs_branch", l) for l in seg):
+                problems.append(f"planes<{wn}>: MFMA phase {k} has {n_mfma} MFMAs, {len(mem)} memory instructions (or a branch)")
+            bar = max(i for i in bars if i < a)
+            prev = max([i for i in bars if i < bar] + [0])
+            rd = body[prev + 1:bar]
+            waits = [l.strip() for l in rd if "s_waitcnt" in l]
+            if sum("ds_read_b128" in l for l in rd) != 4 + 2 * wn or sum("global_load_lds" in l for l in rd) == 0:
+                problems.append(f"planes<{wn}>: read phase {k}: unexpected fragment read / DMA count")
+            if not any("lgkmcnt(0)" in w for w in waits):
+                problems.append(f"planes<{wn}>: read phase {k} lacks lgkmcnt(0)")
+            if not any(re.search(r"vmcnt\([1-9]\d*\)", w) for w in waits):
+                nowait += 1
+        if nowait > 3:               # the first LA - 1 <= 3 k-steps of the first chunk
+            problems.append(f"planes<{wn}>: {nowait} read phases without a counted vmcnt wait (at most LA - 1 = 3 expected)")
+        for i in range(p1[0], p0[-1]):
+            if re.search(r"s_waitcnt.*vmcnt", raw[i]) and "ASMSTART" not in raw[i - 1]:
+                problems.append(f"planes<{wn}>: compiler-inserted '{raw[i].strip()}' inside the k-loop region (line {i})")
     return problems
 
 
