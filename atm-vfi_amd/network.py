@@ -796,9 +796,10 @@ class Network(BlockRunner, nn.Module):
             flow0 = flow1 = m1 = m2 = None
             pd = self._plane_deconvs(ops)
             pc = self._plane_convs(ops) and rh >= 32
-            # the refiner's strided convs on split planes too (ping-pong GEMM, CONV mode, two plane sources for the concats):
-            # needs whole 32-channel chunks on both sides of every concat
-            unet_p = pc and self.use_unet_planes and rh % 32 == 0 and w1d % 32 == 0 and w2d % 32 == 0
+            # the refiner's strided convs on split planes too (ping-pong GEMM, CONV mode, two plane sources for the concats): the
+            # first source (feat) must end on a 32-channel chunk boundary; the second (dec[:, :w]) may end inside a chunk -- what
+            # follows there in the raw decoder planes (its flow / mask channels, then zeros) meets zero-padded weight channels
+            unet_p = pc and self.use_unet_planes and rh % 32 == 0
             xp_next = None
             pack_c0 = (w3d + 5 + 7) // 8 * 8                                       # the 15 image channels inside the refiner's input planes
             rin_p = self.planes("refine_in_p", b * H * W, pack_c0 + 15) if pc else None
