@@ -1,5 +1,6 @@
-// LDS-DMA GEMM on split-plane activations, "ping-pong" schedule (gfx950): nn.Linear rows and ConvTranspose2d 2x2 / stride 2
-// (attention.py:138-141, 349-351, 93-96; network_base.py:27-32, 79-84) whose input the producing layer left as split planes.
+// LDS-DMA GEMM on split-plane activations, "ping-pong" schedule (gfx950): nn.Linear rows, ConvTranspose2d 2x2 / stride 2 and
+// strided / dilated / 1x1 Conv2d (attention.py:138-141, 349-351, 93-96; network_base.py:20-32, 73-85, 417-424) whose input the
+// producing layer left as split planes.
 //
 // Same arithmetic as gemm_split.hip / gemm_f16x3.hip (x = hi + lo'/1024 in fp16, three v_mfma_f32_16x16x32_f16 per product into two
 // fp32 accumulators, k ascending, per accumulator the same order of products: bit-identical results), same operand layouts, same
@@ -17,8 +18,12 @@
 //     barrier -- so that stage u+1 is complete, for every wave, one barrier before its first reader (the first group) starts, and
 //     both groups' pieces had 1.5-2 k-steps to land.  A stage's buffer is refilled one barrier after its last reader (the second
 //     group) has drained its reads (lgkmcnt(0) before the barrier);
-//   * the k-loop body has no data-dependent branch; the last two k-steps are separate copies without DMA issue, so nothing is in
-//     flight when the epilogue starts.
+//   * the k-loop body has no data-dependent branch; the last two k-steps of a tile are separate copies: after the last tile they
+//     issue nothing (nothing is in flight when the kernel ends), before that they put the next tile's constants and stages 0-1 in
+//     flight -- the grid is PERSISTENT, one workgroup per CU walking its XCD's tiles, and the DMA ring flows across tiles;
+//   * the epilogue is transposed through LDS (the wave's own DMA slots of the stage buffer that was read last), so that the 16 lanes
+//     of an output row cover 256 contiguous bytes; both groups run it together (the first waits a phase for the second).
+// Details and measurements at the places in the code and in DESIGN.md section 3.0b.
 #include "common.h"
 #include "gemm_common.h"
 

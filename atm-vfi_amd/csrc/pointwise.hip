@@ -27,6 +27,48 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
     const float* irow = in + ((in_rpg > 0) ? (src / in_rpg) * in_gstride + (src % in_rpg) * (long long)in_ld
                                            : src * (long long)in_ld);
+    if (c4n <= 128) {
+        // rows of up to 512 channels (every LayerNorm of both variants): the lane's one or two vectors stay in registers over the
+        // three sweeps (same arithmetic in the same order as the loops below)
+        const bool has1 = lane + 64 < c4n, has0 = lane < c4n;
+        const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const f32x4 v0 = has0 ? *reinterpret_cast<const f32x4*>(irow + 4 * lane) : z;
+        const f32x4 v1 = has1 ? *reinterpret_cast<const f32x4*>(irow + 4 * (lane + 64)) : z;
+        float sum = 0.f;
+        if (has0) sum += (v0.x + v0.y) + (v0.z + v0.w);
+        if (has1) sum += (v1.x + v1.y) + (v1.z + v1.w);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        const float mean = sum / (float)C;
+        float sq = 0.f;
+        if (has0) {
+            const float a = v0.x - mean, b = v0.y - mean, c = v0.z - mean, d = v0.w - mean;
+            sq += (a * a + b * b) + (c * c + d * d);
+        }
+        if (has1) {
+            const float a = v1.x - mean, b = v1.y - mean, c = v1.z - mean, d = v1.w - mean;
+            sq += (a * a + b * b) + (c * c + d * d);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+        const float rstd = 1.0f / sqrtf(sq / (float)C + 1e-5f);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = lane + 64 * k;
+            if (k == 0 ? has0 : has1) {
+                const f32x4 v = k == 0 ? v0 : v1;
+                const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + 4 * i);
+                const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + 4 * i);
+                f32x4 y;
+                y.x = (v.x - mean) * rstd * gm.x + bt.x;
+                y.y = (v.y - mean) * rstd * gm.y + bt.y;
+                y.z = (v.z - mean) * rstd * gm.z + bt.z;
+                y.w = (v.w - mean) * rstd * gm.w + bt.w;
+                sink_store4(out, row, 4 * i, y);
+            }
+        }
+        return;
+    }
     float sum = 0.f;
     for (int i = lane; i < c4n; i += 64) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(irow + 4 * i);
@@ -499,13 +541,21 @@ extern "C" int atmvfi_dwconv3x3_gelu(const float* in, int in_ld, float* out, int
     const RowSink sink{out, out_ld, (_Float16*)out_hi, (_Float16*)out_lo, plane_ld};
     ATMVFI_REQUIRE(atmvfi::aligned16(in) && atmvfi::aligned16(out) && atmvfi::aligned16(weight9) && atmvfi::aligned16(bias),
                    ATMVFI_EALIGN, "dwconv3x3_gelu: pointers must be 16-byte aligned");
-    if (C % 64 == 0) {     // sliding-window kernel: 16 x-positions x 64 channels per block, 8-row strips
-        constexpr int RS = 8;
-        const int xblocks = (W + 15) / 16, cblocks = C / 64, strips = (H + RS - 1) / RS;
+    if (C % 64 == 0) {     // sliding-window kernel: 16 x-positions x 64 channels per block, strips of 8 or 16 rows
+        // a strip re-reads its two neighbour rows: 10 / 8 of the input with 8-row strips, 18 / 16 with 16-row ones; the taller strip
+        // when it still leaves a few blocks per CU
+        const int xblocks = (W + 15) / 16, cblocks = C / 64;
+        const bool tall = (long long)N * ((H + 15) / 16) * xblocks * cblocks >= 8ll * atmvfi::cu_count();
+        const int RS = tall ? 16 : 8;
+        const int strips = (H + RS - 1) / RS;
         const long long blocks = (long long)N * strips * xblocks * cblocks;
         ATMVFI_REQUIRE(blocks < (1ll << 31), ATMVFI_EINVAL, "dwconv3x3_gelu: grid too large");
-        hipLaunchKernelGGL(dwconv_gelu_rows_kernel<RS>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, in_ld, sink,
-                           weight9, bias, N, H, W, C, xblocks, cblocks, strips);
+        if (tall)
+            hipLaunchKernelGGL(dwconv_gelu_rows_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, in_ld, sink,
+                               weight9, bias, N, H, W, C, xblocks, cblocks, strips);
+        else
+            hipLaunchKernelGGL(dwconv_gelu_rows_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, in_ld, sink,
+                               weight9, bias, N, H, W, C, xblocks, cblocks, strips);
         return atmvfi::check_launch("dwconv3x3_gelu");
     }
     const long long total = (long long)N * H * W * (C / 4);
