@@ -59,14 +59,17 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(const GemmDev a) {
 #pragma unroll
     for (int o4 = 0; o4 < CO4; ++o4) {
         f32x4 acc = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + 4 * o4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x2 a01 = acc.xy, a23 = acc.zw;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const f32x4 w = *reinterpret_cast<const f32x4*>(wl + k * COUT + 4 * o4);     // same address in every lane: broadcast
-            acc.x += x[k] * w.x;       // separate multiply and add (packed v_pk_mul/v_pk_add: measured faster here than fmaf, 0.24 vs 0.36 ms)
-            acc.y += x[k] * w.y;
-            acc.z += x[k] * w.z;
-            acc.w += x[k] * w.w;
+            // explicit packed fused multiply-adds (v_pk_fma_f32: half the instructions of v_pk_mul + v_pk_add, which in turn beat four
+            // scalar fmaf, 0.24 against 0.36 ms; always fused, so the result does not depend on how the loop is scheduled)
+            const f32x2 xx = {x[k], x[k]};
+            a01 = __builtin_elementwise_fma(xx, w.xy, a01);
+            a23 = __builtin_elementwise_fma(xx, w.zw, a23);
         }
+        acc = (f32x4){a01.x, a01.y, a23.x, a23.y};
         if (a.prelu) {
             const f32x4 p = *reinterpret_cast<const f32x4*>(a.prelu + 4 * o4);
             acc.x = acc.x > 0.f ? acc.x : p.x * acc.x;
