@@ -280,6 +280,44 @@ __global__ __launch_bounds__(256) void flow_warp_planar_kernel(const float* __re
     }
 }
 
+// flow_warp of a planar image by a planar flow AND the x2 up-sampling of that flow to the next finer level (upsample_flow,
+// network_base.py:11-18: bilinear, align_corners=True, values x 2) in one launch: the global flow's walk down the image pyramid
+// (network_base.py:468-485) is four warps and three up-samplings in a chain.  The two halves of the index space are independent
+// and use the arithmetic of flow_warp_planar_kernel / resize_ac_kernel unchanged: bit-identical to the two launches.
+__global__ __launch_bounds__(256) void flow_warp_up2_kernel(const float* __restrict__ src, const float* __restrict__ flow, float* __restrict__ dst,
+                                                            float* __restrict__ flow_up, int B, int C, int H, int W) {
+    const long long hw = (long long)H * W;
+    const long long nwarp = (long long)B * hw;
+    const int Ho = 2 * H, Wo = 2 * W;
+    const long long ohw = (long long)Ho * Wo;
+    const long long nup = (long long)B * 2 * ohw;
+    const float sh = (float)(H - 1) / (float)(Ho - 1), sw = (float)(W - 1) / (float)(Wo - 1);
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < nwarp + nup; idx += (long long)gridDim.x * blockDim.x) {
+        if (idx < nwarp) {
+            const int b = (int)(idx / hw);
+            const long long pix = idx - (long long)b * hw;
+            const int y = (int)(pix / W), x = (int)(pix - (long long)y * W);
+            const float* fp = flow + (long long)b * 2 * hw + pix;
+            const Taps t = make_taps((float)x + fp[0], (float)y + fp[hw], W, H);
+            for (int c = 0; c < C; ++c)
+                dst[((long long)b * C + c) * hw + pix] = sample_plane(src + ((long long)b * C + c) * hw, t, W);
+        } else {
+            const long long e = idx - nwarp;
+            const int p = (int)(e / ohw);                    // plane b * 2 + c
+            const long long pix = e - (long long)p * ohw;
+            const int oy = (int)(pix / Wo), ox = (int)(pix - (long long)oy * Wo);
+            const float ry = sh * (float)oy, rx = sw * (float)ox;
+            const int y0 = (int)ry, x0 = (int)rx;
+            const int yp = (y0 < H - 1) ? 1 : 0, xp = (x0 < W - 1) ? 1 : 0;
+            const float ly = ry - (float)y0, lx = rx - (float)x0;
+            const float hy = 1.0f - ly, hx = 1.0f - lx;
+            const float* s = flow + (long long)p * hw + (long long)y0 * W + x0;
+            const float v = hy * (hx * s[0] + lx * s[xp]) + ly * (hx * s[yp * W] + lx * s[yp * W + xp]);
+            flow_up[e] = v * 2.0f;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void flow_warp_nhwc_kernel(const float* __restrict__ src, int src_ld, long long src_bstride,
                                                              const float* __restrict__ flow, long long flow_bstride,
                                                              int flow_pstride, int flow_cstride, float* __restrict__ dst,
@@ -410,6 +448,50 @@ __global__ __launch_bounds__(256) void resize_ac_kernel(const float* __restrict_
         const float* s = src + pb * sb + pc * sc + y0 * sy + x0 * sx;
         const float v = hy * (hx * s[0] + lx * s[xp * sx]) + ly * (hx * s[yp * sy] + lx * s[yp * sy + xp * sx]);
         dst[idx] = v * value_scale;
+    }
+}
+
+// The three x0.5 image-pyramid levels of both frames in ONE launch (network_base.py:444-448: F.interpolate(scale 0.5, bilinear,
+// align_corners=True) applied level by level).  A thread owns one output element of one level and evaluates the levels below it on
+// the fly with resize_ac_kernel's arithmetic, in its order -- bit-identical to three sequential resizes (level 3 costs 64 reads
+// of the frame per element; it has 1 / 64 of the frame's pixels).  Four dependent 7-us launches become one.
+template <int L>
+__device__ __forceinline__ float pyramid_value(const float* __restrict__ plane, int H, int W, int oy, int ox) {
+    if constexpr (L == 0) {
+        return plane[(long long)oy * W + ox];
+    } else {
+        const int Hi = H >> (L - 1), Wi = W >> (L - 1), Ho = H >> L, Wo = W >> L;
+        const float sh = (Ho > 1) ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f;
+        const float sw = (Wo > 1) ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
+        const float ry = sh * (float)oy, rx = sw * (float)ox;
+        const int y0 = (int)ry, x0 = (int)rx;
+        const int yp = (y0 < Hi - 1) ? 1 : 0, xp = (x0 < Wi - 1) ? 1 : 0;
+        const float ly = ry - (float)y0, lx = rx - (float)x0;
+        const float hy = 1.0f - ly, hx = 1.0f - lx;
+        const float v00 = pyramid_value<L - 1>(plane, H, W, y0, x0), v01 = pyramid_value<L - 1>(plane, H, W, y0, x0 + xp);
+        const float v10 = pyramid_value<L - 1>(plane, H, W, y0 + yp, x0), v11 = pyramid_value<L - 1>(plane, H, W, y0 + yp, x0 + xp);
+        const float v = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+        return v * 1.0f;
+    }
+}
+
+__global__ __launch_bounds__(256) void image_pyramid_kernel(const float* __restrict__ im0, const float* __restrict__ im1, float* __restrict__ l1,
+                                                            float* __restrict__ l2, float* __restrict__ l3, int B, int H, int W) {
+    const long long n1 = (long long)(H >> 1) * (W >> 1), n2 = (long long)(H >> 2) * (W >> 2), n3 = (long long)(H >> 3) * (W >> 3);
+    const long long planes = 2ll * B * 3;
+    const long long t1 = planes * n1, t2 = planes * n2, t3 = planes * n3;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < t1 + t2 + t3; idx += (long long)gridDim.x * blockDim.x) {
+        const int lvl = idx < t1 ? 1 : (idx < t1 + t2 ? 2 : 3);
+        const long long e = idx - (lvl == 1 ? 0 : (lvl == 2 ? t1 : t1 + t2));
+        const long long n = lvl == 1 ? n1 : (lvl == 2 ? n2 : n3);
+        const int pl = (int)(e / n);                                   // stacked plane: [im0 batch x 3, im1 batch x 3]
+        const long long pix = e - (long long)pl * n;
+        const int Wo = W >> lvl;
+        const int oy = (int)(pix / Wo), ox = (int)(pix - (long long)oy * Wo);
+        const float* src = (pl < 3 * B ? im0 + (long long)pl * H * W : im1 + (long long)(pl - 3 * B) * H * W);
+        if (lvl == 1) l1[e] = pyramid_value<1>(src, H, W, oy, ox);
+        else if (lvl == 2) l2[e] = pyramid_value<2>(src, H, W, oy, ox);
+        else l3[e] = pyramid_value<3>(src, H, W, oy, ox);
     }
 }
 
@@ -579,6 +661,14 @@ extern "C" int atmvfi_flow_warp(const float* src, const float* flow, int64_t flo
     return atmvfi::check_launch("flow_warp");
 }
 
+extern "C" int atmvfi_flow_warp_up2(const float* src, const float* flow, float* dst, float* flow_up, int B, int C, int H, int W, void* stream) {
+    ATMVFI_REQUIRE(src && flow && dst && flow_up, ATMVFI_EINVAL, "flow_warp_up2: null pointer");
+    ATMVFI_REQUIRE(B > 0 && C > 0 && H > 1 && W > 1, ATMVFI_EINVAL, "flow_warp_up2: bad shape (H, W must be > 1)");
+    hipLaunchKernelGGL(flow_warp_up2_kernel, dim3(grid_for((long long)B * H * W * 9)), dim3(256), 0, (hipStream_t)stream, src, flow, dst, flow_up,
+                       B, C, H, W);
+    return atmvfi::check_launch("flow_warp_up2");
+}
+
 extern "C" int atmvfi_flow_warp_nhwc(const float* src, int src_ld, int64_t src_bstride, const float* flow,
                                       int64_t flow_bstride, int flow_pstride, int flow_cstride, float* dst, int dst_ld,
                                       int64_t dst_bstride, int B, int C, int H, int W, void* stream) {
@@ -630,6 +720,14 @@ extern "C" int atmvfi_resize_bilinear_ac(const float* src, int64_t src_bstride, 
                        (long long)src_bstride, (long long)src_cstride, (long long)src_ystride, (long long)src_xstride, dst,
                        B, C, Hi, Wi, Ho, Wo, value_scale);
     return atmvfi::check_launch("resize_bilinear_ac");
+}
+
+extern "C" int atmvfi_image_pyramid(const float* im0, const float* im1, float* l1, float* l2, float* l3, int B, int H, int W, void* stream) {
+    ATMVFI_REQUIRE(im0 && im1 && l1 && l2 && l3, ATMVFI_EINVAL, "image_pyramid: null pointer");
+    ATMVFI_REQUIRE(B > 0 && H >= 8 && W >= 8 && H % 8 == 0 && W % 8 == 0, ATMVFI_EINVAL, "image_pyramid: H, W must be multiples of 8 (got %dx%d)", H, W);
+    const long long total = 2ll * B * 3 * ((long long)(H >> 1) * (W >> 1) + (long long)(H >> 2) * (W >> 2) + (long long)(H >> 3) * (W >> 3));
+    hipLaunchKernelGGL(image_pyramid_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, im0, im1, l1, l2, l3, B, H, W);
+    return atmvfi::check_launch("image_pyramid");
 }
 
 extern "C" int atmvfi_pack_frames(const float* im0, const float* im1, float* dst, int B, int H, int W, void* stream) {

@@ -75,6 +75,8 @@ SIGNATURES = {
     "atmvfi_pack_weight_conv3x3": (c_i, [c_f, c_f, c_f, c_i, c_i, c_f]),
     "atmvfi_conv3x3_f16x3": (c_i, [c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_l, c_f, c_i, c_i, c_f]),
     "atmvfi_conv3x3_planes": (c_i, [c_f, c_f, c_l, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_l, c_i, c_f, c_i, c_i, c_f]),
+    "atmvfi_flow_warp_up2": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
+    "atmvfi_image_pyramid": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f]),
     "atmvfi_head1x1_planes": (c_i, [c_f, c_f, c_l, c_l, c_i, c_f, c_f, c_i, c_f, c_i, c_f]),
     "atmvfi_conv3x3_planes2": (c_i, [c_f, c_f, c_l, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_l, c_i, c_f, c_f, c_f, c_l, c_i, c_i, c_i, c_f]),
     "atmvfi_layernorm": (c_i, [c_f, c_i, c_l, c_i, c_f, c_f, c_i, c_f, c_f, c_l, c_i, c_f, c_f, c_i, c_f]),
@@ -643,6 +645,15 @@ class HipOps:
         meta = {"bytes": 4.0 * b * h * w * (2 * c + 2)}
         self._run("flow_warp", meta, self.lib.atmvfi_flow_warp, _ptr(src), _ptr(flow), bs, ps, cs, _ptr(dst), b, c, h, w, self._stream())
 
+    def flow_warp_up2(self, src, flow, dst, flow_up):
+        """flow_warp(src, flow) -> dst and the flow up-sampled x2 (values doubled) -> flow_up, one launch; all contiguous planar."""
+        b, c, h, w = src.shape
+        if (not all(t.is_contiguous() for t in (src, flow, dst, flow_up)) or tuple(dst.shape) != (b, c, h, w) or tuple(flow.shape) != (b, 2, h, w)
+                or tuple(flow_up.shape) != (b, 2, 2 * h, 2 * w)):
+            raise ValueError("flow_warp_up2: contiguous src/dst [B,C,H,W], flow [B,2,H,W], flow_up [B,2,2H,2W] expected")
+        meta = {"bytes": 4.0 * b * h * w * (2 * c + 2 + 8)}
+        self._run("flow_warp_up2", meta, self.lib.atmvfi_flow_warp_up2, _ptr(src), _ptr(flow), _ptr(dst), _ptr(flow_up), b, c, h, w, self._stream())
+
     def flow_warp_nhwc(self, src, flow, dst):
         ld, b, h, w, c = nhwc_view(src, "flow_warp_nhwc.src")
         old, ob, oh, ow, oc = nhwc_view(dst, "flow_warp_nhwc.dst")
@@ -688,6 +699,17 @@ class HipOps:
         meta = {"bytes": 4.0 * b * c * (hi * wi + dst.shape[2] * dst.shape[3])}
         self._run("resize_bilinear_ac", meta, self.lib.atmvfi_resize_bilinear_ac, _ptr(src), src.stride(0), src.stride(1),
                   src.stride(2), src.stride(3), _ptr(dst), b, c, hi, wi, dst.shape[2], dst.shape[3], float(value_scale), self._stream())
+
+    def image_pyramid(self, im0, im1, l1, l2, l3):
+        """The x0.5 pyramid levels 1..3 of both frames in one launch: im0 / im1 contiguous [B,3,H,W]; l1..l3 contiguous [2B,3,H>>l,W>>l]."""
+        b, c, h, w = im0.shape
+        for t, l in ((l1, 1), (l2, 2), (l3, 3)):
+            if not t.is_contiguous() or tuple(t.shape) != (2 * b, 3, h >> l, w >> l):
+                raise ValueError(f"image_pyramid: level {l} must be contiguous [{2 * b},3,{h >> l},{w >> l}], got {tuple(t.shape)}")
+        if c != 3 or im1.shape != im0.shape or not im0.is_contiguous() or not im1.is_contiguous():
+            raise ValueError("image_pyramid: frames must be contiguous [B,3,H,W]")
+        meta = {"bytes": 4.0 * 2 * b * 3 * h * w * (1 + 0.25 + 0.0625 + 0.015625)}
+        self._run("image_pyramid", meta, self.lib.atmvfi_image_pyramid, _ptr(im0), _ptr(im1), _ptr(l1), _ptr(l2), _ptr(l3), b, h, w, self._stream())
 
     def frame_u8_to_f32(self, src_u8, dst, pad_top: int, pad_left: int, bgr: bool):
         """uint8 [H,W,3] device tensor -> fp32 planar [3,Hp,Wp] (x / 255, replicate padding, optional BGR -> RGB)."""

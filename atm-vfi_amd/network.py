@@ -705,12 +705,9 @@ class Network(BlockRunner, nn.Module):
             pyr_st = [None]
             for l in range(1, 4):
                 t = self.buf(f"pyr_{l}", 2 * b, 3, H >> l, W >> l)
-                if l == 1:
-                    ops.resize(im0, t[:b]); ops.resize(im1, t[b:])
-                else:
-                    ops.resize(pyr_st[-1], t)
                 pyr_st.append(t)
                 pyr0.append(t[:b]); pyr1.append(t[b:])
+            ops.image_pyramid(im0, im1, pyr_st[1], pyr_st[2], pyr_st[3])      # one launch for the three levels of both frames
             # encoder + local fusion (:451-455)
             x0 = self.buf("x0", 2 * b, H, W, 4); ops.pack_frames(im0, im1, x0)
             cache_ok = self._frame_cache_on and not self.global_motion
@@ -755,14 +752,13 @@ class Network(BlockRunner, nn.Module):
                 x_tokens = featw.reshape(2 * b * h * w, C)
                 for i in (3, 2, 1, 0):
                     nw = self.buf(f"pw_{i}", 2 * b, 3, H >> i, W >> i)
-                    if i:
-                        ops.flow_warp(pyr_st[i], gf, nw)
+                    if i:       # the level's warp and the flow's x2 up-sampling to the next level: one launch
+                        u = self.buf(f"gf_{i - 1}", 2 * b, 2, H >> (i - 1), W >> (i - 1))
+                        ops.flow_warp_up2(pyr_st[i], gf, nw, u)
+                        gf = u
                     else:
                         ops.flow_warp(im0, gf[:b], nw[:b]); ops.flow_warp(im1, gf[b:], nw[b:])
                     pyr0[i], pyr1[i] = nw[:b], nw[b:]
-                    if i:
-                        u = self.buf(f"gf_{i - 1}", 2 * b, 2, H >> (i - 1), W >> (i - 1)); ops.resize(gf, u, 2.0)
-                        gf = u
             # local motion (:490) -> raw motion map goes straight into the decoder input
             cdec = 2 * C + S.MOTION_OUT
             dec_in = self.buf("dec_in", b, h, w, _r4(cdec))

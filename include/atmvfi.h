@@ -304,6 +304,16 @@ int atmvfi_resize_bilinear_ac(const float* src, int64_t src_bstride, int64_t src
                               int64_t src_xstride, float* dst, int B, int C, int Hi, int Wi, int Ho, int Wo,
                               float value_scale, void* stream);
 
+/* The three x0.5 levels of the image pyramid of both frames (network_base.py:444-448) in one launch: im0 / im1 planar [B,3,H,W]
+ * (H, W multiples of 8); l1 / l2 / l3 planar [2B,3,H>>l,W>>l], frame 0's images first.  Bit-identical to atmvfi_resize_bilinear_ac
+ * applied level by level. */
+int atmvfi_image_pyramid(const float* im0, const float* im1, float* l1, float* l2, float* l3, int B, int H, int W, void* stream);
+
+/* flow_warp (flow_warp.py:50-60) of a planar image [B,C,H,W] by a contiguous planar flow [B,2,H,W] into dst, AND that flow up-sampled
+ * to [B,2,2H,2W] with its values doubled (upsample_flow, network_base.py:11-18) into flow_up, in one launch: one step of the global
+ * flow's walk down the image pyramid (network_base.py:468-485).  Bit-identical to atmvfi_flow_warp + atmvfi_resize_bilinear_ac(x2). */
+int atmvfi_flow_warp_up2(const float* src, const float* flow, float* dst, float* flow_up, int B, int C, int H, int W, void* stream);
+
 /* torch.cat([im0, im1], 0) (network_base.py:451) fused with NCHW -> NHWC4 (4th channel 0). */
 int atmvfi_pack_frames(const float* im0, const float* im1, float* dst /*[2B,H,W,4]*/, int B, int H, int W, void* stream);
 

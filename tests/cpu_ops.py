@@ -187,6 +187,18 @@ class CpuOps:
         self.calls.append("resize_bilinear_ac")
         dst.copy_(F.interpolate(src, size=dst.shape[-2:], mode="bilinear", align_corners=True) * value_scale)
 
+    def flow_warp_up2(self, src, flow, dst, flow_up):
+        self.flow_warp(src, flow, dst)
+        self.resize(flow, flow_up, 2.0)
+
+    def image_pyramid(self, im0, im1, l1, l2, l3):
+        self.calls.append("image_pyramid")
+        b = im0.shape[0]
+        prev = torch.cat([im0, im1], 0)
+        for dst in (l1, l2, l3):
+            dst.copy_(F.interpolate(prev, size=dst.shape[-2:], mode="bilinear", align_corners=True))
+            prev = dst
+
     def pack_frames(self, im0, im1, dst):
         self.calls.append("pack_frames")
         x = torch.cat([im0, im1], 0).permute(0, 2, 3, 1)

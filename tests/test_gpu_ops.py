@@ -865,6 +865,41 @@ def test_conv_from_two_plane_sources(hip, dev):
 
 
 @pytest.mark.gpu
+def test_flow_warp_up2_equals_two_launches(hip, dev):
+    """flow_warp + x2 flow up-sampling in one launch == the two kernels, bit for bit (incl. flows that leave the image)."""
+    g = torch.Generator().manual_seed(99)
+    b, c, h, w = 2, 3, 17, 29
+    src = torch.rand(b, c, h, w, generator=g).to(dev)
+    flow = ((torch.rand(b, 2, h, w, generator=g) - 0.5) * 12).to(dev)
+    flow[0, :, 0, 0] = 1e6
+    d0, u0 = torch.empty_like(src), torch.empty(b, 2, 2 * h, 2 * w, device=dev)
+    d1, u1 = torch.full_like(src, 3.0), torch.full((b, 2, 2 * h, 2 * w), 3.0, device=dev)
+    hip.flow_warp(src, flow, d0); hip.resize(flow, u0, 2.0)
+    hip.flow_warp_up2(src, flow, d1, u1)
+    torch.cuda.synchronize()
+    assert torch.equal(d0, d1) and torch.equal(u0, u1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 64, 96), (2, 136, 248), (1, 8, 8)], ids=lambda s: f"{s[0]}x{s[1]}x{s[2]}")
+def test_image_pyramid_equals_sequential_resizes(shape, hip, dev):
+    """One launch for the x0.5 pyramid levels 1..3 of both frames == F.interpolate-style resizes applied level by level, bit for bit."""
+    b, h, w = shape
+    g = torch.Generator().manual_seed(h * w)
+    im0, im1 = torch.rand(b, 3, h, w, generator=g).to(dev), torch.rand(b, 3, h, w, generator=g).to(dev)
+    lv = [torch.full((2 * b, 3, h >> l, w >> l), 5.0, device=dev) for l in (1, 2, 3)]
+    hip.image_pyramid(im0, im1, *lv)
+    ref = [torch.empty_like(t) for t in lv]
+    hip.resize(im0, ref[0][:b]); hip.resize(im1, ref[0][b:])
+    hip.resize(ref[0], ref[1]); hip.resize(ref[1], ref[2])
+    torch.cuda.synchronize()
+    for a, r in zip(lv, ref):
+        assert torch.equal(a, r), maxdiff(a, r)
+    want = torch.nn.functional.interpolate(torch.cat([im0, im1], 0), scale_factor=0.5, mode="bilinear", align_corners=True)
+    assert maxdiff(lv[0], want) <= 1e-6
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(1, 68, 120, 576, 5), (2, 17, 23, 768, 5), (1, 9, 11, 100, 8), (1, 5, 7, 40, 1)], ids=lambda s: f"{s[3]}to{s[4]}")
 def test_head1x1_planes(shape, hip, dev):
     """The 5-channel read-out of a motion MLP (network_base.py:158,195) on split-plane input: fp32 FMAs per pixel row against fp64, and
