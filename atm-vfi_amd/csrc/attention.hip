@@ -196,6 +196,258 @@ __global__ __launch_bounds__(64 * NT) void window_attn_kernel(
     }
 }
 
+// the A operand of one 16x16x32 step out of a row-major [key][d] fp16 image: two transposing reads (keys +0..3 and +16..19 of the
+// lane group's block, 16 d columns), each 4 halves per lane
+typedef __fp16 h16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+__device__ __forceinline__ f16x8_t tr_pair(unsigned a0, unsigned a1) {
+    const h16x4_t x = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h16x4_t*)(unsigned long long)a0);
+    const h16x4_t y = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h16x4_t*)(unsigned long long)a1);
+    struct Two { h16x4_t x, y; };
+    return __builtin_bit_cast(f16x8_t, (Two){x, y});
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same attention on the f16x3 arithmetic of the contraction engines (x = hi + lo'/1024 in fp16, three
+// v_mfma_f32_16x16x32_f16 per product into two fp32 accumulators: 1/4 of the fp32-MFMA cycles, ~22 significand bits).
+//   staging       : K and V of the head are converted while they are staged, ROW-MAJOR, as fp16 hi / lo' images (no transposing
+//                   store: the old kernel's scalar ds_write_b32 transpose of V was 2.7 conflict cycles per LDS instruction);
+//                   K rows are 16-byte slots XOR-swizzled for the ds_read_b128 lane groups, V rows have a pitch that is an odd
+//                   multiple of 32 bytes for the transposed reads (both images: 0 conflicts by the bank rules, tools/lds_banks.py)
+//   S^T = K Q^T   : A = K fragment (ds_read_b128: 8 consecutive d of one key), B = Q fragment (global, split in registers)
+//                   -> lane (r = lane&15, g = lane>>4) holds S[q = 16w + r][key = 16kt + 4g + e], exactly as the fp32 kernel
+//   softmax / motion: unchanged, fp32, lane-local + two __shfl_xor
+//   O^T = V^T P^T : B = P^T straight from the S registers: k-step kt2 takes tiles 2 kt2 and 2 kt2 + 1, element j of lane group g is
+//                   key 32 kt2 + 16 (j>>2) + 4 g + (j&3); A = V^T fragment in that same key order = two ds_read_b64_tr_b16 (the
+//                   gfx950 transposing read: 4 keys x 16 d per 16 lanes, delivered column-major) of the row-major V image.
+template <int NT>
+__global__ __launch_bounds__(64 * NT) void window_attn_x3_kernel(
+    const float* __restrict__ qkv, const RowSink out, float* __restrict__ motion,
+    const int* __restrict__ labels, int N, int nW, int ws, int heads, int hd, int C, int Bw, int kv_shift,
+    float scale) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NPAD = NT * 16, KT2 = (NT + 1) / 2, VROWS = 32 * KT2, T = 64 * NT;
+    constexpr int MAXC = NT >= 13 ? 2 : 4;       // 32-wide d chunks: hd <= 128 (<= 64 for the 13..16-tile windows: 1024 threads leave 128 registers)
+    const int D32 = (hd + 31) >> 5, DT = (hd + 15) >> 4;
+    const int SPK = D32 <= 1 ? 4 : D32 == 2 ? 8 : 16;     // 16-byte slots per K row and plane (power of two: XOR swizzle)
+    const int KS = SPK * 16;                              // K row pitch, bytes
+    const int VS = 32 * DT + ((DT & 1) ? 0 : 32);         // V row pitch, bytes: odd multiple of 32
+    unsigned char* Kh = reinterpret_cast<unsigned char*>(smem);
+    unsigned char* Kl = Kh + NPAD * KS;
+    unsigned char* Vh = Kl + NPAD * KS;
+    unsigned char* Vl = Vh + VROWS * VS;
+    int* Ls = reinterpret_cast<int*>(Vl + VROWS * VS);
+
+    const int tid = threadIdx.x;
+    const int slot = blockIdx.x >> 3;            // XCD-aware order: the heads of a window back to back on one XCD (see above)
+    const int b = (slot / heads) * 8 + (blockIdx.x & 7);
+    const int h = slot % heads;
+    if (b >= Bw) return;
+    const int bk = (b + kv_shift) % Bw;
+    const int C3 = 3 * C;
+    const int lane = tid & 63;
+    const int w = tid >> 6;
+    const int r = lane & 15;
+    const int g = lane >> 4;
+    const int q = 16 * w + r;
+    const bool qok = q < N;
+
+    // ---- Q fragments of this wave (B operand: lane holds d = 32 c + 8 g .. + 7 of its query), requested before the staging ----
+    f32x4 qx[MAXC][2];
+    const float* qrow = qkv + ((long long)b * N + (qok ? q : 0)) * C3 + h * hd;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        if (c < D32) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int d = 32 * c + 8 * g + 4 * hf;
+                qx[c][hf] = *reinterpret_cast<const f32x4*>(qrow + (d < hd ? d : 0));
+            }
+        }
+    }
+
+    // ---- stage K and V (fp32 -> fp16 hi / lo'), zeros for padded keys and for K's head-dim padding; all loads of a pass are
+    // requested before the first conversion (unconditional loads from clamped addresses, zeroed by selects) ----
+    const int dg = 8 * D32;                       // 4-float units per K row (padding included)
+    const float inv_dg = 1.0f / (float)dg;
+    const int ksw_mask = SPK - 1;
+    constexpr int UNR = 4;
+    const float* kvbase = qkv + (long long)bk * N * C3 + C + h * hd;
+    for (int base = 0; base < VROWS * dg; base += T * UNR) {
+        f32x4 kv[UNR], vv[UNR];
+        int rowv[UNR], d4v[UNR];
+        bool okv[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int idx = base + u * T + tid;
+            const int row = (int)(((float)idx + 0.5f) * inv_dg);      // exact: idx < 2^13
+            const int d4 = idx - row * dg;
+            rowv[u] = row;
+            d4v[u] = d4;
+            okv[u] = row < N && (d4 << 2) < hd;
+            const float* p = kvbase + (long long)(okv[u] ? row : 0) * C3 + (okv[u] ? (d4 << 2) : 0);
+            kv[u] = *reinterpret_cast<const f32x4*>(p);
+            vv[u] = *reinterpret_cast<const f32x4*>(p + C);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int row = rowv[u], d4 = d4v[u];
+            if (row < VROWS) {
+                const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const f32x4 k4 = okv[u] ? kv[u] : z, v4 = okv[u] ? vv[u] : z;
+                f16x2 h0, l0, h1, l1;
+                if (row < NPAD) {
+                    split_pair((f32x2){k4.x, k4.y}, h0, l0);
+                    split_pair((f32x2){k4.z, k4.w}, h1, l1);
+                    const int sw = SPK == 16 ? (row & 15) : SPK == 8 ? ((row >> 1) & 7) : ((0x1320 >> (((row >> 2) & 3) * 4)) & 3);
+                    const int off = row * KS + ((((d4 >> 1) ^ sw) & ksw_mask) << 4) + ((d4 & 1) << 3);
+                    *reinterpret_cast<f16x4*>(Kh + off) = (f16x4){h0.x, h0.y, h1.x, h1.y};
+                    *reinterpret_cast<f16x4*>(Kl + off) = (f16x4){l0.x, l0.y, l1.x, l1.y};
+                }
+                if (d4 < 4 * DT) {
+                    split_pair((f32x2){v4.x, v4.y}, h0, l0);
+                    split_pair((f32x2){v4.z, v4.w}, h1, l1);
+                    const int off = row * VS + (d4 << 3);
+                    *reinterpret_cast<f16x4*>(Vh + off) = (f16x4){h0.x, h0.y, h1.x, h1.y};
+                    *reinterpret_cast<f16x4*>(Vl + off) = (f16x4){l0.x, l0.y, l1.x, l1.y};
+                }
+            }
+        }
+    }
+    for (int idx = tid; idx < NPAD; idx += T)
+        Ls[idx] = (labels && idx < N) ? labels[(long long)(b % nW) * N + idx] : 0;
+
+    // split the Q fragments (zero outside the head dim / the window)
+    f16x8_t qh[MAXC], ql[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        if (c < D32) {
+            f16x2 hh[4], ll[4];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const bool ok = qok && (32 * c + 8 * g + 4 * hf) < hd;
+                const f32x4 x = qx[c][hf];
+                split_pair(ok ? (f32x2){x.x, x.y} : (f32x2){0.f, 0.f}, hh[2 * hf], ll[2 * hf]);
+                split_pair(ok ? (f32x2){x.z, x.w} : (f32x2){0.f, 0.f}, hh[2 * hf + 1], ll[2 * hf + 1]);
+            }
+            qh[c] = (f16x8_t){hh[0].x, hh[0].y, hh[1].x, hh[1].y, hh[2].x, hh[2].y, hh[3].x, hh[3].y};
+            ql[c] = (f16x8_t){ll[0].x, ll[0].y, ll[1].x, ll[1].y, ll[2].x, ll[2].y, ll[3].x, ll[3].y};
+        }
+    }
+    __syncthreads();
+
+    // ---- S^T = K Q^T ----
+    const int rsw = SPK == 16 ? r : SPK == 8 ? (r >> 1) : ((0x1320 >> ((r >> 2) * 4)) & 3);     // the swizzle of rows 16 kt + r
+    f32x4 s[NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, cor = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            if (c < D32) {
+                const int off = (16 * kt + r) * KS + ((((4 * c + g) ^ rsw) & ksw_mask) << 4);
+                const f16x8_t kh = *reinterpret_cast<const f16x8_t*>(Kh + off);
+                const f16x8_t kl = *reinterpret_cast<const f16x8_t*>(Kl + off);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh[c], acc, 0, 0, 0);
+                cor = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql[c], cor, 0, 0, 0);
+                cor = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh[c], cor, 0, 0, 0);
+            }
+        }
+        s[kt] = acc + cor * (1.0f / 1024.0f);
+    }
+
+    // ---- scale + mask + softmax over keys (attention.py:192-200) ----
+    const int lab_q = Ls[qok ? q : 0];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+        const int4 lk = *reinterpret_cast<const int4*>(Ls + 16 * kt + 4 * g);
+        const int lks[4] = {lk.x, lk.y, lk.z, lk.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int key = 16 * kt + 4 * g + e;
+            float v = s[kt][e] * scale;
+            if (labels && lks[e] != lab_q) v += -100.0f;
+            if (key >= N) v = -INFINITY;
+            s[kt][e] = v;
+            mx = fmaxf(mx, v);
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float p = expf(s[kt][e] - mx);
+            s[kt][e] = p;
+            sum += p;
+        }
+    const float inv_ws = 1.0f / (float)ws;        // key / ws for key < 256, ws <= 16: floor((key + 0.5) / ws) is exact in fp32
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    const float qy = floorf(((float)q + 0.5f) * inv_ws), qx_ = (float)q - qy * (float)ws;
+    float mox = 0.f, moy = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int key = 16 * kt + 4 * g + e;
+            const float p = s[kt][e] * inv;
+            s[kt][e] = p;
+            const float ky = floorf(((float)key + 0.5f) * inv_ws);
+            mox += p * (((float)key - ky * (float)ws) - qx_);
+            moy += p * (ky - qy);
+        }
+    if (motion) {
+        mox += __shfl_xor(mox, 16);
+        mox += __shfl_xor(mox, 32);
+        moy += __shfl_xor(moy, 16);
+        moy += __shfl_xor(moy, 32);
+        if (g == 0 && qok) {
+            float* mp = motion + (((long long)b * N + q) * heads + h) * 2;
+            mp[0] = mox;
+            mp[1] = moy;
+        }
+    }
+
+    // ---- P^T fragments: tiles 2 kt2 and 2 kt2 + 1 of the S registers, split in place ----
+    f16x8_t ph[KT2], pl[KT2];
+#pragma unroll
+    for (int k2 = 0; k2 < KT2; ++k2) {
+        const f32x4 a = s[2 * k2];
+        const f32x4 c = (2 * k2 + 1 < NT) ? s[2 * k2 + 1 < NT ? 2 * k2 + 1 : 0] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        f16x2 hh[4], ll[4];
+        split_pair((f32x2){a.x, a.y}, hh[0], ll[0]);
+        split_pair((f32x2){a.z, a.w}, hh[1], ll[1]);
+        split_pair((f32x2){c.x, c.y}, hh[2], ll[2]);
+        split_pair((f32x2){c.z, c.w}, hh[3], ll[3]);
+        ph[k2] = (f16x8_t){hh[0].x, hh[0].y, hh[1].x, hh[1].y, hh[2].x, hh[2].y, hh[3].x, hh[3].y};
+        pl[k2] = (f16x8_t){ll[0].x, ll[0].y, ll[1].x, ll[1].y, ll[2].x, ll[2].y, ll[3].x, ll[3].y};
+    }
+
+    // ---- O^T = V^T P^T.  Transposed read: lane 4 qq + p of a 16-lane group supplies the address of block row qq, columns
+    // 4 p .. 4 p + 3; lane i receives column i of the 4 rows.  EXEC is all ones here (no lane has left the kernel). ----
+    const long long orow = (long long)b * N + (qok ? q : 0);
+    const unsigned vlane = (unsigned)((4 * g + ((lane >> 2) & 3)) * VS + ((lane & 3) << 3));
+    const unsigned vh0 = lds_offset(Vh) + vlane, vl0 = lds_offset(Vl) + vlane;
+    for (int dt = 0; dt < DT; ++dt) {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, cor = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k2 = 0; k2 < KT2; ++k2) {
+            const unsigned o0 = (unsigned)(32 * k2 * VS + 32 * dt), o1 = o0 + (unsigned)(16 * VS);
+            const f16x8_t vh = tr_pair(vh0 + o0, vh0 + o1), vl = tr_pair(vl0 + o0, vl0 + o1);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph[k2], acc, 0, 0, 0);
+            cor = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl[k2], cor, 0, 0, 0);
+            cor = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph[k2], cor, 0, 0, 0);
+        }
+        const f32x4 o = acc + cor * (1.0f / 1024.0f);
+        const int d = 16 * dt + 4 * g;
+        if (qok && d < hd) sink_store4(out, orow, h * hd + d, o);
+    }
+}
+
 __global__ void motion_head_kernel(const float* __restrict__ motion, const int* __restrict__ row_map,
                                    const float* __restrict__ w0, const float* __restrict__ b0,
                                    const float* __restrict__ w1, const float* __restrict__ b1,
@@ -243,11 +495,27 @@ int launch_attn(const float* qkv, const RowSink out, float* motion, const int* l
     return atmvfi::check_launch("window_attention");
 }
 
-}  // namespace
+template <int NT>
+int launch_attn_x3(const float* qkv, const RowSink out, float* motion, const int* labels, int Bw, int nW, int N, int ws,
+                   int heads, int hd, int kv_shift, hipStream_t s) {
+    const int d32 = (hd + 31) / 32, dt = (hd + 15) / 16, npad = NT * 16, vrows = 32 * ((NT + 1) / 2);
+    const int ks = (d32 <= 1 ? 4 : d32 == 2 ? 8 : 16) * 16, vs = 32 * dt + ((dt & 1) ? 0 : 32);
+    const size_t lds = 2 * (size_t)npad * ks + 2 * (size_t)vrows * vs + (size_t)npad * sizeof(int);
+    ATMVFI_REQUIRE(hd <= (NT >= 13 ? 64 : 128), ATMVFI_EINVAL, "window_attention: head dim %d too large for a %d-token window", hd, N);
+    ATMVFI_REQUIRE(lds <= 160 * 1024, ATMVFI_EINVAL,
+                   "window_attention: K/V tile of %zu bytes exceeds the 160 KiB LDS (ws %d, hd %d)", lds, ws, hd);
+    if (lds > 48 * 1024) {
+        const hipError_t e = atmvfi::allow_dynamic_lds<window_attn_x3_kernel<NT>>(lds);
+        ATMVFI_REQUIRE(e == hipSuccess, ATMVFI_ELAUNCH, "window_attention: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
+    const float scale = 1.0f / sqrtf((float)hd);
+    hipLaunchKernelGGL(window_attn_x3_kernel<NT>, dim3((unsigned)((Bw + 7) / 8 * 8 * heads)), dim3(64 * NT), lds, s, qkv, out, motion,
+                       labels, N, nW, ws, heads, hd, heads * hd, Bw, kv_shift, scale);
+    return atmvfi::check_launch("window_attention_f16x3");
+}
 
-extern "C" int atmvfi_window_attention(const float* qkv, float* out, float* motion, const int32_t* labels, int Bw,
-                                        int nW, int ws, int heads, int hd, int kv_shift, void* out_hi, void* out_lo,
-                                        int plane_ld, void* stream) {
+int attention_entry(bool x3, const float* qkv, float* out, float* motion, const int32_t* labels, int Bw, int nW, int ws, int heads,
+                    int hd, int kv_shift, void* out_hi, void* out_lo, int plane_ld, void* stream) {
     ATMVFI_REQUIRE(qkv, ATMVFI_EINVAL, "window_attention: null pointer");
     ATMVFI_REQUIRE(sink_ok(out, heads * hd, heads * hd, out_hi, out_lo, plane_ld, (long long)Bw * ws * ws), ATMVFI_EALIGN,
                    "window_attention: output needs fp32 rows and/or both fp16 planes (plane rows >= Bw*ws*ws), 16-byte aligned");
@@ -261,8 +529,10 @@ extern "C" int atmvfi_window_attention(const float* qkv, float* out, float* moti
     const int N = ws * ws;
     const int nt = (N + 15) / 16;
     hipStream_t s = (hipStream_t)stream;
-#define ATMVFI_ATTN_CASE(k) \
-    case k: return launch_attn<k>(qkv, sink, motion, labels, Bw, nW, N, ws, heads, hd, kv_shift, s);
+#define ATMVFI_ATTN_CASE(k)                                                                                              \
+    case k:                                                                                                              \
+        return x3 ? launch_attn_x3<k>(qkv, sink, motion, labels, Bw, nW, N, ws, heads, hd, kv_shift, s)                   \
+                  : launch_attn<k>(qkv, sink, motion, labels, Bw, nW, N, ws, heads, hd, kv_shift, s);
     switch (nt) {
         ATMVFI_ATTN_CASE(1) ATMVFI_ATTN_CASE(2) ATMVFI_ATTN_CASE(3) ATMVFI_ATTN_CASE(4) ATMVFI_ATTN_CASE(5)
         ATMVFI_ATTN_CASE(6) ATMVFI_ATTN_CASE(7) ATMVFI_ATTN_CASE(8) ATMVFI_ATTN_CASE(9) ATMVFI_ATTN_CASE(10)
@@ -272,6 +542,20 @@ extern "C" int atmvfi_window_attention(const float* qkv, float* out, float* moti
 #undef ATMVFI_ATTN_CASE
     atmvfi::set_error("window_attention: unsupported token count %d", N);
     return ATMVFI_EINVAL;
+}
+
+}  // namespace
+
+extern "C" int atmvfi_window_attention_f16x3(const float* qkv, float* out, float* motion, const int32_t* labels, int Bw,
+                                              int nW, int ws, int heads, int hd, int kv_shift, void* out_hi, void* out_lo,
+                                              int plane_ld, void* stream) {
+    return attention_entry(true, qkv, out, motion, labels, Bw, nW, ws, heads, hd, kv_shift, out_hi, out_lo, plane_ld, stream);
+}
+
+extern "C" int atmvfi_window_attention(const float* qkv, float* out, float* motion, const int32_t* labels, int Bw,
+                                        int nW, int ws, int heads, int hd, int kv_shift, void* out_hi, void* out_lo,
+                                        int plane_ld, void* stream) {
+    return attention_entry(false, qkv, out, motion, labels, Bw, nW, ws, heads, hd, kv_shift, out_hi, out_lo, plane_ld, stream);
 }
 
 extern "C" int atmvfi_window_attn_cross_motion(const float* qkv, float* out, float* motion, const int32_t* labels,

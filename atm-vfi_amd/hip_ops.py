@@ -83,6 +83,7 @@ SIGNATURES = {
     "atmvfi_dwconv3x3_gelu": (c_i, [c_f, c_i, c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f]),
     "atmvfi_pack_dw_weight": (c_i, [c_f, c_f, c_i, c_f]),
     "atmvfi_window_attention": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f]),
+    "atmvfi_window_attention_f16x3": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f]),
     "atmvfi_window_attn_cross_motion": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
     "atmvfi_window_attn_self": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
     "atmvfi_motion_head": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_l, c_i, c_l, c_i, c_f]),
@@ -239,6 +240,7 @@ class HipOps:
         # "f16x3": 3x3/s1 convs run split-precision on the 16-bit MFMA (hi*hi + hi*lo + lo*hi, fp32 accumulate);
         # "f32": everything on the exact-fp32 MFMA.
         self.precision = "f16x3"
+        self.attention_f16x3 = True        # window attention on the f16x3 MFMA path too (False: the exact-fp32 kernel)
         # per-call kernel-instance overrides (parity tests, sweeps): (schedule, wn) of the fp32-input 3x3 kernel, tile width of the
         # fp32-input f16x3 GEMM; None / 0 = the library's cost model
         self.conv3_instance = None
@@ -624,7 +626,8 @@ class HipOps:
             raise ValueError("window_attention: labels must be CUDA int32 [nW, N]")
         meta = {"flops": 4.0 * bw * heads * n * n * hd, "bytes": 4.0 * bw * n * 4 * c}
         hi, lo, pld = self._sink(planes, bw * n, c, "window_attention")
-        self._run("window_attention", meta, self.lib.atmvfi_window_attention, _ptr(qkv), _ptr(out), _ptr(motion), _ptr(labels),
+        fn = self.lib.atmvfi_window_attention_f16x3 if self.precision == "f16x3" and self.attention_f16x3 else self.lib.atmvfi_window_attention
+        self._run("window_attention", meta, fn, _ptr(qkv), _ptr(out), _ptr(motion), _ptr(labels),
                   bw, nw, ws, heads, hd, kv_shift, hi, lo, pld, self._stream())
 
     def motion_head(self, motion, row_map, w0, b0, w1, b1, out):

@@ -244,6 +244,13 @@ int atmvfi_pack_dw_weight(const float* src /*[C,1,3,3]*/, float* dst /*[9][C]*/,
 int atmvfi_window_attention(const float* qkv, float* out /*[Bw*N, C]*/, float* motion,
                             const int32_t* labels, int Bw, int nW, int ws, int heads, int hd,
                             int kv_shift, void* out_hi, void* out_lo, int plane_rows, void* stream);
+/* The same contract on the f16x3 arithmetic of the contraction engines (x = hi + lo'/1024 in fp16, three
+ * v_mfma_f32_16x16x32_f16 per product, fp32 accumulation: ~22 significand bits; operands beyond +-65504 saturate like
+ * every other f16x3 kernel): K / V converted while they are staged, V read back through gfx950's transposing LDS read.
+ * What Network.forward calls under precision "f16x3"; atmvfi_window_attention stays the exact-fp32 kernel. */
+int atmvfi_window_attention_f16x3(const float* qkv, float* out /*[Bw*N, C]*/, float* motion,
+                                  const int32_t* labels, int Bw, int nW, int ws, int heads, int hd,
+                                  int kv_shift, void* out_hi, void* out_lo, int plane_rows, void* stream);
 /* Named entry points of SURVEY.md section 8b (shims over atmvfi_window_attention). */
 int atmvfi_window_attn_cross_motion(const float* qkv, float* out, float* motion, const int32_t* labels,
                                     int Bw, int nW, int ws, int heads, int hd, void* stream);

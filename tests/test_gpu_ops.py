@@ -243,9 +243,18 @@ ATTN_CASES = [
 ]
 
 
-@pytest.mark.parametrize("case", ATTN_CASES, ids=lambda c: f"ws{c[0]}_hd{c[1]}_{c[3]}x{c[4]}_s{c[5]}_{'x' if c[6] else 'self'}")
-def test_window_attention(case, hip, cpu, dev):
+ATTN_CASES_X3 = [(8, 128, 2, 8, 16, 4, True), (16, 64, 2, 16, 16, 8, True), (10, 36, 2, 10, 20, 5, False), (14, 20, 2, 14, 14, 7, True)]
+
+
+@pytest.mark.parametrize("engine", ["f16x3", "f32"])
+@pytest.mark.parametrize("case", ATTN_CASES + ATTN_CASES_X3,
+                         ids=lambda c: f"ws{c[0]}_hd{c[1]}_{c[3]}x{c[4]}_s{c[5]}_{'x' if c[6] else 'self'}")
+def test_window_attention(case, engine, hip, cpu, dev):
+    """Both kernels behind the entry points: atmvfi_window_attention_f16x3 (what the f16x3 forward calls) and the exact-fp32
+    atmvfi_window_attention."""
     ws, hd, frames, h, w, shift, cross = case
+    hip = hip_ops.HipOps(dev)
+    hip.attention_f16x3 = engine == "f16x3"
     heads = 8
     C = heads * hd
     g = torch.Generator().manual_seed(ws * 100 + hd + shift)
