@@ -219,17 +219,61 @@ __device__ __forceinline__ f16x8_t tr_pair(unsigned a0, unsigned a1) {
 //   O^T = V^T P^T : B = P^T straight from the S registers: k-step kt2 takes tiles 2 kt2 and 2 kt2 + 1, element j of lane group g is
 //                   key 32 kt2 + 16 (j>>2) + 4 g + (j&3); A = V^T fragment in that same key order = two ds_read_b64_tr_b16 (the
 //                   gfx950 transposing read: 4 keys x 16 d per 16 lanes, delivered column-major) of the row-major V image.
-template <int NT>
-__global__ __launch_bounds__(64 * NT) void window_attn_x3_kernel(
+// The hi / lo' split under MODE.FP16_OVFL = 1 (set at the top of window_attn_x3_kernel): a conversion to fp16 that overflows then
+// returns +-65504 instead of +-inf (tools/probes/f16_ovfl_probe.hip), which is what the four v_med3_f32 of split_pair are for --
+// 3 VALU instructions per value instead of 5, bit-identical for every finite input (a true inf stays inf: it ends as NaN here
+// and as a saturated value in split_pair; the fp32 reference has inf or NaN there either way).
+__device__ __forceinline__ void split_pair_ovfl(const f32x2 x, f16x2& hi, f16x2& lo) {
+    hi = __builtin_convertvector(x, f16x2);
+    lo = __builtin_convertvector((x - __builtin_convertvector(hi, f32x2)) * 1024.0f, f16x2);
+}
+__device__ __forceinline__ void sink_store4_ovfl(const RowSink& s, long long row, int c, const f32x4 v) {
+    if (s.f32) *reinterpret_cast<f32x4*>(s.f32 + row * s.ld + c) = v;
+    if (s.hi) {
+        f16x2 h0, l0, h1, l1;
+        split_pair_ovfl((f32x2){v.x, v.y}, h0, l0);
+        split_pair_ovfl((f32x2){v.z, v.w}, h1, l1);
+        const long long off = ((long long)(c >> 5) * s.plane_rows + row) * 32 + (c & 31);
+        *reinterpret_cast<f16x4*>(s.hi + off) = (f16x4){h0.x, h0.y, h1.x, h1.y};
+        *reinterpret_cast<f16x4*>(s.lo + off) = (f16x4){l0.x, l0.y, l1.x, l1.y};
+    }
+}
+#ifdef ATMVFI_STAMP
+__device__ unsigned long long* g_attn_stamp = nullptr;   // diagnostic build only: phase cycles of workgroup 0, wave 0 (tools/stamp_attn.py)
+#define AT_STAMP(i)                                                     \
+    do {                                                                \
+        if (stamping) {                                                 \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+            tacc[i] += t_ - tlast;                                      \
+            tlast = t_;                                                 \
+        }                                                               \
+    } while (0)
+#else
+#define AT_STAMP(i) do { } while (0)
+#endif
+// Persistent: a workgroup walks (window, head) items v = blockIdx.x, + gridDim.x, ... (grid a multiple of 8, so v & 7 stays the XCD and
+// the heads of a window still run together on one XCD).  The K / V rows of the NEXT item are requested into registers before the
+// current item's products start and converted into the LDS images after them (8 160 one-shot workgroups spent most of their life
+// waiting for their first loads and for the dispatcher); everything that does not depend on the item -- the zero padding of both
+// images, the key-position columns -- is written once.
+template <int NT, int DCH>        // DCH = ceil(hd / 32): 32-wide d chunks of the QK^T product
+__global__ __launch_bounds__(64 * NT, (NT <= 4 ? 3 : NT <= 8 ? 2 : NT <= 12 ? 3 : 4)) void window_attn_x3_kernel(
     const float* __restrict__ qkv, const RowSink out, float* __restrict__ motion,
     const int* __restrict__ labels, int N, int nW, int ws, int heads, int hd, int C, int Bw, int kv_shift,
-    float scale) {
+    float scale, int vitems) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");      // MODE.FP16_OVFL: fp16 conversions saturate (split_pair_ovfl)
     constexpr int NPAD = NT * 16, KT2 = (NT + 1) / 2, VROWS = 32 * KT2, T = 64 * NT;
-    constexpr int MAXC = NT >= 13 ? 2 : 4;       // 32-wide d chunks: hd <= 128 (<= 64 for the 13..16-tile windows: 1024 threads leave 128 registers)
-    const int D32 = (hd + 31) >> 5, DT = (hd + 15) >> 4;
-    const int SPK = D32 <= 1 ? 4 : D32 == 2 ? 8 : 16;     // 16-byte slots per K row and plane (power of two: XOR swizzle)
-    const int KS = SPK * 16;                              // K row pitch, bytes
+    // windows of more than 128 tokens (9+ waves) have no registers for the next item's rows: one item per workgroup there (the
+    // loop below runs once and the compiler sees it)
+    constexpr bool PERSIST = NT <= 8, PREFETCH = PERSIST, PREFETCH_Q = PERSIST;
+    constexpr int UNR = 2 * DCH;                  // 4-float units of K and of V per thread: N hd / 4 <= 64 NT * 2 DCH
+    // With a motion output the V image carries four more columns hd .. hd + 3 = (key x, key y, 0, 0): the expected key position
+    // sum_k P[q,k] k_xy falls out of the PV product as two more output columns instead of ~9 VALU instructions per (q, key).
+    constexpr int D32 = DCH;
+    const int DT = (hd + (motion ? 4 : 0) + 15) >> 4;
+    constexpr int SPK = D32 <= 1 ? 4 : D32 == 2 ? 8 : 16;     // 16-byte slots per K row and plane (power of two: XOR swizzle)
+    constexpr int KS = SPK * 16;                              // K row pitch, bytes
     const int VS = 32 * DT + ((DT & 1) ? 0 : 32);         // V row pitch, bytes: odd multiple of 32
     unsigned char* Kh = reinterpret_cast<unsigned char*>(smem);
     unsigned char* Kl = Kh + NPAD * KS;
@@ -238,11 +282,6 @@ __global__ __launch_bounds__(64 * NT) void window_attn_x3_kernel(
     int* Ls = reinterpret_cast<int*>(Vl + VROWS * VS);
 
     const int tid = threadIdx.x;
-    const int slot = blockIdx.x >> 3;            // XCD-aware order: the heads of a window back to back on one XCD (see above)
-    const int b = (slot / heads) * 8 + (blockIdx.x & 7);
-    const int h = slot % heads;
-    if (b >= Bw) return;
-    const int bk = (b + kv_shift) % Bw;
     const int C3 = 3 * C;
     const int lane = tid & 63;
     const int w = tid >> 6;
@@ -250,202 +289,265 @@ __global__ __launch_bounds__(64 * NT) void window_attn_x3_kernel(
     const int g = lane >> 4;
     const int q = 16 * w + r;
     const bool qok = q < N;
+    const float inv_ws = 1.0f / (float)ws;        // key / ws for key < 256, ws <= 16: floor((key + 0.5) / ws) is exact in fp32
 
-    // ---- Q fragments of this wave (B operand: lane holds d = 32 c + 8 g .. + 7 of its query), requested before the staging ----
-    f32x4 qx[MAXC][2];
-    const float* qrow = qkv + ((long long)b * N + (qok ? q : 0)) * C3 + h * hd;
+    // ---- once: zero both images (padded keys, K's head-dim padding), then the key-position columns ----
+    {
+        const int words16 = (2 * NPAD * KS + 2 * VROWS * VS) >> 4;
+        for (int idx = tid; idx < words16; idx += T) reinterpret_cast<f32x4*>(smem)[idx] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+        if (motion && tid < N) {                  // small integers: exact in fp16, lo' = 0
+            const float ky = floorf(((float)tid + 0.5f) * inv_ws), kx = (float)tid - ky * (float)ws;
+            *reinterpret_cast<f16x4*>(Vh + tid * VS + (hd << 1)) = (f16x4){(_Float16)kx, (_Float16)ky, (_Float16)0.f, (_Float16)0.f};
+        }
+    }
+
+    // ---- staging units: 4 floats (row, d4) of the head's K and V, item independent per thread ----
+    const int dgr = hd >> 2;                      // units per row (hd % 4 == 0)
+    const int units = N * dgr;
+    const float inv_dgr = 1.0f / (float)dgr;
+    constexpr int ksw_mask = SPK - 1;
+    int goff[UNR], koff[UNR], voff[UNR];          // global offset (floats), LDS byte offsets; -1: no unit
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
-        if (c < D32) {
+    for (int u = 0; u < UNR; ++u) {
+        const int idx = u * T + tid;
+        const int row = (int)(((float)idx + 0.5f) * inv_dgr);     // exact: idx < 2^14
+        const int d4 = idx - row * dgr;
+        const bool ok = idx < units;
+        const int sw = SPK == 16 ? (row & 15) : SPK == 8 ? ((row >> 1) & 7) : ((0x1320 >> (((row >> 2) & 3) * 4)) & 3);
+        goff[u] = ok ? row * C3 + (d4 << 2) : 0;
+        koff[u] = ok ? row * KS + ((((d4 >> 1) ^ sw) & ksw_mask) << 4) + ((d4 & 1) << 3) : -1;
+        voff[u] = row * VS + (d4 << 3);
+    }
+
+    auto item_of = [&](int v, int& b, int& h) {
+        const int slot = v >> 3;
+        b = (slot / heads) * 8 + (v & 7);
+        h = slot % heads;
+    };
+    auto convert_store = [&](const f32x4 k4, const f32x4 v4, int ko, int vo) {
+        f16x2 h0, l0, h1, l1;
+        split_pair_ovfl((f32x2){k4.x, k4.y}, h0, l0);
+        split_pair_ovfl((f32x2){k4.z, k4.w}, h1, l1);
+        *reinterpret_cast<f16x4*>(Kh + ko) = (f16x4){h0.x, h0.y, h1.x, h1.y};
+        *reinterpret_cast<f16x4*>(Kl + ko) = (f16x4){l0.x, l0.y, l1.x, l1.y};
+        split_pair_ovfl((f32x2){v4.x, v4.y}, h0, l0);
+        split_pair_ovfl((f32x2){v4.z, v4.w}, h1, l1);
+        *reinterpret_cast<f16x4*>(Vh + vo) = (f16x4){h0.x, h0.y, h1.x, h1.y};
+        *reinterpret_cast<f16x4*>(Vl + vo) = (f16x4){l0.x, l0.y, l1.x, l1.y};
+    };
+
+    int v = blockIdx.x, b, h;
+    item_of(v, b, h);
+    while (v < vitems && b >= Bw) {               // the padded tail of the virtual item space (Bw not a multiple of 8)
+        v += gridDim.x;
+        item_of(v, b, h);
+    }
+    if (v >= vitems) return;
+
+    f32x4 k0[UNR], v0[UNR];                       // the rows of the current item (requested one item ahead)
+    auto request0 = [&](int bb, int hh) {
+        const float* kvbase = qkv + (long long)((bb + kv_shift) % Bw) * N * C3 + C + hh * hd;
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            if (u * T < units) {                  // wave-uniform: hd = 48 needs 3 of the 4 units a thread may have
+                k0[u] = *reinterpret_cast<const f32x4*>(kvbase + goff[u]);
+                v0[u] = *reinterpret_cast<const f32x4*>(kvbase + goff[u] + C);
+            }
+        }
+    };
+    request0(b, h);
+    // Q fragments of this wave (B operand: lane holds d = 32 c + 8 g .. + 7 of its query), also requested one item ahead: right
+    // after the QK^T product, into the registers its operands leave.  Requested at the top of an item they would sit BEHIND the
+    // previous item's stores in the in-order vmcnt, and every item would wait for a store round trip plus a load round trip
+    // (SQ_WAIT_ANY was 65 % of the wave cycles).
+    f32x4 qx[DCH][2];
+    auto request_q = [&](int bb, int hh) {
+        const float* qrow = qkv + ((long long)bb * N + (qok ? q : 0)) * C3 + hh * hd;
+#pragma unroll
+        for (int c = 0; c < DCH; ++c)
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 const int d = 32 * c + 8 * g + 4 * hf;
                 qx[c][hf] = *reinterpret_cast<const f32x4*>(qrow + (d < hd ? d : 0));
             }
-        }
-    }
+    };
+    request_q(b, h);
+#ifdef ATMVFI_STAMP
+    const bool stamping = g_attn_stamp && blockIdx.x == 0 && tid < 64;
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0, titems = 0;
+#endif
 
-    // ---- stage K and V (fp32 -> fp16 hi / lo'), zeros for padded keys and for K's head-dim padding; all loads of a pass are
-    // requested before the first conversion (unconditional loads from clamped addresses, zeroed by selects) ----
-    const int dg = 8 * D32;                       // 4-float units per K row (padding included)
-    const float inv_dg = 1.0f / (float)dg;
-    const int ksw_mask = SPK - 1;
-    constexpr int UNR = 4;
-    const float* kvbase = qkv + (long long)bk * N * C3 + C + h * hd;
-    for (int base = 0; base < VROWS * dg; base += T * UNR) {
-        f32x4 kv[UNR], vv[UNR];
-        int rowv[UNR], d4v[UNR];
-        bool okv[UNR];
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const int idx = base + u * T + tid;
-            const int row = (int)(((float)idx + 0.5f) * inv_dg);      // exact: idx < 2^13
-            const int d4 = idx - row * dg;
-            rowv[u] = row;
-            d4v[u] = d4;
-            okv[u] = row < N && (d4 << 2) < hd;
-            const float* p = kvbase + (long long)(okv[u] ? row : 0) * C3 + (okv[u] ? (d4 << 2) : 0);
-            kv[u] = *reinterpret_cast<const f32x4*>(p);
-            vv[u] = *reinterpret_cast<const f32x4*>(p + C);
-        }
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const int row = rowv[u], d4 = d4v[u];
-            if (row < VROWS) {
-                const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
-                const f32x4 k4 = okv[u] ? kv[u] : z, v4 = okv[u] ? vv[u] : z;
-                f16x2 h0, l0, h1, l1;
-                if (row < NPAD) {
-                    split_pair((f32x2){k4.x, k4.y}, h0, l0);
-                    split_pair((f32x2){k4.z, k4.w}, h1, l1);
-                    const int sw = SPK == 16 ? (row & 15) : SPK == 8 ? ((row >> 1) & 7) : ((0x1320 >> (((row >> 2) & 3) * 4)) & 3);
-                    const int off = row * KS + ((((d4 >> 1) ^ sw) & ksw_mask) << 4) + ((d4 & 1) << 3);
-                    *reinterpret_cast<f16x4*>(Kh + off) = (f16x4){h0.x, h0.y, h1.x, h1.y};
-                    *reinterpret_cast<f16x4*>(Kl + off) = (f16x4){l0.x, l0.y, l1.x, l1.y};
-                }
-                if (d4 < 4 * DT) {
-                    split_pair((f32x2){v4.x, v4.y}, h0, l0);
-                    split_pair((f32x2){v4.z, v4.w}, h1, l1);
-                    const int off = row * VS + (d4 << 3);
-                    *reinterpret_cast<f16x4*>(Vh + off) = (f16x4){h0.x, h0.y, h1.x, h1.y};
-                    *reinterpret_cast<f16x4*>(Vl + off) = (f16x4){l0.x, l0.y, l1.x, l1.y};
-                }
-            }
-        }
-    }
-    for (int idx = tid; idx < NPAD; idx += T)
-        Ls[idx] = (labels && idx < N) ? labels[(long long)(b % nW) * N + idx] : 0;
-
-    // split the Q fragments (zero outside the head dim / the window)
-    f16x8_t qh[MAXC], ql[MAXC];
-#pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
-        if (c < D32) {
-            f16x2 hh[4], ll[4];
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                const bool ok = qok && (32 * c + 8 * g + 4 * hf) < hd;
-                const f32x4 x = qx[c][hf];
-                split_pair(ok ? (f32x2){x.x, x.y} : (f32x2){0.f, 0.f}, hh[2 * hf], ll[2 * hf]);
-                split_pair(ok ? (f32x2){x.z, x.w} : (f32x2){0.f, 0.f}, hh[2 * hf + 1], ll[2 * hf + 1]);
-            }
-            qh[c] = (f16x8_t){hh[0].x, hh[0].y, hh[1].x, hh[1].y, hh[2].x, hh[2].y, hh[3].x, hh[3].y};
-            ql[c] = (f16x8_t){ll[0].x, ll[0].y, ll[1].x, ll[1].y, ll[2].x, ll[2].y, ll[3].x, ll[3].y};
-        }
-    }
-    __syncthreads();
-
-    // ---- S^T = K Q^T ----
     const int rsw = SPK == 16 ? r : SPK == 8 ? (r >> 1) : ((0x1320 >> ((r >> 2) * 4)) & 3);     // the swizzle of rows 16 kt + r
-    f32x4 s[NT];
-#pragma unroll
-    for (int kt = 0; kt < NT; ++kt) {
-        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, cor = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
-            if (c < D32) {
-                const int off = (16 * kt + r) * KS + ((((4 * c + g) ^ rsw) & ksw_mask) << 4);
-                const f16x8_t kh = *reinterpret_cast<const f16x8_t*>(Kh + off);
-                const f16x8_t kl = *reinterpret_cast<const f16x8_t*>(Kl + off);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh[c], acc, 0, 0, 0);
-                cor = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql[c], cor, 0, 0, 0);
-                cor = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh[c], cor, 0, 0, 0);
-            }
-        }
-        s[kt] = acc + cor * (1.0f / 1024.0f);
-    }
-
-    // ---- scale + mask + softmax over keys (attention.py:192-200) ----
-    const int lab_q = Ls[qok ? q : 0];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int kt = 0; kt < NT; ++kt) {
-        const int4 lk = *reinterpret_cast<const int4*>(Ls + 16 * kt + 4 * g);
-        const int lks[4] = {lk.x, lk.y, lk.z, lk.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int key = 16 * kt + 4 * g + e;
-            float v = s[kt][e] * scale;
-            if (labels && lks[e] != lab_q) v += -100.0f;
-            if (key >= N) v = -INFINITY;
-            s[kt][e] = v;
-            mx = fmaxf(mx, v);
-        }
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    float sum = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float p = expf(s[kt][e] - mx);
-            s[kt][e] = p;
-            sum += p;
-        }
-    const float inv_ws = 1.0f / (float)ws;        // key / ws for key < 256, ws <= 16: floor((key + 0.5) / ws) is exact in fp32
-    sum += __shfl_xor(sum, 16);
-    sum += __shfl_xor(sum, 32);
-    const float inv = 1.0f / sum;
-    const float qy = floorf(((float)q + 0.5f) * inv_ws), qx_ = (float)q - qy * (float)ws;
-    float mox = 0.f, moy = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int key = 16 * kt + 4 * g + e;
-            const float p = s[kt][e] * inv;
-            s[kt][e] = p;
-            const float ky = floorf(((float)key + 0.5f) * inv_ws);
-            mox += p * (((float)key - ky * (float)ws) - qx_);
-            moy += p * (ky - qy);
-        }
-    if (motion) {
-        mox += __shfl_xor(mox, 16);
-        mox += __shfl_xor(mox, 32);
-        moy += __shfl_xor(moy, 16);
-        moy += __shfl_xor(moy, 32);
-        if (g == 0 && qok) {
-            float* mp = motion + (((long long)b * N + q) * heads + h) * 2;
-            mp[0] = mox;
-            mp[1] = moy;
-        }
-    }
-
-    // ---- P^T fragments: tiles 2 kt2 and 2 kt2 + 1 of the S registers, split in place ----
-    f16x8_t ph[KT2], pl[KT2];
-#pragma unroll
-    for (int k2 = 0; k2 < KT2; ++k2) {
-        const f32x4 a = s[2 * k2];
-        const f32x4 c = (2 * k2 + 1 < NT) ? s[2 * k2 + 1 < NT ? 2 * k2 + 1 : 0] : (f32x4){0.f, 0.f, 0.f, 0.f};
-        f16x2 hh[4], ll[4];
-        split_pair((f32x2){a.x, a.y}, hh[0], ll[0]);
-        split_pair((f32x2){a.z, a.w}, hh[1], ll[1]);
-        split_pair((f32x2){c.x, c.y}, hh[2], ll[2]);
-        split_pair((f32x2){c.z, c.w}, hh[3], ll[3]);
-        ph[k2] = (f16x8_t){hh[0].x, hh[0].y, hh[1].x, hh[1].y, hh[2].x, hh[2].y, hh[3].x, hh[3].y};
-        pl[k2] = (f16x8_t){ll[0].x, ll[0].y, ll[1].x, ll[1].y, ll[2].x, ll[2].y, ll[3].x, ll[3].y};
-    }
-
-    // ---- O^T = V^T P^T.  Transposed read: lane 4 qq + p of a 16-lane group supplies the address of block row qq, columns
-    // 4 p .. 4 p + 3; lane i receives column i of the 4 rows.  EXEC is all ones here (no lane has left the kernel). ----
-    const long long orow = (long long)b * N + (qok ? q : 0);
     const unsigned vlane = (unsigned)((4 * g + ((lane >> 2) & 3)) * VS + ((lane & 3) << 3));
     const unsigned vh0 = lds_offset(Vh) + vlane, vl0 = lds_offset(Vl) + vlane;
-    for (int dt = 0; dt < DT; ++dt) {
-        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, cor = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float qy = floorf(((float)q + 0.5f) * inv_ws), qxc = (float)q - qy * (float)ws;
+    constexpr float LOG2E = 1.4426950408889634f;
+    const float sl2 = scale * LOG2E;
+
+    for (;;) {
+#ifdef ATMVFI_STAMP
+        if (stamping) { tlast = __builtin_amdgcn_s_memtime(); ++titems; }
+#endif
+        // ---- stage K and V (fp32 -> fp16 hi / lo') from the registers ----
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+            if (koff[u] >= 0) convert_store(k0[u], v0[u], koff[u], voff[u]);
+        AT_STAMP(0);
+        if (labels && tid < N) Ls[tid] = labels[(long long)(b % nW) * N + tid];      // 64 NT threads >= N
+
+        // split the Q fragments (zero outside the head dim / the window)
+        f16x8_t qh[DCH], ql[DCH];
+#pragma unroll
+        for (int c = 0; c < DCH; ++c) {
+            if (c < D32) {
+                f16x2 hh[4], ll[4];
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const bool ok = qok && (32 * c + 8 * g + 4 * hf) < hd;
+                    const f32x4 x = qx[c][hf];
+                    split_pair_ovfl(ok ? (f32x2){x.x, x.y} : (f32x2){0.f, 0.f}, hh[2 * hf], ll[2 * hf]);
+                    split_pair_ovfl(ok ? (f32x2){x.z, x.w} : (f32x2){0.f, 0.f}, hh[2 * hf + 1], ll[2 * hf + 1]);
+                }
+                qh[c] = (f16x8_t){hh[0].x, hh[0].y, hh[1].x, hh[1].y, hh[2].x, hh[2].y, hh[3].x, hh[3].y};
+                ql[c] = (f16x8_t){ll[0].x, ll[0].y, ll[1].x, ll[1].y, ll[2].x, ll[2].y, ll[3].x, ll[3].y};
+            }
+        }
+        AT_STAMP(1);
+        __syncthreads();
+        AT_STAMP(2);
+
+        // ---- the next item of this workgroup; its first rows are on their way while this item is computed ----
+        int vn = vitems, bn = 0, hn = 0;
+        if constexpr (PERSIST) {
+            vn = v + gridDim.x;
+            item_of(vn, bn, hn);
+            while (vn < vitems && bn >= Bw) {
+                vn += gridDim.x;
+                item_of(vn, bn, hn);
+            }
+        }
+        const bool has_next = PERSIST && vn < vitems;
+        if (PREFETCH && has_next) request0(bn, hn);
+        AT_STAMP(3);
+
+        // ---- S^T = K Q^T ----
+        f32x4 s[NT];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, cor = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < DCH; ++c) {
+                if (c < D32) {
+                    const int off = (16 * kt + r) * KS + ((((4 * c + g) ^ rsw) & ksw_mask) << 4);
+                    const f16x8_t kh = *reinterpret_cast<const f16x8_t*>(Kh + off);
+                    const f16x8_t kl = *reinterpret_cast<const f16x8_t*>(Kl + off);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh[c], acc, 0, 0, 0);
+                    cor = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql[c], cor, 0, 0, 0);
+                    cor = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh[c], cor, 0, 0, 0);
+                }
+            }
+            s[kt] = acc + cor * (1.0f / 1024.0f);
+        }
+
+        if (PREFETCH_Q && has_next) request_q(bn, hn);
+        AT_STAMP(4);
+        // ---- scale + mask + softmax numerators over keys (attention.py:192-200) in base 2: exp(x - m) = 2^((x - m) log2 e); the
+        // division by the sum is applied to the outputs (a lane owns ONE query), so P stays the numerators in (0, 1] ----
+        float mx = -INFINITY;
+        if (labels) {
+            const int lab_q = Ls[qok ? q : 0];
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                const int4 lk = *reinterpret_cast<const int4*>(Ls + 16 * kt + 4 * g);     // padded keys: stale, masked below
+                const int lks[4] = {lk.x, lk.y, lk.z, lk.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = s[kt][e] * sl2;
+                    x += lks[e] != lab_q ? -100.0f * LOG2E : 0.0f;
+                    s[kt][e] = x;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) s[kt] *= sl2;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)                // only the last tile has padded keys (NT = ceil(N / 16))
+            if (16 * (NT - 1) + 4 * g + e >= N) s[NT - 1][e] = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mx = fmaxf(mx, s[kt][e]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float p = __builtin_amdgcn_exp2f(s[kt][e] - mx);
+                s[kt][e] = p;
+                sum += p;
+            }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+
+        // ---- P^T fragments: tiles 2 kt2 and 2 kt2 + 1 of the S registers, split in place ----
+        f16x8_t ph[KT2], pl[KT2];
 #pragma unroll
         for (int k2 = 0; k2 < KT2; ++k2) {
-            const unsigned o0 = (unsigned)(32 * k2 * VS + 32 * dt), o1 = o0 + (unsigned)(16 * VS);
-            const f16x8_t vh = tr_pair(vh0 + o0, vh0 + o1), vl = tr_pair(vl0 + o0, vl0 + o1);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph[k2], acc, 0, 0, 0);
-            cor = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl[k2], cor, 0, 0, 0);
-            cor = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph[k2], cor, 0, 0, 0);
+            const f32x4 a = s[2 * k2];
+            const f32x4 c = (2 * k2 + 1 < NT) ? s[2 * k2 + 1 < NT ? 2 * k2 + 1 : 0] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            f16x2 hh[4], ll[4];
+            split_pair_ovfl((f32x2){a.x, a.y}, hh[0], ll[0]);
+            split_pair_ovfl((f32x2){a.z, a.w}, hh[1], ll[1]);
+            split_pair_ovfl((f32x2){c.x, c.y}, hh[2], ll[2]);
+            split_pair_ovfl((f32x2){c.z, c.w}, hh[3], ll[3]);
+            ph[k2] = (f16x8_t){hh[0].x, hh[0].y, hh[1].x, hh[1].y, hh[2].x, hh[2].y, hh[3].x, hh[3].y};
+            pl[k2] = (f16x8_t){ll[0].x, ll[0].y, ll[1].x, ll[1].y, ll[2].x, ll[2].y, ll[3].x, ll[3].y};
         }
-        const f32x4 o = acc + cor * (1.0f / 1024.0f);
-        const int d = 16 * dt + 4 * g;
-        if (qok && d < hd) sink_store4(out, orow, h * hd + d, o);
+
+        AT_STAMP(5);
+        // ---- O^T = V^T P^T.  Transposed read: lane 4 qq + p of a 16-lane group supplies the address of block row qq, columns
+        // 4 p .. 4 p + 3; lane i receives column i of the 4 rows.  EXEC is all ones here (every lane of the wave walks the items). ----
+        const long long orow = (long long)b * N + (qok ? q : 0);
+        for (int dt = 0; dt < DT; ++dt) {
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, cor = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k2 = 0; k2 < KT2; ++k2) {
+                const unsigned o0 = (unsigned)(32 * k2 * VS + 32 * dt), o1 = o0 + (unsigned)(16 * VS);
+                const f16x8_t vh = tr_pair(vh0 + o0, vh0 + o1), vl = tr_pair(vl0 + o0, vl0 + o1);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph[k2], acc, 0, 0, 0);
+                cor = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl[k2], cor, 0, 0, 0);
+                cor = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph[k2], cor, 0, 0, 0);
+            }
+            const f32x4 o = (acc + cor * (1.0f / 1024.0f)) * inv;
+            const int d = 16 * dt + 4 * g;
+            if (qok && d < hd) sink_store4_ovfl(out, orow, h * hd + d, o);
+            if (motion && qok && d == hd) {       // sum_k P (k_xy - q_xy) = sum_k P k_xy - q_xy   (sum_k P = 1)
+                float* mp = motion + (((long long)b * N + q) * heads + h) * 2;
+                mp[0] = o[0] - qxc;
+                mp[1] = o[1] - qy;
+            }
+        }
+        AT_STAMP(6);
+        if (!has_next) break;
+        v = vn;
+        b = bn;
+        h = hn;
+        if (!PREFETCH) request0(b, h);
+        if (!PREFETCH_Q) request_q(b, h);
+        __syncthreads();                          // every wave is done with the images
+        AT_STAMP(7);
     }
+#ifdef ATMVFI_STAMP
+    if (stamping && tid == 0) {
+        for (int i = 0; i < 8; ++i) g_attn_stamp[i] = tacc[i];
+        g_attn_stamp[8] = titems;
+    }
+#endif
 }
 
 __global__ void motion_head_kernel(const float* __restrict__ motion, const int* __restrict__ row_map,
@@ -495,23 +597,52 @@ int launch_attn(const float* qkv, const RowSink out, float* motion, const int* l
     return atmvfi::check_launch("window_attention");
 }
 
-template <int NT>
+template <int NT, int DCH>
 int launch_attn_x3(const float* qkv, const RowSink out, float* motion, const int* labels, int Bw, int nW, int N, int ws,
                    int heads, int hd, int kv_shift, hipStream_t s) {
-    const int d32 = (hd + 31) / 32, dt = (hd + 15) / 16, npad = NT * 16, vrows = 32 * ((NT + 1) / 2);
-    const int ks = (d32 <= 1 ? 4 : d32 == 2 ? 8 : 16) * 16, vs = 32 * dt + ((dt & 1) ? 0 : 32);
+    const int d32 = (hd + 31) / 32, dt = (hd + (motion ? 4 : 0) + 15) / 16, npad = NT * 16, vrows = 32 * ((NT + 1) / 2);
+    const int ks = (d32 <= 1 ? 4 : d32 == 2 ? 8 : 16) * 16, vs = 32 * dt + ((dt & 1) ? 0 : 32);      // as in the kernel
     const size_t lds = 2 * (size_t)npad * ks + 2 * (size_t)vrows * vs + (size_t)npad * sizeof(int);
     ATMVFI_REQUIRE(hd <= (NT >= 13 ? 64 : 128), ATMVFI_EINVAL, "window_attention: head dim %d too large for a %d-token window", hd, N);
     ATMVFI_REQUIRE(lds <= 160 * 1024, ATMVFI_EINVAL,
                    "window_attention: K/V tile of %zu bytes exceeds the 160 KiB LDS (ws %d, hd %d)", lds, ws, hd);
     if (lds > 48 * 1024) {
-        const hipError_t e = atmvfi::allow_dynamic_lds<window_attn_x3_kernel<NT>>(lds);
+        const hipError_t e = atmvfi::allow_dynamic_lds<window_attn_x3_kernel<NT, DCH>>(lds);
         ATMVFI_REQUIRE(e == hipSuccess, ATMVFI_ELAUNCH, "window_attention: hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
     const float scale = 1.0f / sqrtf((float)hd);
-    hipLaunchKernelGGL(window_attn_x3_kernel<NT>, dim3((unsigned)((Bw + 7) / 8 * 8 * heads)), dim3(64 * NT), lds, s, qkv, out, motion,
-                       labels, N, nW, ws, heads, hd, heads * hd, Bw, kv_shift, scale);
+    // persistent grid: as many workgroups as the CUs hold at once (LDS, registers, threads: asked of the runtime once per instance
+    // and LDS size), a multiple of 8, at most one per item
+    const int vitems = (Bw + 7) / 8 * 8 * heads;
+    static std::atomic<long long> occ_cache{0};   // (lds bytes << 8) | workgroups per CU
+    long long oc = occ_cache.load(std::memory_order_relaxed);
+    if ((oc >> 8) != (long long)lds || (oc & 255) == 0) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, window_attn_x3_kernel<NT, DCH>, 64 * NT, lds) != hipSuccess || n < 1) n = 1;
+        oc = ((long long)lds << 8) | (n > 255 ? 255 : n);
+        occ_cache.store(oc, std::memory_order_relaxed);
+    }
+    const int per_cu = (int)(oc & 255);
+    int grid = atmvfi::cu_count() * per_cu;
+    if (grid > vitems || NT > 8) grid = vitems;   // vitems is a multiple of 8; NT > 8: one item per workgroup (PERSIST in the kernel)
+    hipLaunchKernelGGL((window_attn_x3_kernel<NT, DCH>), dim3((unsigned)grid), dim3(64 * NT), lds, s, qkv, out, motion, labels, N, nW, ws,
+                       heads, hd, heads * hd, Bw, kv_shift, scale, vitems);
     return atmvfi::check_launch("window_attention_f16x3");
+}
+
+template <int NT>
+int launch_attn_x3_d(const float* qkv, const RowSink out, float* motion, const int* labels, int Bw, int nW, int N, int ws,
+                     int heads, int hd, int kv_shift, hipStream_t s) {
+    ATMVFI_REQUIRE(hd <= (NT >= 13 ? 64 : 128), ATMVFI_EINVAL, "window_attention: head dim %d too large for a %d-token window", hd, N);
+    switch ((hd + 31) / 32) {
+        case 1: return launch_attn_x3<NT, 1>(qkv, out, motion, labels, Bw, nW, N, ws, heads, hd, kv_shift, s);
+        case 2: return launch_attn_x3<NT, 2>(qkv, out, motion, labels, Bw, nW, N, ws, heads, hd, kv_shift, s);
+    }
+    if constexpr (NT <= 12) {
+        if (hd <= 96) return launch_attn_x3<NT, 3>(qkv, out, motion, labels, Bw, nW, N, ws, heads, hd, kv_shift, s);
+        return launch_attn_x3<NT, 4>(qkv, out, motion, labels, Bw, nW, N, ws, heads, hd, kv_shift, s);
+    }
+    return ATMVFI_EINVAL;
 }
 
 int attention_entry(bool x3, const float* qkv, float* out, float* motion, const int32_t* labels, int Bw, int nW, int ws, int heads,
@@ -531,7 +662,7 @@ int attention_entry(bool x3, const float* qkv, float* out, float* motion, const 
     hipStream_t s = (hipStream_t)stream;
 #define ATMVFI_ATTN_CASE(k)                                                                                              \
     case k:                                                                                                              \
-        return x3 ? launch_attn_x3<k>(qkv, sink, motion, labels, Bw, nW, N, ws, heads, hd, kv_shift, s)                   \
+        return x3 ? launch_attn_x3_d<k>(qkv, sink, motion, labels, Bw, nW, N, ws, heads, hd, kv_shift, s)                 \
                   : launch_attn<k>(qkv, sink, motion, labels, Bw, nW, N, ws, heads, hd, kv_shift, s);
     switch (nt) {
         ATMVFI_ATTN_CASE(1) ATMVFI_ATTN_CASE(2) ATMVFI_ATTN_CASE(3) ATMVFI_ATTN_CASE(4) ATMVFI_ATTN_CASE(5)
@@ -545,6 +676,12 @@ int attention_entry(bool x3, const float* qkv, float* out, float* motion, const 
 }
 
 }  // namespace
+
+#ifdef ATMVFI_STAMP
+extern "C" int atmvfi_debug_set_attn_stamp_buffer(void* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamp), &buf, sizeof(buf)) == hipSuccess ? 0 : ATMVFI_ELAUNCH;
+}
+#endif
 
 extern "C" int atmvfi_window_attention_f16x3(const float* qkv, float* out, float* motion, const int32_t* labels, int Bw,
                                               int nW, int ws, int heads, int hd, int kv_shift, void* out_hi, void* out_lo,
