@@ -30,6 +30,7 @@ __global__ __launch_bounds__(64 * NT) void window_attn_kernel(
     const float* __restrict__ qkv, const RowSink out, float* __restrict__ motion,
     const int* __restrict__ labels, int N, int nW, int ws, int heads, int hd, int C, int Bw, int kv_shift,
     float scale) {
+    fp16_saturate_on();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NPAD = NT * 16;
     const int nchunks = (hd + 15) >> 4;          // 16-wide d chunks (QK^T) = 16-row d tiles (PV)
@@ -219,25 +220,6 @@ __device__ __forceinline__ f16x8_t tr_pair(unsigned a0, unsigned a1) {
 //   O^T = V^T P^T : B = P^T straight from the S registers: k-step kt2 takes tiles 2 kt2 and 2 kt2 + 1, element j of lane group g is
 //                   key 32 kt2 + 16 (j>>2) + 4 g + (j&3); A = V^T fragment in that same key order = two ds_read_b64_tr_b16 (the
 //                   gfx950 transposing read: 4 keys x 16 d per 16 lanes, delivered column-major) of the row-major V image.
-// The hi / lo' split under MODE.FP16_OVFL = 1 (set at the top of window_attn_x3_kernel): a conversion to fp16 that overflows then
-// returns +-65504 instead of +-inf (tools/probes/f16_ovfl_probe.hip), which is what the four v_med3_f32 of split_pair are for --
-// 3 VALU instructions per value instead of 5, bit-identical for every finite input (a true inf stays inf: it ends as NaN here
-// and as a saturated value in split_pair; the fp32 reference has inf or NaN there either way).
-__device__ __forceinline__ void split_pair_ovfl(const f32x2 x, f16x2& hi, f16x2& lo) {
-    hi = __builtin_convertvector(x, f16x2);
-    lo = __builtin_convertvector((x - __builtin_convertvector(hi, f32x2)) * 1024.0f, f16x2);
-}
-__device__ __forceinline__ void sink_store4_ovfl(const RowSink& s, long long row, int c, const f32x4 v) {
-    if (s.f32) *reinterpret_cast<f32x4*>(s.f32 + row * s.ld + c) = v;
-    if (s.hi) {
-        f16x2 h0, l0, h1, l1;
-        split_pair_ovfl((f32x2){v.x, v.y}, h0, l0);
-        split_pair_ovfl((f32x2){v.z, v.w}, h1, l1);
-        const long long off = ((long long)(c >> 5) * s.plane_rows + row) * 32 + (c & 31);
-        *reinterpret_cast<f16x4*>(s.hi + off) = (f16x4){h0.x, h0.y, h1.x, h1.y};
-        *reinterpret_cast<f16x4*>(s.lo + off) = (f16x4){l0.x, l0.y, l1.x, l1.y};
-    }
-}
 #ifdef ATMVFI_STAMP
 __device__ unsigned long long* g_attn_stamp = nullptr;   // diagnostic build only: phase cycles of workgroup 0, wave 0 (tools/stamp_attn.py)
 #define AT_STAMP(i)                                                     \
@@ -262,7 +244,7 @@ __global__ __launch_bounds__(64 * NT, (NT <= 4 ? 3 : NT <= 8 ? 2 : NT <= 12 ? 3 
     const int* __restrict__ labels, int N, int nW, int ws, int heads, int hd, int C, int Bw, int kv_shift,
     float scale, int vitems) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");      // MODE.FP16_OVFL: fp16 conversions saturate (split_pair_ovfl)
+    fp16_saturate_on();
     constexpr int NPAD = NT * 16, KT2 = (NT + 1) / 2, VROWS = 32 * KT2, T = 64 * NT;
     // windows of more than 128 tokens (9+ waves) have no registers for the next item's rows: one item per workgroup there (the
     // loop below runs once and the compiler sees it)
@@ -327,12 +309,12 @@ __global__ __launch_bounds__(64 * NT, (NT <= 4 ? 3 : NT <= 8 ? 2 : NT <= 12 ? 3 
     };
     auto convert_store = [&](const f32x4 k4, const f32x4 v4, int ko, int vo) {
         f16x2 h0, l0, h1, l1;
-        split_pair_ovfl((f32x2){k4.x, k4.y}, h0, l0);
-        split_pair_ovfl((f32x2){k4.z, k4.w}, h1, l1);
+        split_pair((f32x2){k4.x, k4.y}, h0, l0);
+        split_pair((f32x2){k4.z, k4.w}, h1, l1);
         *reinterpret_cast<f16x4*>(Kh + ko) = (f16x4){h0.x, h0.y, h1.x, h1.y};
         *reinterpret_cast<f16x4*>(Kl + ko) = (f16x4){l0.x, l0.y, l1.x, l1.y};
-        split_pair_ovfl((f32x2){v4.x, v4.y}, h0, l0);
-        split_pair_ovfl((f32x2){v4.z, v4.w}, h1, l1);
+        split_pair((f32x2){v4.x, v4.y}, h0, l0);
+        split_pair((f32x2){v4.z, v4.w}, h1, l1);
         *reinterpret_cast<f16x4*>(Vh + vo) = (f16x4){h0.x, h0.y, h1.x, h1.y};
         *reinterpret_cast<f16x4*>(Vl + vo) = (f16x4){l0.x, l0.y, l1.x, l1.y};
     };
@@ -406,8 +388,8 @@ __global__ __launch_bounds__(64 * NT, (NT <= 4 ? 3 : NT <= 8 ? 2 : NT <= 12 ? 3 
                 for (int hf = 0; hf < 2; ++hf) {
                     const bool ok = qok && (32 * c + 8 * g + 4 * hf) < hd;
                     const f32x4 x = qx[c][hf];
-                    split_pair_ovfl(ok ? (f32x2){x.x, x.y} : (f32x2){0.f, 0.f}, hh[2 * hf], ll[2 * hf]);
-                    split_pair_ovfl(ok ? (f32x2){x.z, x.w} : (f32x2){0.f, 0.f}, hh[2 * hf + 1], ll[2 * hf + 1]);
+                    split_pair(ok ? (f32x2){x.x, x.y} : (f32x2){0.f, 0.f}, hh[2 * hf], ll[2 * hf]);
+                    split_pair(ok ? (f32x2){x.z, x.w} : (f32x2){0.f, 0.f}, hh[2 * hf + 1], ll[2 * hf + 1]);
                 }
                 qh[c] = (f16x8_t){hh[0].x, hh[0].y, hh[1].x, hh[1].y, hh[2].x, hh[2].y, hh[3].x, hh[3].y};
                 ql[c] = (f16x8_t){ll[0].x, ll[0].y, ll[1].x, ll[1].y, ll[2].x, ll[2].y, ll[3].x, ll[3].y};
@@ -501,10 +483,10 @@ __global__ __launch_bounds__(64 * NT, (NT <= 4 ? 3 : NT <= 8 ? 2 : NT <= 12 ? 3 
             const f32x4 a = s[2 * k2];
             const f32x4 c = (2 * k2 + 1 < NT) ? s[2 * k2 + 1 < NT ? 2 * k2 + 1 : 0] : (f32x4){0.f, 0.f, 0.f, 0.f};
             f16x2 hh[4], ll[4];
-            split_pair_ovfl((f32x2){a.x, a.y}, hh[0], ll[0]);
-            split_pair_ovfl((f32x2){a.z, a.w}, hh[1], ll[1]);
-            split_pair_ovfl((f32x2){c.x, c.y}, hh[2], ll[2]);
-            split_pair_ovfl((f32x2){c.z, c.w}, hh[3], ll[3]);
+            split_pair((f32x2){a.x, a.y}, hh[0], ll[0]);
+            split_pair((f32x2){a.z, a.w}, hh[1], ll[1]);
+            split_pair((f32x2){c.x, c.y}, hh[2], ll[2]);
+            split_pair((f32x2){c.z, c.w}, hh[3], ll[3]);
             ph[k2] = (f16x8_t){hh[0].x, hh[0].y, hh[1].x, hh[1].y, hh[2].x, hh[2].y, hh[3].x, hh[3].y};
             pl[k2] = (f16x8_t){ll[0].x, ll[0].y, ll[1].x, ll[1].y, ll[2].x, ll[2].y, ll[3].x, ll[3].y};
         }
@@ -525,7 +507,7 @@ __global__ __launch_bounds__(64 * NT, (NT <= 4 ? 3 : NT <= 8 ? 2 : NT <= 12 ? 3 
             }
             const f32x4 o = (acc + cor * (1.0f / 1024.0f)) * inv;
             const int d = 16 * dt + 4 * g;
-            if (qok && d < hd) sink_store4_ovfl(out, orow, h * hd + d, o);
+            if (qok && d < hd) sink_store4(out, orow, h * hd + d, o);
             if (motion && qok && d == hd) {       // sum_k P (k_xy - q_xy) = sum_k P k_xy - q_xy   (sum_k P = 1)
                 float* mp = motion + (((long long)b * N + q) * heads + h) * 2;
                 mp[0] = o[0] - qxc;
@@ -555,6 +537,7 @@ __global__ void motion_head_kernel(const float* __restrict__ motion, const int* 
                                    const float* __restrict__ w1, const float* __restrict__ b1,
                                    float* __restrict__ out, int out_ld, long long out_gstride, int out_rpg,
                                    long long rows, int heads) {
+    fp16_saturate_on();
     const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= rows) return;
     const long long ro = row_map ? row_map[m] : m;

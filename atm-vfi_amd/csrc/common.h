@@ -64,16 +64,20 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-// The hi/lo split of the f16x3 engines on two values at once: hi = fp16(clamp(x)), lo' = fp16(clamp((x - hi) * 1024)), clamps at
-// +-65504.  Written on 2-vectors so that it compiles to v_med3 / v_cvt_pk_f16_f32 / v_pk_add_f32 / v_pk_mul_f32 -- 5 VALU
-// instructions per value; the scalar fminf(fmaxf()) form cost 8.5 (NaN-canonicalising v_max, one conversion per half, a second
-// conversion to pack) and made the operand staging of gemm_f16x3 dearer than its MFMAs.  Bit-identical for every non-NaN input.
+// MODE.FP16_OVFL = 1 for the rest of the wave: a conversion to fp16 that overflows returns +-65504 instead of +-inf (a true
+// inf stays inf; tools/probes/f16_ovfl_probe.hip).  Every kernel that splits values calls this first: the split below relies on
+// it for its saturation.
+__device__ __forceinline__ void fp16_saturate_on() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1"); }
+
+// The hi/lo split of the f16x3 engines on two values at once: hi = fp16(x), lo' = fp16((x - hi) * 1024), both conversions
+// saturating at +-65504 through MODE.FP16_OVFL (fp16_saturate_on() at the kernel's top): v_cvt_pk_f16_f32, two v_cvt_f32_f16,
+// v_pk_add_f32, v_pk_mul_f32, v_cvt_pk_f16_f32 -- 3 VALU instructions per value.  Until round 2 the saturation was four
+// v_med3_f32 (5 per value, and the epilogues / operand stagings that split are VALU-bound); bit-identical for every finite
+// input.  An infinite input now stays infinite in hi and makes lo' NaN (it was +-65504 / +-65504): the fp32 reference has inf or
+// NaN downstream of such a value as well.
 __device__ __forceinline__ void split_pair(const f32x2 x, f16x2& hi, f16x2& lo) {
-    const f32x2 m = {__builtin_amdgcn_fmed3f(x.x, -65504.0f, 65504.0f), __builtin_amdgcn_fmed3f(x.y, -65504.0f, 65504.0f)};
-    hi = __builtin_convertvector(m, f16x2);
-    const f32x2 d = (x - __builtin_convertvector(hi, f32x2)) * 1024.0f;
-    const f32x2 c = {__builtin_amdgcn_fmed3f(d.x, -65504.0f, 65504.0f), __builtin_amdgcn_fmed3f(d.y, -65504.0f, 65504.0f)};
-    lo = __builtin_convertvector(c, f16x2);
+    hi = __builtin_convertvector(x, f16x2);
+    lo = __builtin_convertvector((x - __builtin_convertvector(hi, f32x2)) * 1024.0f, f16x2);
 }
 
 // Output of a row-producing kernel: fp32 rows, and/or the split-plane pair (hi = fp16(x), lo = fp16((x - hi) * 1024), both

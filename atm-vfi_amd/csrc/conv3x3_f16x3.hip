@@ -31,6 +31,7 @@ namespace {
 // load / LDS-DMA instruction of the GEMM engines moves are one contiguous KiB (gemm_f16x3.hip, gemm_split.hip)
 __global__ void pack_split_kernel(int mode, const float* __restrict__ src, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
                                   int Cout, int Cin, int kh, int kw, int rows, int cin_pad, int coutp) {
+    fp16_saturate_on();
     const int taps = (mode == ATMVFI_GEMM_DECONV) ? 1 : kh * kw;
     const int cpt = cin_pad >> 5;
     const long long total = (long long)rows * taps * cin_pad;
@@ -61,6 +62,7 @@ __global__ void pack_split_kernel(int mode, const float* __restrict__ src, _Floa
 // conv3x3 layout: k-step major, tap-packed tail (see the file header)
 __global__ void pack_conv3x3_kernel(const float* __restrict__ src, _Float16* __restrict__ hi, _Float16* __restrict__ lo, int Cout, int Cin,
                                     int rows, int cf, int tail) {
+    fp16_saturate_on();
     const int nsteps = 9 * (cf >> 5) + (tail ? 3 : 0);
     const long long total = (long long)nsteps * rows * 32;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {

@@ -43,6 +43,7 @@ namespace {
 //               barrier wait and halo conversion run under the other's MFMAs (at twice the weight traffic per pixel)
 template <int WN, int NWV, int TAPS>
 __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void conv3x3_f16x3_row_kernel(const Conv3Dev a) {
+    fp16_saturate_on();
     constexpr int BN = 16 * WN;
     constexpr int NT = 64 * NWV;
     constexpr int TH = 2 * NWV, NPIX = HW_ * (TH + 2), HALO_TASKS = NPIX * 8, HALO_TPT = (HALO_TASKS + NT - 1) / NT;

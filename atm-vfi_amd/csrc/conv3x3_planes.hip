@@ -91,6 +91,7 @@ __device__ __forceinline__ void dma16(const unsigned char* src, unsigned char* l
 
 template <int WN>
 __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev a) {
+    fp16_saturate_on();
     constexpr int BN = 16 * WN;
     constexpr int WSLOT = 2 * BN * 64;                  // bytes of one ring slot: [hi BN rows][lo BN rows] x 64 B
     constexpr int SW = (2 * WN + 7) / 8;                // weight pieces per wave and k-step (some waves one fewer)

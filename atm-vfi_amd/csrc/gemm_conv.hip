@@ -29,6 +29,7 @@ __device__ __forceinline__ int swz(int row) { return (0x1320 >> (((row >> 2) & 3
 
 template <int WM, int WN>
 __global__ __launch_bounds__(256) void gemm_mfma_f32(const GemmDev a) {
+    fp16_saturate_on();
     constexpr int BM = 64 * WM;
     constexpr int BN = 16 * WN;
     constexpr int NB = (BN * 4 + 255) / 256;      // B float4 loads per thread
@@ -192,6 +193,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32(const GemmDev a) {
 // -------- weight packing --------
 __global__ void pack_weight_kernel(int mode, const float* __restrict__ src, float* __restrict__ dst,
                                    int Cout, int Cin, int kh, int kw, int rows, int cin_pad, int coutp) {
+    fp16_saturate_on();
     const int taps = (mode == ATMVFI_GEMM_DECONV) ? 1 : kh * kw;
     const long long total = (long long)rows * taps * cin_pad;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;

@@ -49,6 +49,7 @@ __device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, f16x8& hi, 
 
 template <int WN>
 __global__ __launch_bounds__(512) void gemm_f16x3_kernel(const GemmDev a) {
+    fp16_saturate_on();
     constexpr int BM = 256;
     constexpr int BN = 16 * WN;
     extern __shared__ __attribute__((aligned(16))) _Float16 smem[];

@@ -67,6 +67,7 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 
 template <bool CONVM>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmDev a) {
+    fp16_saturate_on();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;

@@ -65,6 +65,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 template <int WGM, int WGN, bool CONVM>
 __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_split_kernel(const GemmDev a) {
+    fp16_saturate_on();
     constexpr int NW = WGM * WGN;
     constexpr int NT = 64 * NW;
     constexpr int BM = 64 * WGM, BN = 64 * WGN;
@@ -328,6 +329,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_split_kernel(const Gem
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ in, int in_ld, long long M, int C,
                                                            const float* __restrict__ prelu, _Float16* hi, _Float16* lo, long long plane_rows,
                                                            int c0p, int pad_to) {
+    fp16_saturate_on();
     const int groups = (C + pad_to - 1) / pad_to * (pad_to / 8);
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= M * groups) return;
@@ -372,6 +374,7 @@ template <int NO>
 __global__ __launch_bounds__(256) void head1x1_planes_kernel(const _Float16* __restrict__ hi, const _Float16* __restrict__ lo, long long plane_rows,
                                                              long long rows, int cin, const float* __restrict__ w, const float* __restrict__ bias,
                                                              float* __restrict__ out, int out_ld, int cout) {
+    fp16_saturate_on();
     // A block = 64 pixel rows x 4 waves; wave k takes the 32-channel chunks k, k + 4, ... (a lane per row with the whole K leaves 2
     // waves per CU walking 18-24 dependent chunk loads: 0.05 ms for 50 MFLOP), partial sums meet in LDS.  The weights of a wave's
     // chunk are wave-uniform: scalar loads.

@@ -15,6 +15,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         const RowSink out,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         long long rows, int C) {
+    fp16_saturate_on();
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -106,6 +107,7 @@ __global__ __launch_bounds__(256) void dwconv_gelu_kernel(const float* __restric
                                                           const RowSink out,
                                                           const float* __restrict__ w9, const float* __restrict__ bias,
                                                           int N, int H, int W, int C) {
+    fp16_saturate_on();
     const int c4n = C >> 2;
     const long long total = (long long)N * H * W * c4n;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -150,6 +152,7 @@ __global__ __launch_bounds__(256) void dwconv_gelu_rows_kernel(const float* __re
                                                                const RowSink out,
                                                                const float* __restrict__ w9, const float* __restrict__ bias,
                                                                int N, int H, int W, int C, int xblocks, int cblocks, int strips) {
+    fp16_saturate_on();
     int bid = blockIdx.x;
     const int cb = bid % cblocks; bid /= cblocks;
     const int xb = bid % xblocks; bid /= xblocks;
@@ -209,6 +212,7 @@ __global__ __launch_bounds__(256) void dwconv_gelu_rows_kernel(const float* __re
 }
 
 __global__ void pack_dw_kernel(const float* __restrict__ src, float* __restrict__ dst, int C) {
+    fp16_saturate_on();
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < 9 * C) {
         const int tap = idx / C, c = idx - tap * C;
@@ -266,6 +270,7 @@ __device__ __forceinline__ float sample_plane(const float* __restrict__ p, const
 __global__ __launch_bounds__(256) void flow_warp_planar_kernel(const float* __restrict__ src, const float* __restrict__ flow,
                                                                long long flow_bstride, int flow_pstride, int flow_cstride,
                                                                float* __restrict__ dst, int B, int C, int H, int W) {
+    fp16_saturate_on();
     const long long hw = (long long)H * W;
     const long long total = (long long)B * hw;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -286,6 +291,7 @@ __global__ __launch_bounds__(256) void flow_warp_planar_kernel(const float* __re
 // and use the arithmetic of flow_warp_planar_kernel / resize_ac_kernel unchanged: bit-identical to the two launches.
 __global__ __launch_bounds__(256) void flow_warp_up2_kernel(const float* __restrict__ src, const float* __restrict__ flow, float* __restrict__ dst,
                                                             float* __restrict__ flow_up, int B, int C, int H, int W) {
+    fp16_saturate_on();
     const long long hw = (long long)H * W;
     const long long nwarp = (long long)B * hw;
     const int Ho = 2 * H, Wo = 2 * W;
@@ -322,6 +328,7 @@ __global__ __launch_bounds__(256) void flow_warp_nhwc_kernel(const float* __rest
                                                              const float* __restrict__ flow, long long flow_bstride,
                                                              int flow_pstride, int flow_cstride, float* __restrict__ dst,
                                                              int dst_ld, long long dst_bstride, int B, int C, int H, int W) {
+    fp16_saturate_on();
     const int c4n = C >> 2;
     const long long hw = (long long)H * W;
     const long long total = (long long)B * hw * c4n;
@@ -356,6 +363,7 @@ __global__ __launch_bounds__(256) void warp_blend_kernel(const float* __restrict
                                                          float* __restrict__ pack15, int pack_ld, _Float16* __restrict__ pack_hi,
                                                          _Float16* __restrict__ pack_lo, long long pack_rows, int pack_c0, int B, int H,
                                                          int W) {
+    fp16_saturate_on();
     const long long hw = (long long)H * W;
     const long long total = (long long)B * hw;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -430,6 +438,7 @@ __global__ __launch_bounds__(256) void warp_blend_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void resize_ac_kernel(const float* __restrict__ src, long long sb, long long sc, long long sy,
                                                         long long sx, float* __restrict__ dst, int B, int C,
                                                         int Hi, int Wi, int Ho, int Wo, float value_scale) {
+    fp16_saturate_on();
     const float sh = (Ho > 1) ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f;
     const float sw = (Wo > 1) ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
     const long long ohw = (long long)Ho * Wo;
@@ -477,6 +486,7 @@ __device__ __forceinline__ float pyramid_value(const float* __restrict__ plane, 
 
 __global__ __launch_bounds__(256) void image_pyramid_kernel(const float* __restrict__ im0, const float* __restrict__ im1, float* __restrict__ l1,
                                                             float* __restrict__ l2, float* __restrict__ l3, int B, int H, int W) {
+    fp16_saturate_on();
     const long long n1 = (long long)(H >> 1) * (W >> 1), n2 = (long long)(H >> 2) * (W >> 2), n3 = (long long)(H >> 3) * (W >> 3);
     const long long planes = 2ll * B * 3;
     const long long t1 = planes * n1, t2 = planes * n2, t3 = planes * n3;
@@ -497,6 +507,7 @@ __global__ __launch_bounds__(256) void image_pyramid_kernel(const float* __restr
 
 __global__ __launch_bounds__(256) void pack_frames_kernel(const float* __restrict__ im0, const float* __restrict__ im1,
                                                           float* __restrict__ dst, int B, int H, int W) {
+    fp16_saturate_on();
     const long long hw = (long long)H * W;
     const long long total = 2ll * B * hw;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -516,6 +527,7 @@ __global__ __launch_bounds__(256) void pack_frames_kernel(const float* __restric
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void frame_u8_to_f32_kernel(const unsigned char* __restrict__ src, int H, int W, int bgr,
                                                               float* __restrict__ dst, int Hp, int Wp, int pad_top, int pad_left) {
+    fp16_saturate_on();
     const long long total = (long long)Hp * Wp;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
         const int y = (int)(idx / Wp), x = (int)(idx - (long long)y * Wp);
@@ -532,6 +544,7 @@ __global__ __launch_bounds__(256) void frame_u8_to_f32_kernel(const unsigned cha
 
 __global__ __launch_bounds__(256) void frame_f32_to_u8_kernel(const float* __restrict__ src, int Hp, int Wp, int pad_top, int pad_left,
                                                               unsigned char* __restrict__ dst, int H, int W, int bgr) {
+    fp16_saturate_on();
     const long long total = (long long)H * W, plane = (long long)Hp * Wp;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
         const int y = (int)(idx / W), x = (int)(idx - (long long)y * W);
@@ -552,6 +565,7 @@ __global__ __launch_bounds__(256) void frame_f32_to_u8_kernel(const float* __res
 __global__ __launch_bounds__(256) void final_residual_kernel(const float* __restrict__ it, const float* __restrict__ r, int r_ld,
                                                              float* __restrict__ it_sum, float* __restrict__ it_clamped,
                                                              int B, int H, int W) {
+    fp16_saturate_on();
     const long long hw = (long long)H * W;
     const long long total = (long long)B * hw;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -571,6 +585,7 @@ __global__ __launch_bounds__(256) void final_residual_kernel(const float* __rest
 
 __global__ __launch_bounds__(256) void l1_mean_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                       float* __restrict__ out, long long per_sample) {
+    fp16_saturate_on();
     __shared__ float red[4];
     const int s = blockIdx.y;
     const float* pa = a + (long long)s * per_sample;
