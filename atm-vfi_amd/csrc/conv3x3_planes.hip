@@ -612,8 +612,9 @@ extern "C" int atmvfi_conv3x3_planes2(const void* in_hi, const void* in_lo, int6
                        (!bias || atmvfi::aligned16(bias)) && (!prelu || atmvfi::aligned16(prelu)),
                    ATMVFI_EALIGN, "conv3x3_planes: pointers (incl. bias/prelu) must be 16-byte aligned");
     if (out)
-        ATMVFI_REQUIRE(atmvfi::aligned16(out) && out_ld % 4 == 0 && out_ld >= atmvfi::round_up(Cout, 4), ATMVFI_EALIGN,
-                       "conv3x3_planes: fp32 output must be 16-byte aligned with ld %% 4 == 0 covering the channels");
+        ATMVFI_REQUIRE(atmvfi::aligned16(out) && out_ld % 4 == 0 && out_cmin >= 0 && out_cmin % 4 == 0 &&
+                           out_ld >= atmvfi::round_up(Cout, 4) - out_cmin,
+                       ATMVFI_EALIGN, "conv3x3_planes: fp32 output must be 16-byte aligned with ld %% 4 == 0 covering the stored channels");
     ATMVFI_REQUIRE((out_hi == nullptr) == (out_lo == nullptr), ATMVFI_EINVAL, "conv3x3_planes: plane sink needs both planes");
     if (out_hi) {
         ATMVFI_REQUIRE(plane_rows >= (int64_t)N * H * W && out_c0 >= 0 && out_c0 % 8 == 0, ATMVFI_EINVAL,

@@ -392,10 +392,15 @@ class HipOps:
                              "(one spare zero row is required)")
         cout = w.cout
         old = 0
+        out_ptr = _ptr(out)
         if out is not None:
             old, on, oh, ow, oc = nhwc_view(out, "conv3x3_planes.out")
-            if (on, oh, ow, oc) != (n, h, wd, cout):
-                raise ValueError(f"conv3x3_planes: out {tuple(out.shape)} != [{n},{h},{wd},{cout}]")
+            if (on, oh, ow) == (n, h, wd) and oc == cout - out_cmin and out_cmin > 0:
+                # compact view of just the stored channels [out_cmin, cout): the kernel never touches columns below out_cmin, so the
+                # base may point that many floats in front of the buffer (out_cmin % 4 == 0 keeps the 16-byte alignment)
+                out_ptr = ctypes.c_void_p(out.data_ptr() - 4 * out_cmin)
+            elif (on, oh, ow, oc) != (n, h, wd, cout):
+                raise ValueError(f"conv3x3_planes: out {tuple(out.shape)} != [{n},{h},{wd},{cout}] (or {cout - out_cmin} channels: compact)")
         elif planes is None:
             raise ValueError("conv3x3_planes: no output")
         if planes is not None:
@@ -409,7 +414,7 @@ class HipOps:
                 "shape": f"M{n * h * wd} N{cout} K{cin * 9}"}
         coff = in_chunk0 * x.ld_rows * 32 * 2       # bytes
         self._run("conv3x3_planes", meta, self.lib.atmvfi_conv3x3_planes2, x.t[0].data_ptr() + coff, x.t[1].data_ptr() + coff, x.ld_rows,
-                  n, h, wd, cin, _ptr(w.hi3), _ptr(w.lo3), cout, _ptr(out), old, _ptr(bias), _ptr(prelu),
+                  n, h, wd, cin, _ptr(w.hi3), _ptr(w.lo3), cout, out_ptr, old, _ptr(bias), _ptr(prelu),
                   planes.t[0].data_ptr() if planes is not None else None, planes.t[1].data_ptr() if planes is not None else None,
                   planes.ld_rows if planes is not None else 0, planes_c0, _ptr(planes_prelu) if planes is not None else None,
                   planes2.t[0].data_ptr() if planes2 is not None else None, planes2.t[1].data_ptr() if planes2 is not None else None,

@@ -804,6 +804,7 @@ class Network(BlockRunner, nn.Module):
                 o = 1 if st else 0
                 cout = dsts[st].shape[-1]
                 hs, wsz = H >> scale, W >> scale
+                mot_c = None
                 if pc:
                     # planes end to end: deconv (LDS-DMA GEMM) -> planes -> conv+PReLU -> planes -> conv -> fp32 map (flows, masks
                     # and the refiner's strided convs read it) + planes for the next stage (through its leading PReLU) or for
@@ -822,16 +823,22 @@ class Network(BlockRunner, nn.Module):
                             # the map goes on twice as planes -- through the next stage's leading PReLU (its deconv) and raw (the
                             # U-Net's strided conv reads cat(feat, dec[:, :w]) from two plane buffers); fp32 only for the five
                             # flow / mask channels that warp_blend reads
+                            # (in a compact 8-float-per-pixel buffer: as the tail of the skip buffer's 400-600-byte rows each
+                            # pixel's 20 bytes cost warp_blend a cache line of their own)
                             raw = self.planes(f"dec_raw_{st}", b * hs * wsz, cout)
-                            self._c3p(ops, P, f"{pfx}.{o + 2}", t2p, b, hs, wsz, out=dsts[st], act=False, sink=xp_next,
-                                      sink_prelu=P[f"inprelu:{st + 1}"], sink2=raw, out_cmin=(cout - 5) // 4 * 4)
+                            cmin = (cout - 5) // 4 * 4
+                            mot_c = self.buf(f"dec_mot_{st}", b, hs, wsz, 8)[..., :cout - cmin]
+                            self._c3p(ops, P, f"{pfx}.{o + 2}", t2p, b, hs, wsz, out=mot_c, act=False, sink=xp_next,
+                                      sink_prelu=P[f"inprelu:{st + 1}"], sink2=raw, out_cmin=cmin)
                         else:
                             self._c3p(ops, P, f"{pfx}.{o + 2}", t2p, b, hs, wsz, out=dsts[st], act=False, sink=xp_next,
                                       sink_prelu=P[f"inprelu:{st + 1}"])
                     else:
                         # finest level: only the five flow / mask channels are read in fp32 (by warp_blend); the features go on
                         # to the refiner as planes
-                        self._c3p(ops, P, f"{pfx}.{o + 2}", t2p, b, hs, wsz, out=dsts[st], act=False, sink=rin_p, out_cmin=(cout - 5) // 4 * 4)
+                        cmin = (cout - 5) // 4 * 4
+                        mot_c = self.buf(f"dec_mot_{st}", b, hs, wsz, 8)[..., :cout - cmin]
+                        self._c3p(ops, P, f"{pfx}.{o + 2}", t2p, b, hs, wsz, out=mot_c, act=False, sink=rin_p, out_cmin=cmin)
                 else:
                     t1 = self.buf(f"dec_t1_{st}", b, hs, wsz, _r4(cout))[..., :cout]
                     # The deconvs run on the LDS-DMA GEMM from split planes (1.81 against 2.46 ms on the fp32-input engine for the six
@@ -851,7 +858,7 @@ class Network(BlockRunner, nn.Module):
                     else:
                         self._conv_plain(ops, P, f"{pfx}.{o + 2}", t2b, dsts[st])
                 x = dsts[st]
-                mot = x[..., cout - 5:cout]
+                mot = x[..., cout - 5:cout] if mot_c is None else mot_c[..., mot_c.shape[-1] - 5:]
                 a, c, t = (ops.empty(b, 3, hs, wsz) for _ in range(3))
                 if scale == 0:
                     flow0, flow1 = ops.empty(b, 2, H, W), ops.empty(b, 2, H, W)

@@ -189,7 +189,8 @@ int atmvfi_conv3x3_f16x3(const float* in, int in_ld, int N, int H, int W, int Ci
  * issues MFMAs while the other reads fragments and issues DMA).  Bit-identical to atmvfi_conv3x3_f16x3 on the same values.
  * Contract of the input planes: in_rows > N*H*W and row N*H*W of every chunk is ZERO (it is the source of the halo pixels that
  * fall outside the image; atm-vfi_amd's Planes.alloc reserves it); pad channels of the last chunk are zero; in_rows * 64 < 2^32.
- * Outputs: fp32 NHWC view `out` (may be NULL; only channels >= out_cmin, a multiple of 4, are stored) and / or the plane sink
+ * Outputs: fp32 NHWC view `out` (may be NULL; only channels >= out_cmin, a multiple of 4, are stored: columns below are
+ * never touched, so `out` may point out_cmin floats in front of a compact buffer of just the stored channels) and / or the plane sink
  * out_hi / out_lo (may be NULL; not both NULL) at channel offset out_c0 (multiple of 8) of a plane buffer with plane_rows rows,
  * through plane_prelu (as atmvfi_conv3x3_f16x3); plane channels from Cout up to the next multiple of 8 are written as zero.
  * wn: 0 = pick the tile width (n-tiles of 16 output channels per workgroup) from the cost model, 1..8 = force it (tests, sweeps). */

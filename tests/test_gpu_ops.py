@@ -783,6 +783,33 @@ def test_conv3x3_planes_persistent_grid(case, hip, dev):
 
 
 @pytest.mark.gpu
+def test_conv3x3_planes_compact_fp32_tail(hip, dev):
+    """out_cmin: only the channels >= out_cmin reach the fp32 output -- inside the full-width map (columns below untouched), or in a
+    compact buffer of just those channels (the decoder's five flow / mask channels for warp_blend); the planes carry everything."""
+    g = torch.Generator().manual_seed(7300)
+    N, H, W, cin, cout = 1, 40, 72, 101, 101
+    cmin = (cout - 5) // 4 * 4
+    x = rnd(g, N, H, W, 104, scale=1.5).to(dev)
+    wt = rnd(g, cout, cin, 3, 3, scale=1.0 / np.sqrt(9 * cin)).to(dev)
+    bias = rnd(g, cout, scale=0.2).to(dev)
+    pw = hip.pack_weight(GEMM_CONV, wt)
+    xp = hip_ops.Planes.alloc(N * H * W, cin, dev)
+    hip.split_planes(x[..., :cin].flatten(0, 2), xp)
+    full = torch.empty(N, H, W, 104, device=dev)
+    hip.conv3x3_planes(xp, N, H, W, pw, out=full[..., :cout], bias=bias)
+    wide = torch.full((N, H, W, 104), 7.0, device=dev)
+    s1 = hip_ops.Planes.alloc(N * H * W, cout, dev)
+    hip.conv3x3_planes(xp, N, H, W, pw, out=wide[..., :cout], bias=bias, planes=s1, out_cmin=cmin)
+    compact = torch.full((N, H, W, 8), 7.0, device=dev)
+    s2 = hip_ops.Planes.alloc(N * H * W, cout, dev)
+    hip.conv3x3_planes(xp, N, H, W, pw, out=compact[..., :cout - cmin], bias=bias, planes=s2, out_cmin=cmin)
+    torch.cuda.synchronize()
+    assert torch.equal(wide[..., cmin:cout], full[..., cmin:cout]) and (wide[..., :cmin] == 7.0).all()
+    assert torch.equal(compact[..., :cout - cmin], full[..., cmin:cout]) and (compact[..., cout - cmin:] == 7.0).all()
+    assert torch.equal(s1.t, s2.t)
+
+
+@pytest.mark.gpu
 def test_conv3x3_planes_chunk_offset_and_auto_width(hip, dev):
     """Input view starting at a 32-channel chunk of wider planes, automatic tile width, a large-ish ragged map: equals the fp32 kernel."""
     g = torch.Generator().manual_seed(7100)
