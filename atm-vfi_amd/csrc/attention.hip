@@ -290,12 +290,17 @@ __global__ __launch_bounds__(64 * NT, (NT <= 4 ? 3 : NT <= 8 ? 2 : NT <= 12 ? 3 
     const float inv_dgr = 1.0f / (float)dgr;
     constexpr int ksw_mask = SPK - 1;
     int goff[UNR], koff[UNR], voff[UNR];          // global offset (floats), LDS byte offsets; -1: no unit
+    // For head dims of 32 / 64 / 128 chunks (DCH 1 / 2 / 4) a row gets 8 DCH lanes (the last ones idle when hd is not a multiple of
+    // 32): the 16-lane groups of a ds_write_b64 then stay inside one row of either image and its banks (with 12 units per row dealt
+    // to consecutive lanes, groups straddled two rows 128 bytes = 32 banks apart: 0.7 conflict cycles per LDS instruction).
+    constexpr bool ROWGROUPS = DCH != 3;
+    constexpr int LPR = 8 * DCH, RPP = T / LPR;   // lanes per row, rows per unit index u
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
         const int idx = u * T + tid;
-        const int row = (int)(((float)idx + 0.5f) * inv_dgr);     // exact: idx < 2^14
-        const int d4 = idx - row * dgr;
-        const bool ok = idx < units;
+        const int row = ROWGROUPS ? u * RPP + tid / LPR : (int)(((float)idx + 0.5f) * inv_dgr);     // exact: idx < 2^14
+        const int d4 = ROWGROUPS ? tid % LPR : idx - row * dgr;
+        const bool ok = ROWGROUPS ? (row < N && d4 < dgr) : idx < units;
         const int sw = SPK == 16 ? (row & 15) : SPK == 8 ? ((row >> 1) & 7) : ((0x1320 >> (((row >> 2) & 3) * 4)) & 3);
         goff[u] = ok ? row * C3 + (d4 << 2) : 0;
         koff[u] = ok ? row * KS + ((((d4 >> 1) ^ sw) & ksw_mask) << 4) + ((d4 & 1) << 3) : -1;
@@ -332,7 +337,7 @@ __global__ __launch_bounds__(64 * NT, (NT <= 4 ? 3 : NT <= 8 ? 2 : NT <= 12 ? 3 
         const float* kvbase = qkv + (long long)((bb + kv_shift) % Bw) * N * C3 + C + hh * hd;
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            if (u * T < units) {                  // wave-uniform: hd = 48 needs 3 of the 4 units a thread may have
+            if (ROWGROUPS ? u * RPP < N : u * T < units) {      // wave-uniform: the units past the window's rows are nobody's
                 k0[u] = *reinterpret_cast<const f32x4*>(kvbase + goff[u]);
                 v0[u] = *reinterpret_cast<const f32x4*>(kvbase + goff[u] + C);
             }
