@@ -273,14 +273,35 @@ __global__ __launch_bounds__(64 * NT, (NT <= 4 ? 3 : NT <= 8 ? 2 : NT <= 12 ? 3 
     const bool qok = q < N;
     const float inv_ws = 1.0f / (float)ws;        // key / ws for key < 256, ws <= 16: floor((key + 0.5) / ws) is exact in fp32
 
-    // ---- once: zero both images (padded keys, K's head-dim padding), then the key-position columns ----
+    // ---- once: zeros where no staged value ever lands (padded keys, K's head-dim padding), then the key-position columns.  A
+    // persistent workgroup clears both images whole; a one-item workgroup (145 KiB at ws 12 / hd 84) only those regions. ----
     {
-        const int words16 = (2 * NPAD * KS + 2 * VROWS * VS) >> 4;
-        for (int idx = tid; idx < words16; idx += T) reinterpret_cast<f32x4*>(smem)[idx] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        __syncthreads();
+        const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const f16x4 z = (f16x4){(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+        if constexpr (PERSIST) {
+            const int words16 = (2 * NPAD * KS + 2 * VROWS * VS) >> 4;
+            for (int idx = tid; idx < words16; idx += T) reinterpret_cast<f32x4*>(smem)[idx] = z4;
+            __syncthreads();
+        } else {
+            const int dg0 = hd >> 2, kpad = 8 * DCH - dg0;            // staged / padding 4-float units of a K row
+            auto kzero = [&](int row, int d4) {
+                const int sw = SPK == 16 ? (row & 15) : SPK == 8 ? ((row >> 1) & 7) : ((0x1320 >> (((row >> 2) & 3) * 4)) & 3);
+                const int off = row * KS + ((((d4 >> 1) ^ sw) & (SPK - 1)) << 4) + ((d4 & 1) << 3);
+                *reinterpret_cast<f16x4*>(Kh + off) = z;
+                *reinterpret_cast<f16x4*>(Kl + off) = z;
+            };
+            for (int idx = tid; idx < N * kpad; idx += T) kzero(idx / kpad, dg0 + idx % kpad);
+            for (int idx = tid; idx < (NPAD - N) * 8 * DCH; idx += T) kzero(N + idx / (8 * DCH), idx % (8 * DCH));
+            const int vtail16 = ((VROWS - N) * VS) >> 4;              // V rows of the padded keys (VS % 32 == 0)
+            for (int idx = tid; idx < vtail16; idx += T) {
+                reinterpret_cast<f32x4*>(Vh + N * VS)[idx] = z4;
+                reinterpret_cast<f32x4*>(Vl + N * VS)[idx] = z4;
+            }
+        }
         if (motion && tid < N) {                  // small integers: exact in fp16, lo' = 0
             const float ky = floorf(((float)tid + 0.5f) * inv_ws), kx = (float)tid - ky * (float)ws;
             *reinterpret_cast<f16x4*>(Vh + tid * VS + (hd << 1)) = (f16x4){(_Float16)kx, (_Float16)ky, (_Float16)0.f, (_Float16)0.f};
+            *reinterpret_cast<f16x4*>(Vl + tid * VS + (hd << 1)) = z;
         }
     }
 
