@@ -33,6 +33,6 @@ for ws, hd, frames, h, w, shift in [(8, 48, 2, 136, 240, 4), (12, 84, 2, 68, 120
         e.record(); torch.cuda.synchronize()
     t = buf.cpu().tolist()
     items = max(t[8], 1)
-    print(f"ws{ws} hd{hd} {h}x{w}: {s.elapsed_time(e) * 1e3:.1f} us, {items} items per workgroup, {sum(t[:8]) / items:.0f} cycles (100 MHz clock x 1) per item")
+    print(f"ws{ws} hd{hd} {h}x{w}: {s.elapsed_time(e) * 1e3:.1f} us, {items} items per workgroup, {sum(t[:8]) / items:.0f} shader-clock cycles (s_memtime) per item")
     for nme, c in zip(NAMES, t[:8]):
         print(f"    {nme:42s} {c / items:9.0f}")
