@@ -59,6 +59,7 @@ struct GemmDev {
     int out_c0, out_gc;
     int force_wn;     // per-call tile-width override of gemm_f16x3 (0 = cost model)
     int fit32;        // gemm_pp: rows x out_ld x 4 and rows x res_ld x 4 bytes fit 32 bits (unmapped, ungrouped fp32 rows: 32-bit store offsets)
+    int pfit32;       // gemm_pp: a plane of the sink (plane rows x 64 bytes) fits 32 bits: 32-bit row offsets from per-lane chunk pointers
 };
 
 

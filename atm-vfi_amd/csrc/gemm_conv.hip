@@ -353,6 +353,7 @@ extern "C" int atmvfi_gemm(const atmvfi_gemm_params* p, void* stream) {
                    "gemm: tile_wn 0 (auto), 1..8, or -1 (split-plane input: reference schedule), got %d", p->tile_wn);
     d.force_wn = p->tile_wn;
     d.fit32 = 0;
+    d.pfit32 = 0;
     d.nblocks = 0;
     d.dbg = 0;
     d.vblocks = 0;

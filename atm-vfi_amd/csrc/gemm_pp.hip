@@ -566,6 +566,31 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmDev a) {
                 const unsigned rpg = a.out_rpg > 0 ? (unsigned)a.out_rpg : 0x7fffffffu;
                 const RowSink sink{nullptr, 0, a.out_hi, a.out_lo, a.out_plane_rows};
                 const bool col_ok = nb < a.Cout;
+                // ungrouped sink whose planes fit 32-bit byte offsets (every strided / 1x1 conv between plane maps): the lane's
+                // channel group fixes a pointer into each plane once per tile, a row costs a shift (the grouped form divides
+                // every row by the group size: ~25 VALU instructions of a VALU-bound epilogue)
+                auto rows32 = [&](auto f32_tag) {
+                    constexpr bool F32 = decltype(f32_tag)::value;
+                    const int c = a.out_c0 + nb;
+                    const long long cpart = ((long long)(c >> 5) * a.out_plane_rows) * 32 + (c & 31);
+                    unsigned char* ph = reinterpret_cast<unsigned char*>(a.out_hi + cpart);
+                    unsigned char* pl = reinterpret_cast<unsigned char*>(a.out_lo + cpart);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4 v = finish(i, q);
+                            const unsigned rr = ro[i][q] < 0 ? 0u : (unsigned)ro[i][q];
+                            if (ro[i][q] >= 0 && col_ok) {
+                                if constexpr (F32) *reinterpret_cast<f32x4*>(a.out + (unsigned long long)rr * (unsigned)a.out_ld + nb) = v;
+                                f16x2 h0, l0, h1, l1;
+                                split_pair((f32x2){v.x, v.y}, h0, l0);
+                                split_pair((f32x2){v.z, v.w}, h1, l1);
+                                *reinterpret_cast<f16x4*>(ph + (rr << 6)) = (f16x4){h0.x, h0.y, h1.x, h1.y};
+                                *reinterpret_cast<f16x4*>(pl + (rr << 6)) = (f16x4){l0.x, l0.y, l1.x, l1.y};
+                            }
+                        }
+                };
                 auto rows = [&](auto f32_tag) {
                     constexpr bool F32 = decltype(f32_tag)::value;
 #pragma unroll
@@ -582,7 +607,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmDev a) {
                             }
                         }
                 };
-                if (a.out) rows(std::true_type{});
+                if (a.out_rpg == 0 && a.pfit32) {
+                    if (a.out) rows32(std::true_type{});
+                    else rows32(std::false_type{});
+                } else if (a.out) rows(std::true_type{});
                 else rows(std::false_type{});
             } else {
                 // ConvTranspose2d 2x2 / stride 2 into a plane sink (decoder and U-Net stages): column -> (position, channel) is a
@@ -596,6 +624,37 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmDev a) {
                 int dx = rem - dy * a.W;
                 const int qoff = (cp.q >> 1) * a.Wo + (cp.q & 1);
                 const int pc = a.out_c0 + cp.co;
+                if (a.pfit32) {
+                    // 32-bit row offsets from the lane's chunk pointers.  Output row index of (image dn, input row dy, input
+                    // column 0) is (dn Ho + 2 dy) Wo, and because Ho = 2 H it simply grows by 2 Wo whenever the stepped input
+                    // column wraps -- across images too: no (dn, dy) bookkeeping, no 64-bit products per row.
+                    const long long cpart = ((long long)(pc >> 5) * a.out_plane_rows) * 32 + (pc & 31);
+                    unsigned char* ph = reinterpret_cast<unsigned char*>(a.out_hi + cpart);
+                    unsigned char* pl = reinterpret_cast<unsigned char*>(a.out_lo + cpart);
+                    unsigned rowbase = ((unsigned)dn * (unsigned)a.Ho + 2u * (unsigned)dy) * (unsigned)a.Wo + (unsigned)qoff;
+                    const unsigned rstep = 2u * (unsigned)a.Wo;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            f32x4 v = finish(i, q);
+                            v.y = cp.nvalid > 1 ? v.y : 0.f;        // channels past Cout inside the group of 4: the planes' pad channels
+                            v.z = cp.nvalid > 2 ? v.z : 0.f;
+                            v.w = cp.nvalid > 3 ? v.w : 0.f;
+                            const unsigned boff = (rowbase + 2u * (unsigned)dx) << 6;
+                            if (ro[i][q] >= 0 && cp.nvalid > 0) {
+                                f16x2 h0, l0, h1, l1;
+                                split_pair((f32x2){v.x, v.y}, h0, l0);
+                                split_pair((f32x2){v.z, v.w}, h1, l1);
+                                *reinterpret_cast<f16x4*>(ph + boff) = (f16x4){h0.x, h0.y, h1.x, h1.y};
+                                *reinterpret_cast<f16x4*>(pl + boff) = (f16x4){l0.x, l0.y, l1.x, l1.y};
+                            }
+                            dx += 4;                                  // next row of this lane (W >= 4: one wrap at most)
+                            const bool wrap = dx >= a.W;
+                            dx = wrap ? dx - a.W : dx;
+                            rowbase += wrap ? rstep : 0u;
+                        }
+                } else
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -668,6 +727,7 @@ static int launch_pp(const GemmDev& d, int ngemm, hipStream_t s) {
     if (CONVM) ATMVFI_REQUIRE(d.H < 32768 && d.W < 32768, ATMVFI_EINVAL, "gemm_pp: CONV mode packs (y, x) into 16 bits each");
     GemmDev dd = d;
     dd.dbg = 0;
+    dd.pfit32 = d.out_hi && (long long)d.out_plane_rows * 64 < (1ll << 32);
     dd.fit32 = d.out && !d.out_row_map && d.out_rpg == 0 && d.mode != ATMVFI_GEMM_DECONV && (d.M + 1) * (long long)d.out_ld * 4 < (1ll << 32) &&
                (!d.residual || (d.M + 1) * (long long)d.res_ld * 4 < (1ll << 32));
 #ifdef ATMVFI_STAMP
