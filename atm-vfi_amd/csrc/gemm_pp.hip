@@ -522,7 +522,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmDev a) {
         // epilogue of a group is VALU-bound -- one wave per SIMD beside the other group's MFMAs)
         auto fast_rows = [&](auto prelu_tag) {
             constexpr bool PRELU = decltype(prelu_tag)::value;
-            auto finish = [&](int i, int q) -> f32x4 {
+            auto finish = [&](int i, int q, bool with_res = true) -> f32x4 {
                 f32x4 v = acc[i][q] + bvec;
                 if constexpr (PRELU) {
                     v.x = v.x > 0.f ? v.x : pvec.x * v.x;
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmDev a) {
                     v.w = v.w > 0.f ? v.w : pvec.w * v.w;
                 }
                 if constexpr (CONVM) return v;           // convolutions have no residual operand
-                else return v + res[i][q];
+                else return with_res ? v + res[i][q] : v;
             };
             if (a.mode != ATMVFI_GEMM_DECONV && !a.out_hi && a.fit32 && m0 + BM <= M) {
                 // fp32 rows, every row of the tile live, no map: one 32-bit byte offset per lane, stepped by 4 rows -- a row costs
@@ -637,10 +637,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmDev a) {
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            f32x4 v = finish(i, q);
-                            v.y = cp.nvalid > 1 ? v.y : 0.f;        // channels past Cout inside the group of 4: the planes' pad channels
-                            v.z = cp.nvalid > 2 ? v.z : 0.f;
-                            v.w = cp.nvalid > 3 ? v.w : 0.f;
+                            // (no residual on this path; channels past Cout inside the group of 4 are already zero: their weight
+                            // rows and their bias are, and PReLU keeps a zero)
+                            const f32x4 v = finish(i, q, false);
                             const unsigned boff = (rowbase + 2u * (unsigned)dx) << 6;
                             if (ro[i][q] >= 0 && cp.nvalid > 0) {
                                 f16x2 h0, l0, h1, l1;
