@@ -275,6 +275,28 @@ def test_window_attention(case, engine, hip, cpu, dev):
         assert maxdiff(mg, mc) <= 1e-4
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("engine", ["f16x3", "f32"])
+@pytest.mark.parametrize("case", [(8, 32, 4, 13, 3), (8, 48, 6, 21, 0), (12, 20, 2, 5, 4), (5, 64, 3, 37, 11)],
+                         ids=lambda c: f"ws{c[0]}_hd{c[1]}_heads{c[2]}_bw{c[3]}_kv{c[4]}")
+def test_window_attention_other_head_counts(case, engine, cpu, dev):
+    """Head counts other than the network's 8, window counts that are not a multiple of 8 (the persistent walk's padded tail), an
+    arbitrary K/V shift, no label mask -- through the raw op against the CPU double."""
+    ws, hd, heads, bw, kv_shift = case
+    hip = hip_ops.HipOps(dev)
+    hip.attention_f16x3 = engine == "f16x3"
+    C, n = heads * hd, ws * ws
+    g = torch.Generator().manual_seed(ws + hd + heads + bw)
+    qkv = rnd(g, bw * n, 3 * C, scale=1.5)
+    oc, og = torch.empty(bw * n, C), torch.full((bw * n, C), 9.0, device=dev)
+    mc, mg = torch.empty(bw * n, heads, 2), torch.full((bw * n, heads, 2), 9.0, device=dev)
+    cpu.window_attention(qkv, oc, mc, None, bw, 1, ws, heads, hd, kv_shift)
+    hip.window_attention(qkv.to(dev), og, mg, None, bw, 1, ws, heads, hd, kv_shift)
+    torch.cuda.synchronize()
+    assert maxdiff(og, oc) <= 1e-4
+    assert maxdiff(mg, mc) <= 1e-4
+
+
 def test_motion_head(hip, cpu, dev):
     g = torch.Generator().manual_seed(8)
     frames, h, w, ws, shift = 4, 6, 10, 4, 2
