@@ -643,7 +643,8 @@ class Network(BlockRunner, nn.Module):
             self._graphs.clear()
             self._graph_sig = self._prepared_sig
         key = (tuple(im0.shape), tuple(im1.shape), str(im0.device), self.global_motion, self.ensemble_global_motion,
-               self._precision, self.use_split_planes, self.use_plane_convs, self.local_motion_args["window_size"],
+               self._precision, self.use_split_planes, self.use_plane_convs, self.use_unet_planes, self.use_plane_deconvs,
+               getattr(ops, "attention_f16x3", None), self.local_motion_args["window_size"],
                self.global_motion_args["window_size"], self._workspace_key(im0))
         ent = self._graphs.get(key)
         if ent is None:
@@ -658,6 +659,7 @@ class Network(BlockRunner, nn.Module):
             ent = (graph, s0, s1, out)
             self._graphs[key] = ent
         graph, s0, s1, out = ent
+        self._select_workspace(key[-1])                      # replay counts as a use: the hot shape must not be the LRU victim
         s0.copy_(im0)
         s1.copy_(im1)
         graph.replay()

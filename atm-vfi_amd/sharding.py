@@ -55,45 +55,47 @@ class PipelinedGather:
     ``submit(local)`` copies this rank's frames of step k into a send buffer of its own (so the producer -- e.g. a captured HIP
     graph's static output -- may be overwritten by step k+1 straight away), issues the all-gather asynchronously (RCCL runs it on
     its own stream, under the forward of step k+1) and returns the gathered frames of step k-1, waiting for that older collective
-    first; ``drain()`` returns the last step's.  Two sets of buffers alternate, so a set is reused two steps after its gather
-    was waited for.  A rank without a frame in the last (ragged) step submits ``None``: it sends zeros, and ``valid`` counts say
+    first; ``drain()`` returns the last step's.  Two send buffers alternate (a send buffer is reused two steps later, after its
+    gather was waited for); THREE sets of receive buffers rotate, because the gather of step k+1 is issued by the very submit that
+    hands out step k-1's frames... of another set: the frames returned by ``submit`` number k live in set (k-1) mod 3, which the
+    gather of step k+2 overwrites.  A rank without a frame in the last (ragged) step submits ``None``: it sends zeros, and ``valid`` counts say
     how many ranks' frames are real.  ``encode`` (optional) maps the fp32 frames to the wire format before sending, e.g. rounding
     to uint8 (4x fewer bytes over xGMI); it must return a tensor of ``wire_shape`` / ``wire_dtype``.
-    Frames come back as a list of ``world`` tensors in rank order (views of the receive buffers: consume or copy them before the
-    next-but-one submit)."""
+    Frames come back as a list of ``world`` tensors in rank order: views of the receive buffers, valid until the NEXT-BUT-ONE
+    ``submit`` (they survive one further submit; tests/test_sharding_gloo.py reads them after it)."""
 
     def __init__(self, world: int, wire_shape, device, wire_dtype=torch.float32, encode: Callable = None, group=None):
         self.world, self.encode, self.group = world, encode, group
         self.send = [torch.zeros(wire_shape, dtype=wire_dtype, device=device) for _ in range(2)]
-        self.recv = [[torch.empty(wire_shape, dtype=wire_dtype, device=device) for _ in range(world)] for _ in range(2)]
+        self.recv = [[torch.empty(wire_shape, dtype=wire_dtype, device=device) for _ in range(world)] for _ in range(3)]
         self.pending = None            # (work, buffer set, valid count)
         self.k = 0
 
     def _finish(self):
         if self.pending is None:
             return None
-        work, s, valid = self.pending
+        work, r, valid = self.pending
         self.pending = None
         if work is not None:
             work.wait()
-        return self.recv[s][:valid]
+        return self.recv[r][:valid]
 
     def submit(self, local, valid: int = None):
         """local: this rank's frames of the step (wire_shape after ``encode``) or None; valid: ranks holding a real frame this
         step (default: all).  Returns the previous step's gathered frames (list, rank order) or None on the first call."""
-        s = self.k & 1
+        s, r = self.k & 1, self.k % 3
         self.k += 1
         if local is None:
             self.send[s].zero_()
         else:
             self.send[s].copy_(self.encode(local) if self.encode is not None else local)
         prev = self._finish()                       # the older collective first: its receive buffers are about to be handed out
-        if self.world == 1:
-            self.recv[s][0].copy_(self.send[s])
+        if self.world == 1 and not (dist.is_available() and dist.is_initialized()):
+            self.recv[r][0].copy_(self.send[s])
             work = None
         else:
-            work = dist.all_gather(self.recv[s], self.send[s], group=self.group, async_op=True)
-        self.pending = (work, s, self.world if valid is None else valid)
+            work = dist.all_gather(self.recv[r], self.send[s], group=self.group, async_op=True)
+        self.pending = (work, r, self.world if valid is None else valid)
         return prev
 
     def drain(self):
@@ -124,7 +126,12 @@ def interpolate_video_2x_sharded(frames: Sequence, interpolate_pair: Callable, r
     this rank's prediction as a tensor of ``wire_shape`` / ``wire_dtype`` on ``device`` (e.g. the uint8 [H,W,3] frame of
     ``FramePipeline``: 4x fewer bytes over xGMI than fp32); ``reuse_first`` is True when f_a was the previous call's f_b on this
     rank, so an implementation may reuse that frame's encoder features (``Network.enable_frame_cache``).  ``decode`` converts a
-    gathered wire tensor to what is yielded (default: the tensor itself)."""
+    gathered wire tensor to what is yielded (default: the tensor itself).
+
+    The collectives are issued from inside this generator, so EVERY rank must run it to the end (a rank that stops iterating early
+    leaves the others waiting in their next all-gather until the process group's timeout -- create the group with one); when a
+    consumer does abandon the generator (``close()``, an exception, garbage collection) the gather already in flight on this rank
+    is waited for before the generator returns, so no un-waited work object outlives it."""
     n = len(frames)
     if n == 0:
         return
@@ -140,18 +147,21 @@ def interpolate_video_2x_sharded(frames: Sequence, interpolate_pair: Callable, r
 
     prev_meta = None
     last_b = None
-    for start, spans in shard_blocks(n - 1, world, block):
-        a, b = spans[rank]
-        local = None
-        if b > a:
-            local = torch.zeros((block,) + tuple(wire_shape), dtype=wire_dtype, device=device)
-            for i in range(a, b):
-                local[i - a].copy_(interpolate_pair(frames[i], frames[i + 1], last_b == i))
-                last_b = i + 1
-        got = gather.submit(local)
+    try:
+        for start, spans in shard_blocks(n - 1, world, block):
+            a, b = spans[rank]
+            local = None
+            if b > a:
+                local = torch.zeros((block,) + tuple(wire_shape), dtype=wire_dtype, device=device)
+                for i in range(a, b):
+                    local[i - a].copy_(interpolate_pair(frames[i], frames[i + 1], last_b == i))
+                    last_b = i + 1
+            got = gather.submit(local)
+            if prev_meta is not None:
+                yield from emit(prev_meta[0], prev_meta[1], got)
+            prev_meta = (start, spans)
         if prev_meta is not None:
-            yield from emit(prev_meta[0], prev_meta[1], got)
-        prev_meta = (start, spans)
-    if prev_meta is not None:
-        yield from emit(prev_meta[0], prev_meta[1], gather.drain())
-    yield frames[n - 1]          # the last frame is written once (demo_2x.py:160)
+            yield from emit(prev_meta[0], prev_meta[1], gather.drain())
+        yield frames[n - 1]          # the last frame is written once (demo_2x.py:160)
+    finally:
+        gather.drain()               # abandoned early: do not leave an un-waited collective behind

@@ -42,20 +42,29 @@ FLOPS_PER_PAIR = {  # SURVEY.md section 8d, algorithmic FLOPs per frame pair (2 
     ("lite", 256, 448, False): 87.8e9,
     ("lite", 256, 256, True): 56.2e9,
 }
+# BASELINE.json `configs`, in order: (variant, height, width, global branch on, description)
+CONFIGS = {
+    "c1": ("lite", 256, 256, True, "network_lite 256x256 (configs[0], the reference's CPU-runnable case)"),
+    "c2": ("lite", 256, 448, False, "network_lite 256x448 Vimeo90K shape, global off (configs[1])"),
+    "c3": ("base", 540, 960, True, "network_base 540x960 (configs[2])"),
+    "c4": ("base", 1080, 1920, True, "network_base 1080x1920, one pair per GPU (configs[3]; the headline metric)"),
+    "c5": ("base", 2160, 4096, True, "network_base 2160x4096, one pair per GPU (configs[4], run with --gpus 4)"),
+}
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, dense fp32 matrix peak
 PEAK_F16_MFMA_TFLOPS = 2500.0  # dense fp16/bf16 matrix peak (no sparsity)
 PEAK_HBM_GBS = 8000.0
 
 
 def csrc_digest() -> str:
-    """sha256 over the kernel sources: stamps the committed PMC traffic figures with the build they were measured on."""
+    """sha256 over the kernel sources, the C-ABI header and the Makefile (compiler flags): stamps the committed PMC traffic figures with the build they were measured on."""
     import hashlib
     hsh = hashlib.sha256()
     d = os.path.join(ROOT, "atm-vfi_amd", "csrc")
-    for fn in sorted(os.listdir(d)):
-        if fn.endswith((".hip", ".h")):
-            hsh.update(fn.encode())
-            hsh.update(open(os.path.join(d, fn), "rb").read())
+    files = [os.path.join(d, fn) for fn in sorted(os.listdir(d)) if fn.endswith((".hip", ".h")) or fn == "Makefile"]
+    files.append(os.path.join(ROOT, "include", "atmvfi.h"))          # the ABI and the build flags are part of the build
+    for path in files:
+        hsh.update(os.path.basename(path).encode())
+        hsh.update(open(path, "rb").read())
     return hsh.hexdigest()
 
 
@@ -92,10 +101,18 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS),
+                    help="a BASELINE.json configuration by name (sets --variant/--height/--width/--global-off): " +
+                         "; ".join(f"{k} = {v[4]}" for k, v in sorted(CONFIGS.items())) + ".  Default: c4, the headline metric")
     ap.add_argument("--variant", default="base", choices=["base", "lite"])
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--global-off", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher self-test (tests/test_host_logic.py): the ranks rendezvous over gloo on the CPU and rank 0 prints a line; "
+                         "no GPU, no model, nothing is measured")
+    ap.add_argument("--cpu-baseline-crop", action="store_true",
+                    help="time the CPU oracle on a quarter-pixel crop and scale by the pixel ratio (marked extrapolated) instead of the full frame pair")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f32"])
@@ -103,13 +120,65 @@ def parse():
     ap.add_argument("--gather-u8", action="store_true", help="N > 1: all-gather the output frames rounded to uint8 (4x fewer bytes over xGMI)")
     ap.add_argument("--graph", action="store_true", help="replay the forward from a captured HIP graph (Network.enable_graphs); measured "
                     "within 0.5 %% of eager launches at 1080p and at 256x448: the stream is already back to back")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.config:
+        args.variant, args.height, args.width, g_on, _ = CONFIGS[args.config]
+        args.global_off = not g_on
+    return args
+
+
+def self_launch(args) -> int:
+    """``python bench.py --gpus N`` (N > 1) outside a launcher: start the N ranks as FRESH child processes through
+    ``python -m torch.distributed.run`` on 127.0.0.1 with a free port -- before this process has made any GPU call (it never
+    makes one: ``import torch`` does not initialise HIP) and without exec'ing -- relay rank 0's JSON line to stdout, everything
+    else the children print to stderr, and return the launcher's exit code (non-zero if any rank failed)."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL's intra-node transport needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    env["MASTER_ADDR"], env["MASTER_PORT"] = "127.0.0.1", str(port)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"bench.py: starting {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    for line in child.stdout:
+        is_result = line.startswith("{") and '"metric"' in line
+        print(line, end="", file=sys.stdout if is_result else sys.stderr, flush=True)
+    return child.wait()
+
+
+def dry_run(args, dist):
+    """The rendezvous and reporting skeleton of ``main`` without a GPU: what the CPU test of the launcher branch runs."""
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if os.environ.get("ATMVFI_BENCH_DRY_FAIL_RANK") == str(rank):
+        raise SystemExit(3)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert t.item() == world
+        dist.barrier()
+        dist.destroy_process_group()
+    print(f"rank {rank} of {world}: rendezvous at {os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')} ok", flush=True)
+    if rank == 0:
+        print(json.dumps({"metric": "dry-run (launcher self-test, nothing measured)", "value": None, "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup}), flush=True)
 
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))
     import torch.distributed as dist
 
+    if args.dry_run:
+        return dry_run(args, dist)
     import pairs
     pkg = importlib.import_module("atm-vfi_amd")
     host_io = importlib.import_module("atm-vfi_amd.host_io")
@@ -118,20 +187,25 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     torch.set_grad_enabled(False)
     # rehearsal of the N > 1 code path on a one-GPU box: ATMVFI_BENCH_REHEARSAL=1 puts every rank on cuda:0 and uses gloo
     # (RCCL refuses two ranks on one device); never set by the driver
     rehearsal = os.environ.get("ATMVFI_BENCH_REHEARSAL") == "1"
     dev = torch.device("cuda:0" if rehearsal else f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
-    if world > 1:
+    # ATMVFI_BENCH_FORCE_COLLECTIVE=1 (never set by the driver): take the collective code path with ONE rank too, so the RCCL calls
+    # (communicator init, async all_gather into a tensor list, barrier, all_reduce) can be exercised on a one-GPU box
+    collective = world > 1 or os.environ.get("ATMVFI_BENCH_FORCE_COLLECTIVE") == "1"
+    if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        import datetime
+        tmo = datetime.timedelta(seconds=600)      # a stalled rank fails the run instead of hanging it
         if rehearsal:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=tmo)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)   # "nccl" is RCCL on ROCm
 
     # ---- model + synthetic inputs (resident in HBM before the timed region) ----
     variant = args.variant
@@ -156,7 +230,7 @@ def main():
     # timed region (the last one is waited for before the closing synchronize).  --gather-u8 sends the frame rounded to uint8.
     sharding = importlib.import_module("atm-vfi_amd.sharding")
     gather = None
-    if world > 1:
+    if collective:
         if args.gather_u8:
             u8 = torch.empty(H, W, 3, dtype=torch.uint8, device=dev)
 
@@ -184,7 +258,7 @@ def main():
         step(i)
     drain()
     torch.cuda.synchronize()
-    if world > 1:
+    if collective:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -192,11 +266,11 @@ def main():
         step(i)
     drain()
     torch.cuda.synchronize()
-    if world > 1:
+    if collective:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if collective:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
@@ -215,7 +289,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"network_{variant} {args.height}x{args.width} (padded {H}x{W}) bs=1 per GPU, "
                                    f"global {'on' if net.global_motion else 'off'}, fp32, random frame pairs, stress weights seed 1",
-                       "pairs_per_step": world, "parallelism": f"frame-batch dp{world} + all-gather of the {'uint8' if args.gather_u8 else 'fp32'} output frames, one step behind the forward (sharding.PipelinedGather)" if world > 1 else "single GPU"},
+                       "pairs_per_step": world, "parallelism": f"frame-batch dp{world} + all-gather of the {'uint8' if args.gather_u8 else 'fp32'} output frames, one step behind the forward (sharding.PipelinedGather)" if collective else "single GPU"},
         }
         result["launch"] = "eager (one hipLaunchKernel per op)" if not args.graph else "HIP graph replay (captured forward, inputs copied into its static buffers inside the timed region)"
         if flops:
@@ -310,13 +384,16 @@ def main():
         # ---- CPU baseline: the oracle on this node's host cores, bounded sample ----
         if world == 1 and not args.no_cpu_baseline:
             # threads = the cores this process may really use (cgroup quota), CPU model stated, one warm-up,
-            # median of three.  Bounded sample: the same network on a frame pair with a quarter of the pixels (every layer's cost is
-            # proportional to the pixel count), scaled to the timed workload by the pixel ratio.
+            # median of three, on the timed workload itself: the same padded frame pair, full size (~12 s per forward at 1088x1920
+            # on 16 threads).  --cpu-baseline-crop: a quarter-pixel crop scaled by the pixel ratio instead, marked as extrapolated.
             from oracle import atmvfi_oracle as O
             ncore, cpu_desc = host_cores()
             torch.set_num_threads(ncore)
-            sh, sw = (H // 2 + 15) // 16 * 16, (W // 2 + 15) // 16 * 16
             a, b = frames[0]
+            if args.cpu_baseline_crop:
+                sh, sw = (H // 2 + 15) // 16 * 16, (W // 2 + 15) // 16 * 16
+            else:
+                sh, sw = H, W
             a, b = a[..., :sh, :sw].cpu().contiguous(), b[..., :sh, :sw].cpu().contiguous()
             runs = []
             for rep in range(4):
@@ -325,13 +402,17 @@ def main():
                 runs.append(time.perf_counter() - tc)
             med = float(np.median(runs[1:]))
             scale = (H * W) / float(sh * sw)
+            what = (f"a {sh}x{sw} crop of the same frame pair (1/{scale:.2f} of the {H}x{W} pixels), scaled by the pixel ratio" if scale != 1.0
+                    else f"the timed workload itself: the same {H}x{W} frame pair, full size")
             result["cpu_baseline"] = {"value": round(1.0 / (med * scale), 5), "unit": "frames/s", "cores": ncore, "kind": "port",
-                                      "cpu": cpu_desc,
-                                      "sample": f"oracle forward on a {sh}x{sw} crop of the same frame pair (1/{scale:.2f} of the {H}x{W} "
-                                                f"pixels; per-layer cost is proportional to pixels), {ncore} threads, 1 warm-up + median of 3: "
-                                                f"{med:.2f} s per crop (runs {', '.join(f'{t:.2f}' for t in runs)}), scaled by the pixel ratio"}
-        print(json.dumps(result))
-    if world > 1:
+                                      "cpu": cpu_desc, "extrapolated": scale != 1.0, "scale_factor": round(scale, 4),
+                                      "sample": f"oracle forward (oracle/atmvfi_oracle.py) on {what}; {ncore} threads, 1 warm-up + median of 3: "
+                                                f"{med:.2f} s per forward (runs {', '.join(f'{t:.2f}' for t in runs)})"}
+        if collective:
+            result["collective_backend"] = dist.get_backend()
+        print(json.dumps(result), flush=True)
+    if collective:
+        dist.barrier()                      # rank 0's instrumented pass is over: nobody tears the communicator down under it
         dist.destroy_process_group()
 
 

@@ -307,3 +307,50 @@ def test_workspace_cache_evicts_by_itself(nets):
         net.workspace_cap_bytes = cap
         net.release_workspace()
     assert net.workspace_bytes() == 0
+
+
+def _bench(*argv, env=None):
+    import subprocess
+    import sys
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=e, capture_output=True, text=True, timeout=300)
+
+
+def test_bench_starts_its_own_ranks():
+    """``python bench.py --gpus N`` outside a launcher (how the driver calls it) spawns the N ranks itself: fresh children through
+    torch.distributed.run on 127.0.0.1 and a free port; exactly one JSON line on stdout (rank 0's), everything else on stderr."""
+    import json
+    r = _bench("--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1
+    assert "rank 1 of 2: rendezvous at 127.0.0.1:" in r.stderr and "torch.distributed.run" in r.stderr
+
+
+def test_bench_launcher_reports_a_failed_rank():
+    r = _bench("--gpus", "2", "--dry-run", env={"ATMVFI_BENCH_DRY_FAIL_RANK": "1"})
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_single_rank_does_not_spawn_and_rejects_a_wrong_world():
+    r = _bench("--gpus", "1", "--dry-run")
+    assert r.returncode == 0 and "torch.distributed.run" not in r.stderr and r.stdout.count('"metric"') == 1
+    r = _bench("--gpus", "4", "--dry-run", env={"WORLD_SIZE": "2", "RANK": "0"})     # launched with another rank count
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_bench_named_configs_are_baselines():
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    cfg = json.load(open(os.path.join(ROOT, "BASELINE.json")))["configs"]
+    assert len(bench.CONFIGS) == len(cfg)
+    for i, (k, (variant, h, w, g_on, _)) in enumerate(sorted(bench.CONFIGS.items())):
+        text = cfg[i].replace("×", "x")
+        assert f"network_{variant}" in text and f"{h}x{w}" in text
+        assert ("global_off" in text) == (not g_on)

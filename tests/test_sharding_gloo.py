@@ -58,6 +58,7 @@ def _pipelined_worker(rank, world, port, n_steps, q):
         frame = lambda step, r: torch.full((1, 3, 6, 10), (7 * step + 3 * r + 1) / 64.0)
         static_out = torch.empty(1, 3, 6, 10)          # stands in for a captured graph's static output buffer
         got_steps = []
+        held = None                                      # the views submit k returned, read again after submit k+1 (the contract)
         for step in range(n_steps):
             last_ragged = step == n_steps - 1
             mine = None
@@ -71,6 +72,11 @@ def _pipelined_worker(rank, world, port, n_steps, q):
             prev = pg.submit(mine, valid)
             static_out.fill_(-1.0)                       # the producer overwrites its output right away: the gather must not see it
             ok = ok and ((prev is None) == (step == 0))
+            if held is not None:                         # frames of step - 2, handed out one submit ago: still intact
+                for r, t in enumerate(held):
+                    want = frame(step - 2, r)
+                    ok = ok and torch.equal(t, enc(want) if as_u8 else want)
+            held = prev
             if prev is not None:
                 got_steps.append([t.clone() for t in prev])
         got_steps.append([t.clone() for t in pg.drain()])
