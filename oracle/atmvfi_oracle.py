@@ -346,8 +346,9 @@ def _alignment_loss(flow0, flow1, im0, im1):
     return (a - b).abs().mean(dim=[1, 2, 3])
 
 
-def ensemble_global_flows(sd: SD, im0: Tensor, im1: Tensor, ws: int) -> Tuple[Tensor, Tensor]:
-    """multiscale_global_motion_ensemble (network_base.py:564-605)."""
+def ensemble_global_flows(sd: SD, im0: Tensor, im1: Tensor, ws: int, picks: Optional[list] = None) -> Tuple[Tensor, Tensor]:
+    """multiscale_global_motion_ensemble (network_base.py:564-605).  ``picks``: a list that receives the level chosen per sample
+    (the fixtures' manifest records it, so a test can tell which branches of :593-603 a fixture reaches)."""
     b = im0.shape[0]
     im = torch.cat([im0, im1], 0)
     levels, losses = [], []
@@ -364,6 +365,8 @@ def ensemble_global_flows(sd: SD, im0: Tensor, im1: Tensor, ws: int) -> Tuple[Te
         ls = [losses[k][i] for k in range(3)]
         mn = min(ls)
         pick = 0 if ls[0] == mn else (1 if ls[1] == mn else 2)
+        if picks is not None:
+            picks.append(pick)
         if pick == 0:
             f0[i], f1[i] = levels[0][0][i], levels[0][1][i]
         else:

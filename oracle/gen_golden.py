@@ -120,6 +120,9 @@ E2E_CASES = [
     # ensemble on the base variant (network_base.py:564-605); the three global canvases 24x36, 12x24, 12x12 have distinct Hp*Wp, so the
     # reference's shift-mask cache (attention.py:279, keyed on Hp*Wp only) never hands a stale mask to another scale
     ("base_384x576_ens", "base", 1, 384, 576, True, True, "smooth", 32, 4),
+    # ensemble with B = 3 whose samples pick DIFFERENT levels -- 0, 1 and 2 (network_base.py:593-603: the per-sample if / elif chain, the
+    # x2 and x4 up-sampling branches); the manifest records the picks and tests/test_oracle_golden.py asserts they are [0, 1, 2]
+    ("base_384x576_ens_b3_mixed", "base", 3, 384, 576, True, True, "mixed", 40, 4),
     # BASELINE config C5: 2160x4096 through test_xiph.py:115-128's InputPadder(divisor 32) = 2176x4096, untiled, global on
     ("base_2176x4096_g_c5", "base", 1, 2176, 4096, True, False, "smooth", 25, 16),
 ]
@@ -171,7 +174,7 @@ def generate(gold: str, only=None) -> dict:
     for (name, v, b, h, w, g, ens, kind, seed, step) in E2E_CASES:
         if not want(name):
             continue
-        im0, im1 = (pairs.smooth_pair if kind == "smooth" else pairs.random_pair)(b, h, w, seed)
+        im0, im1 = pairs.PAIR_KINDS[kind](b, h, w, seed)
         net = nets[v]
         drop_mask_cache(net)
         net.global_motion = g
@@ -200,13 +203,16 @@ def generate(gold: str, only=None) -> dict:
         lists = [t for t in out["im_t_list"]]
         del out
         ora = O.forward(sds[v], im0, im1, global_motion=g, ensemble_global_motion=ens)
+        picks = []
+        if ens:      # which level each sample's global flow came from (the oracle is bit-identical to the reference on these cases)
+            O.ensemble_global_flows(sds[v], im0, im1, schema.VARIANTS[v].global_window, picks)
         d = (keep["I_t"] - ora["I_t"]).abs().max().item()
         dl = max((a - c).abs().max().item() for a, c in zip(lists, ora["im_t_list"]))
         del ora, keep, lists
         manifest["cases"].append({"name": name, "variant": v, "B": b, "H": h, "W": w, "global": g,
                                   "ensemble": ens, "kind": kind, "seed": seed, "step": step,
                                   "n_lists": n_lists, "oracle_vs_ref_I_t": d,
-                                  "oracle_vs_ref_lists": dl})
+                                  "oracle_vs_ref_lists": dl, **({"ensemble_picks": picks} if ens else {})})
         print(f"{name:24s} oracle-vs-reference max|d| I_t {d:.2e} lists {dl:.2e}  flow|max| {flow_max:.2f}", flush=True)
 
     # ---- 3. demo path: uint8 frames through the reference's inference_2frame ----

@@ -16,7 +16,7 @@ def load_manifest():
 
 
 def e2e_cases():
-    return [c for c in load_manifest()["cases"] if c["kind"] in ("smooth", "random")]
+    return [c for c in load_manifest()["cases"] if c["kind"] in pairs.PAIR_KINDS]
 
 
 def demo_cases():
@@ -28,7 +28,7 @@ def load_npz(name):
 
 
 def case_inputs(c):
-    fn = pairs.smooth_pair if c["kind"] == "smooth" else pairs.random_pair
+    fn = pairs.PAIR_KINDS[c["kind"]]
     im0, im1 = fn(c["B"], c["H"], c["W"], c["seed"])
     return im0, im1
 

@@ -24,6 +24,18 @@ def smooth_pair(b: int, h: int, w: int, seed: int):
             big[:, :, 13:13 + h, 20:20 + w].contiguous())
 
 
+def mixed_batch(b: int, h: int, w: int, seed: int):
+    """A batch whose samples differ in kind: i.i.d. frames (seed), i.i.d. frames (seed + 1), smooth shifted frames (seed), ...
+    Used for the ensemble fixture whose samples pick different pyramid levels (network_base.py:593-603)."""
+    parts = []
+    for i in range(b):
+        parts.append(random_pair(1, h, w, seed + i) if i % 3 < 2 else smooth_pair(1, h, w, seed + i - 2))
+    return torch.cat([p[0] for p in parts], 0), torch.cat([p[1] for p in parts], 0)
+
+
+PAIR_KINDS = {"smooth": smooth_pair, "random": random_pair, "mixed": mixed_batch}
+
+
 def uint8_pair(h: int, w: int, seed: int = 0):
     """Demo-path input: HWC uint8 frames."""
     rng = np.random.default_rng(seed)
