@@ -57,6 +57,22 @@ class GemmParams(ctypes.Structure):
     ]
 
 
+class PlanArg(ctypes.Union):
+    _fields_ = [("u", ctypes.c_uint64), ("i", ctypes.c_int64), ("f", ctypes.c_double)]
+
+
+PLAN_MAX_ARGS = 28
+
+
+class PlanOp(ctypes.Structure):
+    _fields_ = [("fn", ctypes.c_int32), ("nargs", ctypes.c_int32), ("a", PlanArg * PLAN_MAX_ARGS)]
+
+
+class PlanPatch(ctypes.Structure):
+    _fields_ = [("op", ctypes.c_int32), ("arg", ctypes.c_int32), ("slot", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("offset", ctypes.c_int64)]
+
+
 # name -> (restype, argtypes); also the list of symbols the header declares (checked by the CPU tests)
 SIGNATURES = {
     "atmvfi_version": (c_i, []),
@@ -99,6 +115,9 @@ SIGNATURES = {
     "atmvfi_pack_frames": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_f]),
     "atmvfi_final_residual": (c_i, [c_f, c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_f]),
     "atmvfi_l1_mean": (c_i, [c_f, c_f, c_f, c_i, c_l, c_f]),
+    "atmvfi_plan_fn_id": (c_i, [ctypes.c_char_p]),
+    "atmvfi_plan_run": (c_i, [ctypes.POINTER(PlanOp), c_i, ctypes.POINTER(PlanPatch), c_i, ctypes.POINTER(ctypes.c_uint64), c_i,
+                              ctypes.POINTER(c_i), c_f]),
 }
 
 
@@ -230,6 +249,137 @@ def _planar(t: torch.Tensor, c: int, what: str):
         raise ValueError(f"{what}: expected contiguous [B,{c},H,W], got {tuple(t.shape)} strides {t.stride()}")
 
 
+class PlanUnsupported(Exception):
+    """Raised while recording when a forward cannot be expressed as a launch plan (the caller falls back to direct launches)."""
+
+
+class LaunchPlan:
+    """One forward of the hot path recorded as an array of ``atmvfi_plan_op`` (include/atmvfi.h, "Launch plans") and replayed by ONE
+    ``atmvfi_plan_run`` call: per-call memory -- the caller's two frames and the output tensors, fresh on every call -- enters through
+    a slot table that the library patches into the recorded arguments.
+
+    Recording (``HipOps.begin_plan`` ... ``end_plan``): every launch of ``HipOps._run`` is executed as usual AND appended; every
+    ``HipOps.empty`` becomes an output slot; pointer arguments (by the entry point's declared types) that fall inside a slot's
+    memory become patches.  A pointer field of a GEMM parameter block inside per-call memory cannot be patched: PlanUnsupported."""
+
+    def __init__(self, lib, inputs):
+        self.lib = lib
+        self.ops_list = []                 # (fn id, [values], [is_float])
+        self.keep = []                     # parameter blocks referenced by address
+        self.slots = [(t.data_ptr(), t.numel() * t.element_size()) for t in inputs]     # (base, bytes): inputs first, then outputs
+        self.n_inputs = len(inputs)
+        self.out_meta = []                 # (shape, dtype) per output slot, allocation order
+        self.out_tensors = []              # the recording call's own outputs (kept alive until end_plan)
+        self.patches = []
+        self.template = None               # result structure with ("slot", k) leaves
+        self.c_ops = self.c_patches = self.c_slots = None
+        self._fn_ids = {}
+
+    # ---- recording ----
+    def _slot_of(self, ptr: int):
+        for k, (base, nb) in enumerate(self.slots):
+            if base <= ptr < base + nb:
+                return k, ptr - base
+        return None
+
+    def add_output(self, t: torch.Tensor):
+        self.slots.append((t.data_ptr(), t.numel() * t.element_size()))
+        self.out_meta.append((tuple(t.shape), t.dtype))
+        self.out_tensors.append(t)
+
+    def add_op(self, fn, args):
+        name = fn.__name__
+        fid = self._fn_ids.get(name)
+        if fid is None:
+            fid = self.lib.atmvfi_plan_fn_id(name.encode())
+            if fid < 0:
+                raise PlanUnsupported(f"{name} is not a launch entry point")
+            self._fn_ids[name] = fid
+        types = SIGNATURES[name][1]
+        args = args[:-1]                   # the stream is the plan's
+        if len(args) > PLAN_MAX_ARGS:
+            raise PlanUnsupported(f"{name}: {len(args)} arguments")
+        vals = []
+        k = len(self.ops_list)
+        for j, (v, ty) in enumerate(zip(args, types)):
+            if isinstance(v, float):
+                vals.append(("f", v))
+                continue
+            if hasattr(v, "_obj"):         # ctypes.byref(parameter block): referenced by address, kept alive with the plan
+                blk = v._obj
+                for fname, ftype in blk._fields_:
+                    if ftype is c_f and getattr(blk, fname) and self._slot_of(getattr(blk, fname)) is not None:
+                        raise PlanUnsupported(f"{name}: parameter block field {fname} points into per-call memory")
+                self.keep.append(blk)
+                vals.append(("u", ctypes.addressof(blk)))
+                continue
+            if isinstance(v, ctypes.c_void_p):
+                v = v.value
+            v = 0 if v is None else int(v)
+            if ty is c_f and v:
+                hit = self._slot_of(v)
+                if hit is not None:
+                    self.patches.append((k, j, hit[0], hit[1]))
+            vals.append(("u" if v >= 0 else "i", v))
+        self.ops_list.append((fid, vals))
+
+    def finish(self, result):
+        """Freeze the plan; ``result`` is what the recorded forward returned (tensors must be whole output slots)."""
+        by_ptr = {base: k for k, (base, _) in enumerate(self.slots) if k >= self.n_inputs}
+
+        def walk(x):
+            if isinstance(x, torch.Tensor):
+                k = by_ptr.get(x.data_ptr())
+                if k is None or tuple(x.shape) != self.out_meta[k - self.n_inputs][0]:
+                    raise PlanUnsupported("a returned tensor is not a whole per-call output")
+                return ("slot", k)
+            if isinstance(x, dict):
+                return {kk: walk(v) for kk, v in x.items()}
+            if isinstance(x, (list, tuple)):
+                return [walk(v) for v in x]
+            return x
+        self.template = walk(result)
+        n = len(self.ops_list)
+        self.c_ops = (PlanOp * n)()
+        for i, (fid, vals) in enumerate(self.ops_list):
+            op = self.c_ops[i]
+            op.fn, op.nargs = fid, len(vals)
+            for j, (kind, v) in enumerate(vals):
+                setattr(op.a[j], kind, v)
+        self.c_patches = (PlanPatch * max(1, len(self.patches)))()
+        for i, (k, j, slot, off) in enumerate(self.patches):
+            pp = self.c_patches[i]
+            pp.op, pp.arg, pp.slot, pp.offset = k, j, slot, off
+        self.c_slots = (ctypes.c_uint64 * len(self.slots))()
+        self.failed = c_i(-1)
+        self.out_tensors = []
+        return self
+
+    # ---- replay ----
+    def run(self, inputs, device, stream):
+        outs = [torch.empty(shape, dtype=dt, device=device) for shape, dt in self.out_meta]
+        sl = self.c_slots
+        for k, t in enumerate(inputs):
+            sl[k] = t.data_ptr()
+        base = self.n_inputs
+        for k, t in enumerate(outs):
+            sl[base + k] = t.data_ptr()
+        rc = self.lib.atmvfi_plan_run(self.c_ops, len(self.ops_list), self.c_patches, len(self.patches), sl, len(self.slots),
+                                      ctypes.byref(self.failed), stream)
+        if rc != 0:
+            raise RuntimeError(f"plan_run failed ({rc}) at op {self.failed.value}: {self.lib.atmvfi_last_error().decode()}")
+
+        def build(x):
+            if isinstance(x, tuple) and len(x) == 2 and x[0] == "slot":
+                return outs[x[1] - base]
+            if isinstance(x, dict):
+                return {kk: build(v) for kk, v in x.items()}
+            if isinstance(x, list):
+                return [build(v) for v in x]
+            return x
+        return build(self.template)
+
+
 class HipOps:
     """The op vocabulary of the hot path, each a single HIP kernel launch."""
 
@@ -245,6 +395,21 @@ class HipOps:
         # fp32-input f16x3 GEMM; None / 0 = the library's cost model
         self.conv3_instance = None
         self.gemm_tile_wn = 0
+        self.recording: Optional[LaunchPlan] = None     # when set: every launch is also appended to this plan
+
+    # ------------------------------------------------------------------ launch plans
+    def begin_plan(self, inputs) -> LaunchPlan:
+        if self.profile is not None:
+            raise PlanUnsupported("per-launch profiling is on")
+        self.recording = LaunchPlan(self.lib, inputs)
+        return self.recording
+
+    def end_plan(self, result) -> LaunchPlan:
+        plan, self.recording = self.recording, None
+        return plan.finish(result)
+
+    def abort_plan(self):
+        self.recording = None
 
     # ------------------------------------------------------------------ utils
     def _stream(self):
@@ -255,6 +420,8 @@ class HipOps:
             raise RuntimeError(f"{name} failed ({rc}): {self.lib.atmvfi_last_error().decode()}")
 
     def _run(self, name: str, meta: dict, fn, *args):
+        if self.recording is not None:
+            self.recording.add_op(fn, args)
         if self.profile is None:
             self._check(fn(*args), name)
             return
@@ -266,7 +433,10 @@ class HipOps:
         self.profile.append((name, meta, s, e))
 
     def empty(self, *shape) -> torch.Tensor:
-        return torch.empty(*shape, dtype=torch.float32, device=self.device)
+        t = torch.empty(*shape, dtype=torch.float32, device=self.device)
+        if self.recording is not None:
+            self.recording.add_output(t)
+        return t
 
     def to_device_int(self, t: torch.Tensor) -> torch.Tensor:
         return t.to(device=self.device, dtype=torch.int32).contiguous()
@@ -760,6 +930,8 @@ class HipOps:
         _chk(a, "l1_mean.a"); _chk(b, "l1_mean.b")
         if not a.is_contiguous() or not b.is_contiguous() or a.shape != b.shape:
             raise ValueError("l1_mean: inputs must be contiguous and of equal shape")
+        if self.recording is not None:
+            raise PlanUnsupported("l1_mean clears its accumulator with a torch op")
         out.zero_()
         n = a.shape[0]
         self._run("l1_mean", {"bytes": 8.0 * a.numel()}, self.lib.atmvfi_l1_mean, _ptr(a), _ptr(b), _ptr(out), n, a.numel() // n, self._stream())

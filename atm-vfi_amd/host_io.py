@@ -178,10 +178,12 @@ def interpolate_video_2x_distributed(frames, model, rank: int, world: int, isBGR
                                      group=None):
     """``interpolate_video_2x`` over the GPUs of one node (one process per GPU, ``torch.distributed`` initialised by the caller):
     rounds of ``world * block`` consecutive pairs, rank r interpolating ``block`` consecutive ones; the uint8 predictions of a round
-    are all-gathered one step behind the compute (``sharding.PipelinedGather``: 6 MB per 1080p frame over xGMI instead of 25 MB
-    of fp32), and EVERY rank yields the full 2n-1 sequence f0, I(f0,f1), f1, ... as uint8 [H,W,3] arrays, in order.  ``frames``: a
-    sequence of uint8 [H,W,3] frames every rank can index.  Inside a block consecutive pairs share a frame: with
-    ``model.global_motion`` off its encoder + fusion tokens are reused (``Network.enable_frame_cache``) and its device copy too."""
+    are all-gathered one step behind the compute (``sharding.HostGather``: 6 MB per 1080p frame over xGMI instead of 25 MB of fp32;
+    the collective and the device -> pinned-host copies run on a side stream), and EVERY rank yields the full 2n-1 sequence f0,
+    I(f0,f1), f1, ... as uint8 [H,W,3] arrays, in order.  ``frames``: a sequence of uint8 [H,W,3] frames every rank can index.
+    Uploads go through pinned slots on a copy stream, one frame ahead of the forward that needs it.  Inside a block consecutive
+    pairs share a frame: its device copy is reused and so is everything ``forward`` computes per frame
+    (``Network.enable_frame_cache``: encoder, fusions and, with the global branch on, its per-frame half)."""
     from . import sharding
     ops, dev = _hip_ops_of(model)
     if ops is None:
@@ -194,29 +196,69 @@ def interpolate_video_2x_distributed(frames, model, rank: int, world: int, isBGR
     pad_left, _, pad_top, _ = pad._pad
     hp, wp = h + pad._pad[2] + pad._pad[3], w + pad._pad[0] + pad._pad[1]
     fbuf = [torch.empty(1, 3, hp, wp, dtype=torch.float32, device=dev) for _ in range(2)]
-    d_u8 = torch.empty(h, w, 3, dtype=torch.uint8, device=dev)
     out_u8 = torch.empty(h, w, 3, dtype=torch.uint8, device=dev)
-    use_cache = hasattr(model, "enable_frame_cache") and not model.global_motion
+    use_cache = hasattr(model, "enable_frame_cache") and not getattr(model, "ensemble_global_motion", False)
     if use_cache:
         model.enable_frame_cache(True)
-    state = {"cur": 0}            # fbuf[cur] holds the previous pair's second frame
+    # Uploads as in FramePipeline: a ring of pinned host slots + device staging, filled on a copy stream ONE FRAME AHEAD of the
+    # forward that needs it (this rank's pairs, in order, are known up front from the block schedule), so a frame's host -> device
+    # copy runs under the previous pair's forward instead of in front of its own.
+    mine = [i for _, spans in sharding.shard_blocks(n - 1, world, block) for i in range(*spans[rank])]
+    need = []                          # frame indices in upload order: both frames of a block's first pair, then one per pair
+    for k, i in enumerate(mine):
+        if k == 0 or mine[k - 1] != i - 1:
+            need.append(i)
+        need.append(i + 1)
+    depth = 3
+    ring = [{"h": torch.empty(h, w, 3, dtype=torch.uint8).pin_memory(), "d": torch.empty(h, w, 3, dtype=torch.uint8, device=dev),
+             "ready": torch.cuda.Event(), "free": torch.cuda.Event()} for _ in range(depth)]
+    for slot in ring:
+        slot["h_np"] = slot["h"].numpy()
+    copy_in = torch.cuda.Stream(dev)
+    state = {"cur": 0, "issued": 0, "used": 0}     # fbuf[cur] holds the previous pair's second frame
 
-    def to_device(frame, dst):
-        d_u8.copy_(torch.from_numpy(np.ascontiguousarray(frame)), non_blocking=False)
-        ops.frame_u8_to_f32(d_u8, dst[0], pad_top, pad_left, bool(isBGR))
+    def prefetch():
+        """Issue uploads until ``depth - 1`` frames are in flight ahead of the consumer (one slot may still be read by a kernel)."""
+        while state["issued"] < len(need) and state["issued"] - state["used"] < depth - 1:
+            slot = ring[state["issued"] % depth]
+            if state["issued"] >= depth:
+                slot["free"].synchronize()                    # the pre-kernel that read this slot's device copy has run
+            fr = frames[need[state["issued"]]]
+            if fr.shape != (h, w, 3) or fr.dtype != np.uint8:
+                raise ValueError(f"interpolate_video_2x_distributed: expected uint8 [{h},{w},3] frames")
+            np.copyto(slot["h_np"], fr)                       # numpy's single-threaded memcpy (see FramePipeline._upload)
+            with torch.cuda.stream(copy_in):
+                slot["d"].copy_(slot["h"], non_blocking=True)
+                slot["ready"].record(copy_in)
+            state["issued"] += 1
+
+    def to_device(idx, dst):
+        assert need[state["used"]] == idx, "upload schedule out of step with the pair order"
+        prefetch()
+        slot = ring[state["used"] % depth]
+        cur = torch.cuda.current_stream(dev)
+        cur.wait_event(slot["ready"])
+        ops.frame_u8_to_f32(slot["d"], dst[0], pad_top, pad_left, bool(isBGR))
+        slot["free"].record(cur)
+        state["used"] += 1
+        prefetch()                                            # the next frame's upload overlaps this pair's forward
+
+    pos = {"k": 0}
 
     def pair(fa, fb, reuse_first):
+        i = mine[pos["k"]]
+        pos["k"] += 1
         a, b = fbuf[state["cur"]], fbuf[state["cur"] ^ 1]
         if not reuse_first:
-            to_device(fa, a)
-        to_device(fb, b)
+            to_device(i, a)
+        to_device(i + 1, b)
         it = (model.forward(a, b, reuse_first=reuse_first) if use_cache else model.forward(a, b))["I_t"]
         ops.frame_f32_to_u8(it[0], out_u8, pad_top, pad_left, bool(isBGR))
         state["cur"] ^= 1             # fb is the next pair's fa
         return out_u8
     try:
         for item in sharding.interpolate_video_2x_sharded(frames, pair, rank, world, (h, w, 3), torch.uint8, block=block,
-                                                          decode=lambda t: t.cpu().numpy(), device=dev, group=group):
+                                                          device=dev, group=group, host_gather=True):
             yield item
     finally:
         if use_cache:

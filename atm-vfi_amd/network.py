@@ -22,6 +22,7 @@ There is no CPU path: ``forward`` requires CUDA(HIP) tensors and the built libra
 from __future__ import annotations
 
 import math
+import operator
 import os
 from typing import Dict, List, Optional, Tuple
 
@@ -29,8 +30,11 @@ import torch
 import torch.nn as nn
 
 from . import schema as S
-from .hip_ops import GEMM_CONV, GEMM_DECONV, GEMM_LINEAR, HipOps, PackedWeight, Planes
+from .hip_ops import GEMM_CONV, GEMM_DECONV, GEMM_LINEAR, HipOps, PackedWeight, Planes, PlanUnsupported
 from .windows import WindowGeometry, build_window_geometry
+
+
+_VERSION_OF = operator.attrgetter("_version")
 
 
 class _Node(nn.Module):
@@ -63,6 +67,8 @@ class BlockRunner:
         key = (name,) + tuple(shape)
         t = self._bufs.get(key)
         if t is None:
+            if getattr(self._ops_obj, "recording", None) is not None:
+                raise PlanUnsupported(f"workspace buffer {name} created while recording")
             t = self._ops_obj.empty(*shape)
             self._bufs[key] = t
         return t
@@ -72,6 +78,8 @@ class BlockRunner:
         key = ("planes", name, rows, c)
         p = self._bufs.get(key)
         if p is None:
+            if getattr(self._ops_obj, "recording", None) is not None:
+                raise PlanUnsupported(f"workspace planes {name} created while recording")
             p = Planes.alloc(rows, c, self._ops_obj.device)
             self._bufs[key] = p
         return p
@@ -80,6 +88,8 @@ class BlockRunner:
         key = (frames, h, w, ws, shift)
         g = self._geo.get(key)
         if g is None:
+            if getattr(self._ops_obj, "recording", None) is not None:
+                raise PlanUnsupported("window maps created while recording")
             geo = build_window_geometry(frames, h, w, ws, shift)
             ops = self._ops_obj
             g = (geo, ops.to_device_int(geo.row_map), None if geo.labels is None else ops.to_device_int(geo.labels))
@@ -197,6 +207,13 @@ class Network(BlockRunner, nn.Module):
         self._reuse_first = False
         self._graphs: Dict[Tuple, Tuple] = {}
         self._graph_sig = None
+        # launch plans (hip_ops.LaunchPlan): from the third forward with one (shape, mode, weights) key on, a forward is ONE
+        # atmvfi_plan_run call with fresh output tensors; A/B switch ATMVFI_PLANS=0 / enable_plans(False)
+        self.use_plans = os.environ.get("ATMVFI_PLANS", "1") != "0"
+        self._plans: Dict[Tuple, object] = {}       # key -> LaunchPlan | int (eager forwards seen so far) | False (cannot be planned)
+        self._plan_sig = None
+        self._plist = None                          # cached parameter list of the O(1)-per-parameter version check
+        self._pcheck = 0
 
     # ------------------------------------------------------------------ API parity
     def __set_local_window_size__(self, window_size):       # network_base.py:262-265
@@ -261,7 +278,9 @@ class Network(BlockRunner, nn.Module):
         """Everything that lives on one device or was derived there: packed weights, workspaces, window maps, captured graphs."""
         self._prepared = {}
         self._prepared_sig = None
+        self._plist = None
         self._graphs.clear()
+        self._plans.clear()
         self._workspaces.clear()
         self._bufs = {}
         self._ws_key = None
@@ -284,6 +303,7 @@ class Network(BlockRunner, nn.Module):
         return self._ops_obj
 
     def release_workspace(self):
+        self._plans.clear()           # recorded plans and
         self._graphs.clear()          # captured graphs launch into the workspace
         self._workspaces.clear()
         self._bufs = {}
@@ -312,16 +332,51 @@ class Network(BlockRunner, nn.Module):
             del self._workspaces[old]
             for gk in [g for g in self._graphs if g[-1] == old]:      # graphs captured into that workspace
                 del self._graphs[gk]
+            for gk in [g for g in self._plans if g[-1] == old]:       # plans recorded into it
+                del self._plans[gk]
         if len(self._geo) > 64:                                        # window maps are small; bound them all the same
             for gk in list(self._geo)[:len(self._geo) - 64]:
                 del self._geo[gk]
+            self._plans.clear()                                        # a plan may hold a map that just went
+            self._graphs.clear()
 
     # ------------------------------------------------------------------ weights
+    def _apply(self, fn, *a, **k):          # .to() / .cuda() / .float(): parameters get new storage
+        self._plist = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._plist = None
+        return super().load_state_dict(*a, **k)
+
+    def invalidate_weights(self):
+        """Forget the GEMM-layout copies of the weights.  Needed only after replacing a parameter's storage behind the module's back
+        (``p.data = ...``): in-place updates, ``load_state_dict`` and ``.to()`` are noticed by themselves."""
+        self._plist = None
+        self._prepared_sig = None
+
+    def _param_sig(self):
+        """Cheap per-forward check that the packed weights are current: the version counters of the cached parameter list (every
+        in-place update bumps one: 19 us for the 236 entries; walking ``named_parameters()`` and reading the storage pointers too
+        cost 330 us per forward, 15-20 % of a small frame's step).  The storage pointers are compared on every 32nd call and after
+        ``_apply`` / ``load_state_dict`` (which drop the cached list)."""
+        pl = self._plist
+        if pl is None:
+            pl = self._plist = [p for _, p in self.named_parameters()]
+            self._pptrs = tuple(p.data_ptr() for p in pl)
+            self._pcheck = 0
+        self._pcheck += 1
+        if self._pcheck & 31 == 0:
+            ptrs = tuple(p.data_ptr() for p in pl)
+            if ptrs != self._pptrs:
+                self._pptrs = ptrs
+        return (self._pptrs, tuple(map(_VERSION_OF, pl)))
+
     def _prepare(self, ops):
-        sd = {k: v for k, v in self.named_parameters()}
-        sig = tuple((p.data_ptr(), p._version) for p in sd.values())
+        sig = self._param_sig()
         if sig == self._prepared_sig:
             return self._prepared
+        sd = {k: v for k, v in self.named_parameters()}
         P: Dict[str, object] = {}
         for k, p in sd.items():
             P[k] = p.detach()
@@ -528,8 +583,9 @@ class Network(BlockRunner, nn.Module):
         t2 = self.buf(f"{tag}mm2", b, h, w, hid); self._conv_act(ops, P, f"{mlp}.1", t1, t2)
         return mlp_in, t2
 
-    def _global_motion(self, ops, P, e2, fuse_l, b, tag):
-        """estimate_global_motion (network_base.py:391-415): returns the raw 5-channel map [B,h_,w_,5]."""
+    def _global_tokens(self, ops, P, e2, fuse_l, tag):
+        """The per-frame half of estimate_global_motion (network_base.py:391-400): last_feat_extract + the global cross-scale fusion.
+        Returns the LayerNorm'ed tokens [F*h_*w_, global_dim] of the F frames in ``e2`` / ``fuse_l``."""
         v = self._v
         d = v.hidden_dims
         if isinstance(fuse_l, _PMap):
@@ -540,12 +596,7 @@ class Network(BlockRunner, nn.Module):
             ap = self.planes(f"{tag}ga_p", f * h_ * w_, v.last_feat_dim)
             self._conv_p(ops, P, "last_feat_extract.0", s3, stride=2, sink=ap)
             self._c3p(ops, P, "last_feat_extract.1", ap, f, h_, w_, sink=fuse_g.p, sink_c0=d[3] + 2 * d[2])
-            tokens = self._fusion(ops, P, "global_feature_fusion", e2, s3, fuse_g, d[3], d[2], tag + "g")
-            mlp_in, t2 = self._motion_branch(ops, P, "global_motion_atmformer", "global_motion_mlp", tokens, b, h_, w_,
-                                             self.global_motion_args["window_size"], tag + "g")
-            gout = self.buf(f"{tag}gout", b, h_, w_, 8)
-            self._head1x1(ops, P, "global_motion_mlp.2", t2, b, h_, w_, gout[..., :5])
-            return gout
+            return self._fusion(ops, P, "global_feature_fusion", e2, s3, fuse_g, d[3], d[2], tag + "g")
         f, h8, w8, _ = fuse_l.shape
         h_, w_ = h8 // 2, w8 // 2
         s3 = fuse_l[..., v.local_dim - d[3]:]
@@ -558,12 +609,25 @@ class Network(BlockRunner, nn.Module):
             a = self.buf(f"{tag}ga", f, h_, w_, v.last_feat_dim)
             self._conv_act(ops, P, "last_feat_extract.0", s3, a, 2)
             self._conv_act(ops, P, "last_feat_extract.1", a, fuse_g[..., d[3] + 2 * d[2]:])
-        tokens = self._fusion(ops, P, "global_feature_fusion", e2, s3, fuse_g, d[3], d[2], tag + "g")
+        return self._fusion(ops, P, "global_feature_fusion", e2, s3, fuse_g, d[3], d[2], tag + "g")
+
+    def _global_from_tokens(self, ops, P, tokens, b, h_, w_, tag):
+        """The pair half of estimate_global_motion (network_base.py:401-415): two ATMFormer blocks + the motion MLP on the frame-stacked
+        tokens [2B*h_*w_, global_dim].  Returns the raw 5-channel map [B,h_,w_,5] (in an 8-float-per-pixel buffer)."""
         mlp_in, t2 = self._motion_branch(ops, P, "global_motion_atmformer", "global_motion_mlp", tokens, b, h_, w_,
                                          self.global_motion_args["window_size"], tag + "g")
         gout = self.buf(f"{tag}gout", b, h_, w_, 8)
         self._head1x1(ops, P, "global_motion_mlp.2", t2, b, h_, w_, gout[..., :5])
         return gout
+
+    def _global_motion(self, ops, P, e2, fuse_l, b, tag):
+        """estimate_global_motion (network_base.py:391-415): returns the raw 5-channel map [B,h_,w_,5]."""
+        if isinstance(fuse_l, _PMap):
+            h_, w_ = fuse_l.h // 2, fuse_l.w // 2
+        else:
+            h_, w_ = fuse_l.shape[1] // 2, fuse_l.shape[2] // 2
+        tokens = self._global_tokens(ops, P, e2, fuse_l, tag)
+        return self._global_from_tokens(ops, P, tokens, b, h_, w_, tag)
 
     def _head1x1(self, ops, P, p, t2, b, h, w, out):
         """The 1x1 head of a motion MLP (network_base.py:158,195): on the hidden map's planes when the branch left it there."""
@@ -627,25 +691,82 @@ class Network(BlockRunner, nn.Module):
     def enable_frame_cache(self, flag: bool = True):
         """Video mode (demo_2x.py:129-168: pair i+1's first frame is pair i's second): keep the second frame's encoder + fusion
         tokens of every call, so that ``forward(im0, im1, reuse_first=True)`` runs ``shared_feat_extraction`` and the cross-scale
-        fusion (network_base.py:342-352, 451-455) on the new frame only.  Exact (the encoder is per frame); used only with
-        ``global_motion`` off, where nothing else reads the encoder maps; ~3 % of the FLOPs.  Not part of the
-        reference's API; off by default."""
+        fusion (network_base.py:342-352, 451-455) on the new frame only -- and, with ``global_motion`` on, the per-frame half of
+        ``estimate_global_motion`` too (last_feat_extract + the global fusion, :391-400).  Exact: all of that is per frame, the pair
+        meets in the ATMFormers.  Not with the ensemble (three input scales).  Not part of the reference's API; off by default."""
         self._frame_cache_on = bool(flag)
         self._frame_cache = None
 
+    def enable_plans(self, flag: bool = True):
+        """Launch plans (default on): once a (shape, mode, weights) combination has run twice, its forward is recorded
+        (``hip_ops.LaunchPlan``) and every later one is a single ``atmvfi_plan_run`` call -- same launches, same arguments, fresh
+        output tensors -- instead of ~120 Python-side op calls.  Not used with ensemble mode, the frame cache, graphs or per-launch
+        profiling (those forwards contain work outside the C ABI or need the individual launches)."""
+        self.use_plans = bool(flag)
+        if not flag:
+            self._plans.clear()
+
+    def _mode_key(self, ops, im0, im1) -> Tuple:
+        return (tuple(im0.shape), tuple(im1.shape), str(im0.device), self.global_motion, self.ensemble_global_motion,
+                self._precision, self.use_split_planes, self.use_plane_convs, self.use_unet_planes, self.use_plane_deconvs,
+                getattr(ops, "attention_f16x3", None), self.local_motion_args["window_size"],
+                self.global_motion_args["window_size"], self._workspace_key(im0))
+
     def forward(self, im0: torch.Tensor, im1: torch.Tensor, reuse_first: bool = False):
         self._reuse_first = bool(reuse_first)
-        if not self.use_graphs or not im0.is_cuda or self._frame_cache_on:
+        if not im0.is_cuda or self._frame_cache_on:
             return self._forward_eager(im0, im1)
+        if self.use_graphs:
+            return self._forward_graph(im0, im1)
+        ops = self._ops_obj
+        pl = self._plist
+        if (not self.use_plans or self.ensemble_global_motion or not isinstance(ops, HipOps) or ops.profile is not None
+                or pl is None or pl[0].device != im0.device or torch.cuda.is_current_stream_capturing()):
+            return self._forward_eager(im0, im1)         # (also every case that must raise: it validates devices and shapes)
+        self._prepare(ops)
+        if self._plan_sig is not self._prepared_sig:         # parameters changed: recorded launches hold stale weight pointers
+            self._plans.clear()
+            self._plan_sig = self._prepared_sig
+        key = self._mode_key(ops, im0, im1)
+        ent = self._plans.get(key, 0)
+        if ent is False:
+            return self._forward_eager(im0, im1)
+        if isinstance(ent, int):
+            if ent < 2:                                      # the first two forwards build the workspace, maps, kernel attributes
+                self._plans[key] = ent + 1
+                return self._forward_eager(im0, im1)
+            return self._record_plan(ops, key, im0, im1)
+        if im0.shape != im1.shape or im0.device != im1.device or im0.device != ops.device:
+            return self._forward_eager(im0, im1)             # raises the proper error
+        with torch.cuda.device(im0.device):
+            a = im0.detach().contiguous().float()
+            b = im1.detach().contiguous().float()
+            self._select_workspace(key[-1])                  # replay counts as a use for the workspace LRU
+            return ent.run((a, b), ops.device, ops._stream())
+
+    def _record_plan(self, ops, key, im0, im1):
+        a = im0.detach().contiguous().float()
+        b = im1.detach().contiguous().float()
+        try:
+            ops.begin_plan((a, b))
+            out = self._forward_eager(a, b)
+            self._plans[key] = ops.end_plan(out)
+            return out
+        except PlanUnsupported:
+            ops.abort_plan()
+            self._plans[key] = False
+            return self._forward_eager(im0, im1)
+        except Exception:
+            ops.abort_plan()
+            raise
+
+    def _forward_graph(self, im0: torch.Tensor, im1: torch.Tensor):
         ops = self._ops(im0.device)
         self._prepare(ops)
-        if self._graph_sig != self._prepared_sig:            # parameters changed: the captured launches hold stale weights
+        if self._graph_sig is not self._prepared_sig:        # parameters changed: the captured launches hold stale weights
             self._graphs.clear()
             self._graph_sig = self._prepared_sig
-        key = (tuple(im0.shape), tuple(im1.shape), str(im0.device), self.global_motion, self.ensemble_global_motion,
-               self._precision, self.use_split_planes, self.use_plane_convs, self.use_unet_planes, self.use_plane_deconvs,
-               getattr(ops, "attention_f16x3", None), self.local_motion_args["window_size"],
-               self.global_motion_args["window_size"], self._workspace_key(im0))
+        key = self._mode_key(ops, im0, im1)
         ent = self._graphs.get(key)
         if ent is None:
             for _ in range(2):                               # validation, workspace, window maps, packed weights, kernel attributes
@@ -712,23 +833,40 @@ class Network(BlockRunner, nn.Module):
             ops.image_pyramid(im0, im1, pyr_st[1], pyr_st[2], pyr_st[3])      # one launch for the three levels of both frames
             # encoder + local fusion (:451-455)
             x0 = self.buf("x0", 2 * b, H, W, 4); ops.pack_frames(im0, im1, x0)
-            cache_ok = self._frame_cache_on and not self.global_motion
-            ck = (self._ws_key, self._prepared_sig)         # same device, shape, mode and weights as the call that filled the cache
+            cache_ok = self._frame_cache_on and not (self.global_motion and self.ensemble_global_motion)
+            glob = self.global_motion and not self.ensemble_global_motion
+            cg = v.global_dim
+            ck = (self._ws_key, id(self._prepared_sig))     # same device, shape, mode and weights as the call that filled the cache
             hit = cache_ok and self._reuse_first and self._frame_cache is not None and self._frame_cache[0] == ck
+            gtok = None
             if hit:
-                # frame 0 of this pair was frame 1 of the previous call: encoder + fusion on the new frame only
+                # frame 0 of this pair was frame 1 of the previous call: encoder + fusions (everything that is per frame) on the
+                # new frame only; the previous call's tokens of the shared frame are copied in front of the new ones
                 e1, e2, fuse_l = self._encoder(ops, P, x0[b:], "fc")
                 one = self._fusion(ops, P, "cross_scale_feature_fusion", e1, e2, fuse_l, d[2], d[1], "fcl")   # [B*h*w, C]
                 feat = self.buf("lfnorm", 2 * b * h * w, C)
                 feat[:b * h * w].copy_(self._frame_cache[1])
                 feat[b * h * w:].copy_(one)
+                if glob:
+                    g_one = self._global_tokens(ops, P, e2, fuse_l, "fc")                                     # [B*h_*w_, cg]
+                    n_g = b * (H // 16) * (W // 16)
+                    gtok = self.buf("gfnorm", 2 * n_g, cg)
+                    gtok[:n_g].copy_(self._frame_cache[2])
+                    gtok[n_g:].copy_(g_one)
             else:
                 e1, e2, fuse_l = self._encoder(ops, P, x0, "")
                 feat = self._fusion(ops, P, "cross_scale_feature_fusion", e1, e2, fuse_l, d[2], d[1], "l")   # [2B*h*w, C]
+                if glob:
+                    gtok = self._global_tokens(ops, P, e2, fuse_l, "")                                        # [2B*h_*w_, cg]
             if cache_ok:
                 keep = self.buf("frame_cache_tokens", b * h * w, C)
                 keep.copy_(feat[b * h * w:])
-                self._frame_cache = (ck, keep)
+                keep_g = None
+                if glob:
+                    n_g = b * (H // 16) * (W // 16)
+                    keep_g = self.buf("frame_cache_gtokens", n_g, cg)
+                    keep_g.copy_(gtok[n_g:])
+                self._frame_cache = (ck, keep, keep_g)
             self._reuse_first = False
             it_list: List[torch.Tensor] = []
             w0_list: List[torch.Tensor] = []
@@ -739,7 +877,7 @@ class Network(BlockRunner, nn.Module):
                 if self.ensemble_global_motion:
                     g0, g1 = self._ensemble_flows(ops, P, im0, im1)
                 else:
-                    gout = self._global_motion(ops, P, e2, fuse_l, b, "")
+                    gout = self._global_from_tokens(ops, P, gtok, b, h_, w_, "")
                     i_16 = self.buf("im_16", 2 * b, 3, h_, w_); ops.resize(pyr_st[3], i_16)
                     a, c, t = (ops.empty(b, 3, h_, w_) for _ in range(3))
                     ops.warp_blend(i_16[:b], i_16[b:], gout[..., :5], a, c, t)

@@ -102,6 +102,76 @@ class PipelinedGather:
         return self._finish()
 
 
+class HostGather(PipelinedGather):
+    """``PipelinedGather`` for a consumer on the HOST (the video loop): the all-gather and the device -> pinned-host copies of the
+    gathered frames run on a stream of their own, behind an event recorded when this rank's frames were produced -- NOT behind
+    whatever the compute stream has queued since.  ``submit`` / ``drain`` return the previous step's frames as numpy arrays (rank
+    order), blocking the host only until THAT step's gather and copies are done, so the next round's forwards (already enqueued)
+    keep the GPU busy meanwhile.  With ``t.cpu()`` on the compute stream instead, every round's delivery waited for the following
+    round's whole compute and the GPU then idled while the host consumed the frames.  On CPU tensors (gloo tests) it degrades to
+    the plain gather + ``numpy()``."""
+
+    def __init__(self, world: int, wire_shape, device, wire_dtype=torch.float32, encode: Callable = None, group=None):
+        super().__init__(world, wire_shape, device, wire_dtype, encode, group)
+        self.cuda = torch.device(device).type == "cuda"
+        if self.cuda:
+            self.stream = torch.cuda.Stream(device)
+            self.host = [[torch.empty(wire_shape, dtype=wire_dtype).pin_memory() for _ in range(world)] for _ in range(3)]
+
+    def _finish(self):
+        if self.pending is None:
+            return None
+        done, r, valid = self.pending
+        self.pending = None
+        if not self.cuda:
+            if done is not None:
+                done.wait()
+            return [t.numpy().copy() for t in self.recv[r][:valid]]
+        done.synchronize()
+        return [t.numpy().copy() for t in self.host[r][:valid]]
+
+    def submit(self, local, valid: int = None):
+        if not self.cuda:
+            s, r = self.k & 1, self.k % 3
+            self.k += 1
+            if local is None:
+                self.send[s].zero_()
+            else:
+                self.send[s].copy_(self.encode(local) if self.encode is not None else local)
+            prev = self._finish()
+            work = None
+            if self.world == 1 and not (dist.is_available() and dist.is_initialized()):
+                self.recv[r][0].copy_(self.send[s])
+            else:
+                work = dist.all_gather(self.recv[r], self.send[s], group=self.group, async_op=True)
+            self.pending = (work, r, self.world if valid is None else valid)
+            return prev
+        s, r = self.k & 1, self.k % 3
+        self.k += 1
+        cur = torch.cuda.current_stream(self.send[s].device)
+        if local is None:
+            self.send[s].zero_()
+        else:
+            self.send[s].copy_(self.encode(local) if self.encode is not None else local)
+        produced = torch.cuda.Event()
+        produced.record(cur)
+        prev = self._finish()                   # host waits for step k-1's gather + copies (set r of step k-1 is not this one)
+        nv = self.world if valid is None else valid
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(produced)
+            if self.world == 1 and not (dist.is_available() and dist.is_initialized()):
+                self.recv[r][0].copy_(self.send[s], non_blocking=True)
+            else:
+                work = dist.all_gather(self.recv[r], self.send[s], group=self.group, async_op=True)
+                work.wait()                     # RCCL: this side stream waits for the collective; gloo: the host does
+            for i in range(nv):
+                self.host[r][i].copy_(self.recv[r][i], non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        self.pending = (done, r, nv)
+        return prev
+
+
 def shard_blocks(n_items: int, world: int, block: int):
     """Rounds of ``world * block`` consecutive items; in a round rank r owns the ``block`` consecutive items
     ``[round_start + r * block, +block)`` (clipped to ``n_items``).  Consecutive items on one rank let the video path reuse the
@@ -117,7 +187,7 @@ def shard_blocks(n_items: int, world: int, block: int):
 
 
 def interpolate_video_2x_sharded(frames: Sequence, interpolate_pair: Callable, rank: int, world: int, wire_shape, wire_dtype=torch.uint8,
-                                 block: int = 1, decode: Callable = None, device="cpu", group=None):
+                                 block: int = 1, decode: Callable = None, device="cpu", group=None, host_gather: bool = False):
     """demo_2x.py:129-168's frame loop over the GPUs of a node: pair i = (frames[i], frames[i+1]); rounds of ``world * block`` pairs,
     rank r interpolating ``block`` consecutive pairs of each round; the predictions of a round are all-gathered (one step behind the
     next round's compute, PipelinedGather) so that EVERY rank yields the full 2n-1 sequence f0, I(f0,f1), f1, ..., f_{n-1} in order.
@@ -126,7 +196,8 @@ def interpolate_video_2x_sharded(frames: Sequence, interpolate_pair: Callable, r
     this rank's prediction as a tensor of ``wire_shape`` / ``wire_dtype`` on ``device`` (e.g. the uint8 [H,W,3] frame of
     ``FramePipeline``: 4x fewer bytes over xGMI than fp32); ``reuse_first`` is True when f_a was the previous call's f_b on this
     rank, so an implementation may reuse that frame's encoder features (``Network.enable_frame_cache``).  ``decode`` converts a
-    gathered wire tensor to what is yielded (default: the tensor itself).
+    gathered wire tensor to what is yielded (default: the tensor itself).  ``host_gather``: gather through ``HostGather`` -- the
+    frames arrive as numpy arrays from pinned host buffers filled on a side stream (``decode`` is then applied to those arrays).
 
     The collectives are issued from inside this generator, so EVERY rank must run it to the end (a rank that stops iterating early
     leaves the others waiting in their next all-gather until the process group's timeout -- create the group with one); when a
@@ -135,14 +206,15 @@ def interpolate_video_2x_sharded(frames: Sequence, interpolate_pair: Callable, r
     n = len(frames)
     if n == 0:
         return
-    gather = PipelinedGather(world, (block,) + tuple(wire_shape), device, wire_dtype, group=group)
+    gather = (HostGather if host_gather else PipelinedGather)(world, (block,) + tuple(wire_shape), device, wire_dtype, group=group)
 
     def emit(start, spans, got):
         i = start
         for r, (a, b) in enumerate(spans):
             for j in range(b - a):
                 yield frames[i]
-                yield decode(got[r][j]) if decode is not None else got[r][j].clone()
+                f = got[r][j]
+                yield decode(f) if decode is not None else (f.copy() if host_gather else f.clone())
                 i += 1
 
     prev_meta = None

@@ -341,6 +341,30 @@ int atmvfi_frame_f32_to_u8(const float* src, int Hp, int Wp, int pad_top, int pa
 /* mean |a - b| per sample: global_alignmentness (network_base.py:560-561).  out[B] must be zeroed by the caller. */
 int atmvfi_l1_mean(const float* a, const float* b, float* out, int B, int64_t per_sample, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Launch plans: one forward of the hot path as ONE call.
+ *
+ * The reference's callers run `model(im0, im1)` in a loop on frames of one size (benchmark/test_vimeo90k.py: 3 782 triplets of
+ * 256x448; demo_2x.py:129-168: every pair of a video).  For such a loop the sequence of launches of a forward is fixed: same entry
+ * points, same arguments, except the pointers into the caller's two frames and into the freshly allocated output tensors.  The host
+ * records that sequence once (every launch entry point above, arguments in declaration order, stream excluded) and replays it:
+ * atmvfi_plan_run() first patches the arguments that point into per-call memory -- ops[p.op].a[p.arg] = slots[p.slot] + p.offset --
+ * and then issues the ops in order on `stream`, stopping at the first failure (*failed_op = its index; the return value and
+ * atmvfi_last_error() are that op's).  Nothing is cached inside the library: the plan is the caller's array.
+ * atmvfi_plan_fn_id(name) gives the `fn` of an entry point by name (-1 if it is not a launch entry point).
+ * ---------------------------------------------------------------------------------- */
+typedef union atmvfi_plan_arg { uint64_t u; int64_t i; double f; } atmvfi_plan_arg;
+#define ATMVFI_PLAN_MAX_ARGS 28
+typedef struct atmvfi_plan_op {
+    int32_t fn;       /* atmvfi_plan_fn_id() */
+    int32_t nargs;    /* must equal the entry point's argument count without the stream (checked) */
+    atmvfi_plan_arg a[ATMVFI_PLAN_MAX_ARGS];   /* pointers and sizes as .u / .i (64-bit), float arguments as .f */
+} atmvfi_plan_op;
+typedef struct atmvfi_plan_patch { int32_t op, arg, slot, reserved; int64_t offset; } atmvfi_plan_patch;
+int atmvfi_plan_fn_id(const char* name);
+int atmvfi_plan_run(atmvfi_plan_op* ops, int n_ops, const atmvfi_plan_patch* patches, int n_patches, const uint64_t* slots, int n_slots,
+                    int* failed_op, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -382,3 +382,66 @@ def test_model_moved_to_other_device_drops_device_state(dev, weights):
         net(a.to(dev), b.to(dev))                          # parameters on the CPU, inputs on the GPU
     net.to(dev)
     assert torch.equal(net(a.to(dev), b.to(dev))["I_t"], o1)
+
+
+def _flat(out):
+    return [out[k] for k in ("I_t", "opt_flow_0", "opt_flow_1", "I_t_0", "I_t_1", "occ_mask1", "occ_mask2")] + list(out["im_t_list"]) + \
+        list(out["im0_warped_list"]) + list(out["im1_warped_list"])
+
+
+def test_launch_plan_replay_equals_direct_launches(dev, weights):
+    """From the third forward of one (shape, mode, weights) key on, ``forward`` is one atmvfi_plan_run call (hip_ops.LaunchPlan):
+    bit-identical to the direct launches, on new inputs too; output tensors are fresh on every call (a caller may keep earlier
+    results); other shapes and modes keep their own plans; an in-place parameter update re-records; ensemble mode stays eager."""
+    net = pkg.NetworkLite()
+    net.load_state_dict(weights("lite"), strict=True)
+    net.to(dev).eval()
+    a = [t.to(dev) for t in pairs.smooth_pair(1, 128, 192, seed=81)]
+    b = [t.to(dev) for t in pairs.random_pair(1, 128, 192, seed=82)]
+    c = [t.to(dev) for t in pairs.smooth_pair(2, 64, 128, seed=83)]
+    net.enable_plans(False)
+    ref = {n: [t.clone() for t in _flat(net(*x))] for n, x in (("a", a), ("b", b), ("c", c))}
+    net.enable_plans(True)
+    kept = []
+    for rep in range(5):
+        for n, x in (("a", a), ("b", b), ("c", c)):
+            out = net(*x)
+            assert out["I_t_0"] is out["im0_warped_list"][0] and out["im_t_list"][0] is not out["I_t"]
+            for t, r in zip(_flat(out), ref[n]):
+                assert torch.equal(t, r)
+            kept.append((n, out["I_t"]))
+    plans = [p for p in net._plans.values() if not isinstance(p, (int, bool))]
+    assert len(plans) == 2 and all(len(p.ops_list) > 50 and len(p.patches) > 10 for p in plans)     # a and b share shape and mode
+    ptrs = [t.data_ptr() for _, t in kept]
+    assert len(set(ptrs)) == len(ptrs)                      # fresh outputs: nothing handed out twice while the caller holds it
+    for n, t in kept:                                        # ... and earlier results are intact
+        assert torch.equal(t, ref[n][0])
+    # global branch off: another key, another plan, still exact
+    net.global_motion = False
+    net.enable_plans(False)
+    r2 = [t.clone() for t in _flat(net(*a))]
+    net.enable_plans(True)
+    for rep in range(4):
+        for t, r in zip(_flat(net(*a)), r2):
+            assert torch.equal(t, r)
+    net.global_motion = True
+    # an in-place parameter update must reach the replayed forward
+    for rep in range(3):
+        net(*a)
+    with torch.no_grad():
+        net.refine_head._modules["1"]._modules["0"].bias.add_(0.25)
+    out = net(*a)
+    assert not torch.equal(out["I_t"], ref["a"][0])
+    net.enable_plans(False)
+    want = net(*a)["I_t"].clone()
+    net.enable_plans(True)
+    for rep in range(4):
+        assert torch.equal(net(*a)["I_t"], want)
+    # ensemble mode contains torch-side work: never planned, still correct
+    e0, e1 = [t.to(dev) for t in pairs.smooth_pair(1, 128, 192, seed=81)]
+    net.ensemble_global_motion = True
+    big = [torch.nn.functional.interpolate(t, size=(192, 256), mode="bilinear") for t in (e0, e1)]
+    outs = [net(*big)["I_t"].clone() for _ in range(4)]
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    assert not [k for k, p in net._plans.items() if k[4] and not isinstance(p, (int, bool))]
+    net.ensemble_global_motion = False

@@ -354,3 +354,76 @@ def test_bench_named_configs_are_baselines():
         text = cfg[i].replace("×", "x")
         assert f"network_{variant}" in text and f"{h}x{w}" in text
         assert ("global_off" in text) == (not g_on)
+
+
+def test_plan_dispatch_is_generated_from_the_header():
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_plan_dispatch.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_plan_run_patches_dispatches_and_reports_the_failing_op():
+    """atmvfi_plan_run on the CPU box: no launch happens -- the ops below fail their entry point's host-side validation, which is
+    exactly what a direct call reports -- but ids, argument counts, slot patching and the failing-op index are all exercised."""
+    lib = hip_ops.load_library()
+    fid = lib.atmvfi_plan_fn_id(b"atmvfi_pack_frames")
+    assert fid >= 0 and lib.atmvfi_plan_fn_id(b"atmvfi_version") == -1 and lib.atmvfi_plan_fn_id(b"nope") == -1
+    names = [n for n, (res, args) in hip_ops.SIGNATURES.items() if args and args[-1] is hip_ops.c_f and n != "atmvfi_plan_run"
+             and res is hip_ops.c_i and not n.startswith(("atmvfi_packed", "atmvfi_split_weight", "atmvfi_conv3x3_weight"))]
+    ids = sorted(lib.atmvfi_plan_fn_id(n.encode()) for n in names)
+    assert ids == list(range(len(ids))), "every launch entry point of the binding has a plan id"
+
+    ops = (hip_ops.PlanOp * 2)()
+    # op 0: pack_frames(im0, im1, dst, B, H, W) with B = 0 -> EINVAL from the entry point itself
+    ops[0].fn, ops[0].nargs = fid, 6
+    for j, v in enumerate((0x1000, 0x2000, 0x3000, 0, 8, 8)):
+        ops[0].a[j].u = v
+    ops[1].fn, ops[1].nargs = fid, 6
+    patches = (hip_ops.PlanPatch * 1)()
+    patches[0].op, patches[0].arg, patches[0].slot, patches[0].offset = 0, 2, 1, 64
+    slots = (ctypes.c_uint64 * 2)(0x10000, 0x20000)
+    failed = ctypes.c_int(-5)
+    rc = lib.atmvfi_plan_run(ops, 2, patches, 1, slots, 2, ctypes.byref(failed), None)
+    assert rc != 0 and failed.value == 0 and lib.atmvfi_last_error()
+    assert ops[0].a[2].u == 0x20000 + 64                     # patched in place before the ops run
+    # wrong argument count / unknown id are reported with the op index; patches out of range never touch memory
+    ops[0].nargs = 5
+    assert lib.atmvfi_plan_run(ops, 2, None, 0, None, 0, ctypes.byref(failed), None) != 0 and failed.value == 0
+    assert b"arguments" in lib.atmvfi_last_error()
+    ops[0].fn = 999
+    assert lib.atmvfi_plan_run(ops, 1, None, 0, None, 0, ctypes.byref(failed), None) != 0
+    patches[0].slot = 7
+    assert lib.atmvfi_plan_run(ops, 2, patches, 1, slots, 2, ctypes.byref(failed), None) != 0 and b"out of range" in lib.atmvfi_last_error()
+
+
+def test_launch_plan_recorder_on_the_host():
+    """hip_ops.LaunchPlan without a GPU: a fake library and fake tensors -- per-call pointers become patches, parameter blocks are
+    referenced by address and refused when they point into per-call memory, results must be whole output slots."""
+    class T:                                                   # the three tensor attributes the recorder reads
+        def __init__(self, ptr, shape):
+            self.ptr, self.shape, self.dtype = ptr, shape, torch.float32
+        def data_ptr(self): return self.ptr
+        def numel(self): return int(np.prod(self.shape))
+        def element_size(self): return 4
+
+    class Fn:
+        def __init__(self, name): self.__name__ = name
+
+    class Lib:
+        def atmvfi_plan_fn_id(self, n): return {b"atmvfi_pack_frames": 3, b"atmvfi_linear": 5}.get(n, -1)
+
+    im0, im1 = T(0x1000, (1, 3, 4, 4)), T(0x2000, (1, 3, 4, 4))
+    plan = hip_ops.LaunchPlan(Lib(), (im0, im1))
+    out = T(0x9000, (2, 4, 4, 4))
+    plan.add_output(out)
+    plan.add_op(Fn("atmvfi_pack_frames"), (ctypes.c_void_p(0x1000 + 16), ctypes.c_void_p(0x2000), ctypes.c_void_p(0x9000), 1, 4, 4, None))
+    assert plan.patches == [(0, 0, 0, 16), (0, 1, 1, 0), (0, 2, 2, 0)]
+    assert plan.ops_list[0][0] == 3 and [v for _, v in plan.ops_list[0][1]] == [0x1010, 0x2000, 0x9000, 1, 4, 4]
+    blk = hip_ops.GemmParams(out=0x50000)
+    plan.add_op(Fn("atmvfi_linear"), (ctypes.byref(blk), None))
+    assert plan.ops_list[1][1] == [("u", ctypes.addressof(blk))] and plan.keep == [blk]
+    with pytest.raises(hip_ops.PlanUnsupported):
+        plan.add_op(Fn("atmvfi_linear"), (ctypes.byref(hip_ops.GemmParams(out=0x9000 + 8)), None))
+    with pytest.raises(hip_ops.PlanUnsupported):
+        plan.add_op(Fn("atmvfi_version"), (None,))

@@ -93,7 +93,7 @@ def _pipelined_worker(rank, world, port, n_steps, q):
     q.put((rank, bool(ok)))
 
 
-def _video_worker(rank, world, port, n_frames, block, q):
+def _video_worker(rank, world, port, n_frames, block, q, host_gather=False):
     sys.path.insert(0, ROOT)
     sharding = importlib.import_module("atm-vfi_amd.sharding")
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -105,7 +105,8 @@ def _video_worker(rank, world, port, n_frames, block, q):
     def pair(fa, fb, reuse_first):
         calls.append((int(fa[0, 0, 0]) // 10, bool(reuse_first)))
         return ((fa.to(torch.int32) + fb.to(torch.int32)) // 2).to(torch.uint8)     # "interpolated" frame 10 i + 5
-    out = list(sharding.interpolate_video_2x_sharded(frames, pair, rank, world, (4, 5, 3), torch.uint8, block=block))
+    out = list(sharding.interpolate_video_2x_sharded(frames, pair, rank, world, (4, 5, 3), torch.uint8, block=block,
+                                                     host_gather=host_gather))
     vals = [int(t[0, 0, 0]) for t in out]
     ok = vals == [5 * k for k in range(2 * n_frames - 1)]                            # f0, I01, f1, ..., f_{n-1}: every rank, in order
     # this rank computed exactly its blocks, and reuse is announced exactly for consecutive pairs inside a block
@@ -115,6 +116,10 @@ def _video_worker(rank, world, port, n_frames, block, q):
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, bool(ok)))
+
+
+def _video_worker_host(rank, world, port, n_frames, block, q):
+    _video_worker(rank, world, port, n_frames, block, q, host_gather=True)
 
 
 def _run_world2(target, *args):
@@ -138,6 +143,12 @@ def test_pipelined_gather_world2(n_steps):
 @pytest.mark.parametrize("n_frames,block", [(2, 1), (6, 1), (8, 2), (7, 3), (1, 1)])
 def test_sharded_video_frame_order_world2(n_frames, block):
     _run_world2(_video_worker, n_frames, block)
+
+
+@pytest.mark.parametrize("n_frames,block", [(6, 1), (7, 3)])
+def test_sharded_video_through_host_gather_world2(n_frames, block):
+    """HostGather (the video path's collective: frames delivered as numpy arrays from host buffers) on CPU tensors over gloo."""
+    _run_world2(_video_worker_host, n_frames, block)
 
 
 @pytest.mark.parametrize("n_pairs", [8, 5, 1])

@@ -22,15 +22,11 @@ def short(name: str) -> str:
 
 
 def csrc_digest():
-    """sha256 over atm-vfi_amd/csrc (as bench.py computes it): the build these counters were taken on."""
-    import hashlib
-    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "atm-vfi_amd", "csrc")
-    hsh = hashlib.sha256()
-    for fn in sorted(os.listdir(root)):
-        if fn.endswith((".hip", ".h")):
-            hsh.update(fn.encode())
-            hsh.update(open(os.path.join(root, fn), "rb").read())
-    return hsh.hexdigest()
+    """The build these counters were taken on: bench.py's own digest (kernel sources, C-ABI header, Makefile), so the two cannot drift."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    return bench.csrc_digest()
 
 
 def counter_sum(d, counter):
