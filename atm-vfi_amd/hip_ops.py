@@ -115,6 +115,7 @@ SIGNATURES = {
     "atmvfi_pack_frames": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_f]),
     "atmvfi_final_residual": (c_i, [c_f, c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_f]),
     "atmvfi_l1_mean": (c_i, [c_f, c_f, c_f, c_i, c_l, c_f]),
+    "atmvfi_stem_fused": (c_i, [c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_l, c_f]),
     "atmvfi_plan_fn_id": (c_i, [ctypes.c_char_p]),
     "atmvfi_plan_run": (c_i, [ctypes.POINTER(PlanOp), c_i, ctypes.POINTER(PlanPatch), c_i, ctypes.POINTER(ctypes.c_uint64), c_i,
                               ctypes.POINTER(c_i), c_f]),
@@ -147,6 +148,25 @@ class PackedWeight:
     lo: Optional[torch.Tensor] = None
     hi3: Optional[torch.Tensor] = None  # 3x3 weights again in the conv3x3_f16x3 layout (k-step major, tap-packed channel tail)
     lo3: Optional[torch.Tensor] = None
+
+
+@dataclass
+class StemWeights:
+    """Operands of ``atmvfi_stem_fused`` (HipOps.pack_stem)."""
+    c0: int
+    c1: int
+    w1h: torch.Tensor
+    w1l: torch.Tensor
+    b1: torch.Tensor
+    p1: torch.Tensor
+    w2h: torch.Tensor
+    w2l: torch.Tensor
+    b2: torch.Tensor
+    p2: torch.Tensor
+    w3h: torch.Tensor
+    w3l: torch.Tensor
+    b3: torch.Tensor
+    p3: torch.Tensor
 
 
 class Planes:
@@ -287,7 +307,11 @@ class LaunchPlan:
         self.out_meta.append((tuple(t.shape), t.dtype))
         self.out_tensors.append(t)
 
-    def add_op(self, fn, args):
+    def add_op(self, fn, args, ptr_bases=None):
+        """``ptr_bases``: {argument index: address of the tensor the argument belongs to} for pointer arguments that do not point INTO
+        their tensor (the compact fp32 view of the 3x3 plane kernel passes ``buffer - 4 * out_cmin``: an address inside whatever
+        allocation happens to sit in front of the buffer -- classified by its raw value it became a per-call pointer whenever that
+        neighbour was one of the recording's output tensors, and every replay then wrote the map into a fresh output's tail)."""
         name = fn.__name__
         fid = self._fn_ids.get(name)
         if fid is None:
@@ -317,9 +341,10 @@ class LaunchPlan:
                 v = v.value
             v = 0 if v is None else int(v)
             if ty is c_f and v:
-                hit = self._slot_of(v)
+                base = v if not ptr_bases or j not in ptr_bases else ptr_bases[j]
+                hit = self._slot_of(base)
                 if hit is not None:
-                    self.patches.append((k, j, hit[0], hit[1]))
+                    self.patches.append((k, j, hit[0], hit[1] + (v - base)))
             vals.append(("u" if v >= 0 else "i", v))
         self.ops_list.append((fid, vals))
 
@@ -364,8 +389,23 @@ class LaunchPlan:
         base = self.n_inputs
         for k, t in enumerate(outs):
             sl[base + k] = t.data_ptr()
-        rc = self.lib.atmvfi_plan_run(self.c_ops, len(self.ops_list), self.c_patches, len(self.patches), sl, len(self.slots),
-                                      ctypes.byref(self.failed), stream)
+        if os.environ.get("ATMVFI_PLAN_DEBUG") == "1":          # diagnostic: one op per call, synchronised, announced on stderr first
+            import sys
+            names = {v: k for k, v in self._fn_ids.items()}
+            for k, j, slot, off in self.patches:
+                self.c_ops[k].a[j].u = sl[slot] + off
+            rc = 0
+            for i in range(len(self.ops_list)):
+                print(f"plan op {i} {names.get(self.c_ops[i].fn)} args " + " ".join(hex(self.c_ops[i].a[j].u) for j in range(self.c_ops[i].nargs)),
+                      file=sys.stderr, flush=True)
+                one = ctypes.cast(ctypes.byref(self.c_ops[i]), ctypes.POINTER(PlanOp))
+                rc = self.lib.atmvfi_plan_run(one, 1, None, 0, None, 0, ctypes.byref(self.failed), stream)
+                torch.cuda.synchronize()
+                if rc:
+                    break
+        else:
+            rc = self.lib.atmvfi_plan_run(self.c_ops, len(self.ops_list), self.c_patches, len(self.patches), sl, len(self.slots),
+                                          ctypes.byref(self.failed), stream)
         if rc != 0:
             raise RuntimeError(f"plan_run failed ({rc}) at op {self.failed.value}: {self.lib.atmvfi_last_error().decode()}")
 
@@ -421,7 +461,7 @@ class HipOps:
 
     def _run(self, name: str, meta: dict, fn, *args):
         if self.recording is not None:
-            self.recording.add_op(fn, args)
+            self.recording.add_op(fn, args, meta.get("ptr_bases"))
         if self.profile is None:
             self._check(fn(*args), name)
             return
@@ -545,6 +585,55 @@ class HipOps:
         self._gemm_sink(p, planes, n * oh * ow, cout, planes_c0, 0, 1, "conv")
         self._run("conv2d_f16x3" if p.precision else "conv2d", meta, self.lib.atmvfi_conv2d, ctypes.byref(p), self._stream())
 
+    def pack_stem(self, w1, b1, p1, w2, b2, p2, w3, b3, p3) -> "StemWeights":
+        """The operand layouts of ``atmvfi_stem_fused`` (include/atmvfi.h) from the nine parameters of feat_extracts.0.0 / 0.1 / 1.0
+        (weight, bias, PReLU slope each): fp16 hi / lo' planes [k-step][cout][32] with k = (ky * 3 + kx) * Cin + c (layer 1: one
+        k-step of 27 values).  Host-side torch ops, once per parameter version (like the q / kv stacking in ``_prepare``)."""
+        c0, c1 = w2.shape[0], w3.shape[0]
+        if tuple(w1.shape) != (c0, 3, 3, 3) or tuple(w2.shape) != (c0, c0, 3, 3) or tuple(w3.shape) != (c1, c0, 3, 3):
+            raise ValueError("pack_stem: expected 3 -> C0 -> C0 -> C1 3x3 weights")
+        ns = (9 * c0 + 31) // 32
+
+        def planes_of(w, rows):
+            k = w.detach().float().permute(0, 2, 3, 1).reshape(w.shape[0], 9 * c0)          # [cout][(ky, kx, c)]
+            full = torch.zeros(rows, ns * 32, dtype=torch.float32, device=self.device)
+            full[:w.shape[0], :9 * c0] = k
+            full = full.reshape(rows, ns, 32).permute(1, 0, 2).contiguous()                  # [k-step][cout][32]
+            hi = full.half()
+            lo = ((full - hi.float()) * 1024.0).half()
+            return hi, lo
+
+        def padded(v, rows, fill):
+            out = torch.full((rows,), fill, dtype=torch.float32, device=self.device)
+            out[:v.shape[0]] = v.detach().float()
+            return out
+        r2 = (c0 + 15) // 16 * 16
+        w2h, w2l = planes_of(w2, r2)
+        w3h, w3l = planes_of(w3, c1)
+        k1 = torch.zeros(r2, 32, dtype=torch.float32, device=self.device)                   # [cout][(ky, kx, ci)], 27 values
+        k1[:c0, :27] = w1.detach().float().permute(0, 2, 3, 1).reshape(c0, 27)
+        w1h = k1.half()
+        w1l = ((k1 - w1h.float()) * 1024.0).half()
+        return StemWeights(c0, c1, w1h, w1l, padded(b1, r2, 0.0), padded(p1, r2, 1.0), w2h, w2l, padded(b2, r2, 0.0), padded(p2, r2, 1.0),
+                           w3h, w3l, b3.detach().float().contiguous(), p3.detach().float().contiguous())
+
+    def stem_fused(self, x, w: "StemWeights", out: Planes):
+        """feat_extracts.0.0 -> 0.1 -> 1.0 (network_base.py:99-110) in one launch: NHWC4 frames [F,H,W,4] -> split planes of the
+        half-resolution C1-channel map (rows = pixels (f, y, x))."""
+        _chk(x, "stem_fused.x")
+        if x.dim() != 4 or x.shape[3] != 4 or not x.is_contiguous():
+            raise ValueError(f"stem_fused: expected contiguous NHWC4 frames [F,H,W,4], got {tuple(x.shape)}")
+        f, h, wd, _ = x.shape
+        if h % 2 or wd % 2 or out.rows != f * (h // 2) * (wd // 2) or out.c != w.c1:
+            raise ValueError(f"stem_fused: planes [{out.rows},{out.c}] do not hold {f}x{h // 2}x{wd // 2} pixels x {w.c1} channels")
+        if self.precision != "f16x3":
+            raise ValueError("stem_fused: needs the f16x3 engine")
+        flops = 2.0 * f * h * wd * (27 * w.c0 + 9 * w.c0 * w.c0) + 2.0 * f * (h // 2) * (wd // 2) * 9 * w.c0 * w.c1
+        meta = {"flops": flops, "bytes": 16.0 * f * h * wd + 4.0 * out.rows * out.chunks * 32, "shape": f"{f}x{h}x{wd} 3>{w.c0}>{w.c0}>{w.c1}s2"}
+        self._run("stem_fused", meta, self.lib.atmvfi_stem_fused, _ptr(x), f, h, wd, w.c0, w.c1, _ptr(w.w1h), _ptr(w.w1l), _ptr(w.b1), _ptr(w.p1),
+                  _ptr(w.w2h), _ptr(w.w2l), _ptr(w.b2), _ptr(w.p2), _ptr(w.w3h), _ptr(w.w3l), _ptr(w.b3), _ptr(w.p3),
+                  out.t[0].data_ptr(), out.t[1].data_ptr(), out.ld_rows, self._stream())
+
     def conv3x3_planes(self, x: Planes, n: int, h: int, wd: int, w: PackedWeight, out=None, bias=None, prelu=None,
                        planes: Optional[Planes] = None, planes_c0: int = 0, planes_prelu=None, in_chunk0: int = 0, cin: Optional[int] = None,
                        wn: int = 0, out_cmin: int = 0, planes2: Optional[Planes] = None, planes2_c0: int = 0):
@@ -563,12 +652,14 @@ class HipOps:
         cout = w.cout
         old = 0
         out_ptr = _ptr(out)
+        compact_base = None
         if out is not None:
             old, on, oh, ow, oc = nhwc_view(out, "conv3x3_planes.out")
             if (on, oh, ow) == (n, h, wd) and oc == cout - out_cmin and out_cmin > 0:
                 # compact view of just the stored channels [out_cmin, cout): the kernel never touches columns below out_cmin, so the
                 # base may point that many floats in front of the buffer (out_cmin % 4 == 0 keeps the 16-byte alignment)
                 out_ptr = ctypes.c_void_p(out.data_ptr() - 4 * out_cmin)
+                compact_base = out.data_ptr()
             elif (on, oh, ow, oc) != (n, h, wd, cout):
                 raise ValueError(f"conv3x3_planes: out {tuple(out.shape)} != [{n},{h},{wd},{cout}] (or {cout - out_cmin} channels: compact)")
         elif planes is None:
@@ -582,6 +673,8 @@ class HipOps:
             raise ValueError(f"conv3x3_planes: second plane sink [{planes2.rows},{planes2.c}] needs the first one and room for {cout} channels at {planes2_c0}")
         meta = {"flops": 2.0 * n * h * wd * cout * cin * 9, "bytes": 4.0 * (n * h * wd * (cin + cout) + cout * cin * 9),
                 "shape": f"M{n * h * wd} N{cout} K{cin * 9}"}
+        if compact_base is not None:
+            meta["ptr_bases"] = {10: compact_base}      # argument 10 = out: it points 4 * out_cmin bytes in front of its buffer
         coff = in_chunk0 * x.ld_rows * 32 * 2       # bytes
         self._run("conv3x3_planes", meta, self.lib.atmvfi_conv3x3_planes2, x.t[0].data_ptr() + coff, x.t[1].data_ptr() + coff, x.ld_rows,
                   n, h, wd, cin, _ptr(w.hi3), _ptr(w.lo3), cout, out_ptr, old, _ptr(bias), _ptr(prelu),

@@ -188,6 +188,7 @@ class Network(BlockRunner, nn.Module):
         self.use_plane_deconvs = os.environ.get("ATMVFI_PLANE_DECONV", "1") != "0"    # A/B switch: decoder deconvs from split planes
         self.use_plane_convs = os.environ.get("ATMVFI_PLANE_CONV", "1") != "0"        # A/B switch: 3x3 convs on split-plane input
         self.use_unet_planes = os.environ.get("ATMVFI_UNET_PLANES", "1") != "0"       # A/B switch: the refiner's strided convs on split planes
+        self.use_fused_stem = os.environ.get("ATMVFI_FUSED_STEM", "1") != "0"         # A/B switch: the encoder's first three layers in one launch
         self._prepared: Dict[str, object] = {}
         self._prepared_sig = None
         # Workspaces: one dict of named buffers per (device, input shape, mode) key, least recently used first.  The reference's
@@ -409,6 +410,8 @@ class Network(BlockRunner, nn.Module):
             wp = sd["proj.0.weight"].detach()
             wpp = torch.cat([wp[:, :w3], torch.zeros(wp.shape[0], gap, 3, 3, dtype=wp.dtype, device=wp.device), wp[:, w3:]], 1)
             P["pk:proj.0.weight:planes"] = ops.pack_weight(GEMM_CONV, wpp.contiguous())
+        if hasattr(ops, "pack_stem") and getattr(ops, "split_planes_ok", False):
+            P["stem"] = ops.pack_stem(*(sd[f"feat_extracts.{a}.{b}"].detach() for a in ("0.0", "0.1", "1.0") for b in ("0.weight", "0.bias", "1.weight")))
         for st in (1, 2):     # leading PReLU of decoder stages 1-2, applied on the deconv's input load
             P[f"inprelu:{st}"] = ops.pad_channels(sd[f"upsample_pyramid.{st}.0.weight"])
         self._prepared = P
@@ -482,22 +485,30 @@ class Network(BlockRunner, nn.Module):
         with s3 already written into fuse_l[..., -d3:] (network_base.py:342-352)."""
         d = self._v.hidden_dims
         f, h, w, _ = x0.shape
-        a = self.buf(f"{tag}e0a", f, h, w, d[0]); self._conv_act(ops, P, "feat_extracts.0.0", x0[..., :3], a)
-        e0 = self.buf(f"{tag}e0", f, h, w, d[0])
-        if self._plane_convs(ops) and min(d[1:]) >= 32 and (self._v.local_dim - d[3]) % 32 == 0:
+        planes_path = self._plane_convs(ops) and min(d[1:]) >= 32 and (self._v.local_dim - d[3]) % 32 == 0
+        fused = planes_path and self.use_fused_stem and "stem" in P and x0.is_contiguous()
+        if not fused:
+            a = self.buf(f"{tag}e0a", f, h, w, d[0]); self._conv_act(ops, P, "feat_extracts.0.0", x0[..., :3], a)
+            e0 = self.buf(f"{tag}e0", f, h, w, d[0])
+        if planes_path:
             # Stages 1-3 entirely in split planes: stride-2 conv (LDS-DMA GEMM, CONV mode) -> planes -> 3x3 conv (plane kernel) ->
             # planes; the last one writes s3 straight into the fusion buffer's planes.  No fp32 copy of e1, e2, s3 exists: their
             # only readers are contractions.
             # (The first stride-2 conv, 24 -> 48 channels at full resolution, stays on the fp32-input engine: the LDS-DMA GEMM's
             # 128-column tile is 62 % padding at N = 48 -- 0.40 ms against 0.33 -- and e0 exists in fp32 anyway.)
-            self._conv_act(ops, P, "feat_extracts.0.1", a, e0)
+            # The full-resolution stem (3 -> d0 -> d0 -> d1 stride 2) is ONE launch whose two d0-channel maps stay in LDS
+            # (atmvfi_stem_fused); A/B: use_fused_stem = False runs the three layers one by one through fp32 maps in HBM.
+            if not fused:
+                self._conv_act(ops, P, "feat_extracts.0.1", a, e0)
             ld = self._v.local_dim
             fuse_p = self.planes(f"{tag}fuse_l_p", f * (h // 8) * (w // 8), ld)
             src, outs = None, []
             for st in (1, 2, 3):
                 hs, ws = h >> st, w >> st
                 ap = self.planes(f"{tag}e{st}a_p", f * hs * ws, d[st])
-                if st == 1:
+                if st == 1 and fused:
+                    ops.stem_fused(x0, P["stem"], ap)
+                elif st == 1:
                     self._conv_s2_sink(ops, P, "feat_extracts.1.0", e0, ap, (f, hs, ws, d[1]))
                 else:
                     self._conv_p(ops, P, f"feat_extracts.{st}.0", src, stride=2, sink=ap)
@@ -709,7 +720,7 @@ class Network(BlockRunner, nn.Module):
     def _mode_key(self, ops, im0, im1) -> Tuple:
         return (tuple(im0.shape), tuple(im1.shape), str(im0.device), self.global_motion, self.ensemble_global_motion,
                 self._precision, self.use_split_planes, self.use_plane_convs, self.use_unet_planes, self.use_plane_deconvs,
-                getattr(ops, "attention_f16x3", None), self.local_motion_args["window_size"],
+                self.use_fused_stem, getattr(ops, "attention_f16x3", None), self.local_motion_args["window_size"],
                 self.global_motion_args["window_size"], self._workspace_key(im0))
 
     def forward(self, im0: torch.Tensor, im1: torch.Tensor, reuse_first: bool = False):

@@ -319,6 +319,7 @@ def main():
             families = {
                 "conv3x3_planes_kernel (3x3 s1 convs on split-plane input, LDS-DMA halo, ping-pong wave groups)": (["conv3x3_planes"], PEAK_F16_MFMA_TFLOPS / 3.0),
                 "conv3x3_f16x3_row_kernel": (["conv3x3_f16x3"], PEAK_F16_MFMA_TFLOPS / 3.0),
+                "stem_kernel (feat_extracts.0.0 -> 0.1 -> 1.0 in one launch, the full-resolution maps in LDS)": (["stem_fused"], PEAK_F16_MFMA_TFLOPS / 3.0),
                 "gemm_f16x3_kernel (fp32-input rows: strided conv2d)": (["linear_f16x3", "deconv2x2_f16x3", "conv2d_f16x3"], PEAK_F16_MFMA_TFLOPS / 3.0),
                 "gemm_pp_kernel (nn.Linear / ConvTranspose2d / strided Conv2d rows from split planes: LDS-DMA, ping-pong wave groups, persistent)": (["linear_split", "deconv2x2_split", "conv2d_split"], PEAK_F16_MFMA_TFLOPS / 3.0),
                 "gemm_mfma_f32 (exact-fp32 engine)": (["conv2d", "linear", "deconv2x2"], PEAK_F32_MFMA_TFLOPS),

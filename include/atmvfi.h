@@ -341,6 +341,19 @@ int atmvfi_frame_f32_to_u8(const float* src, int Hp, int Wp, int pad_top, int pa
 /* mean |a - b| per sample: global_alignmentness (network_base.py:560-561).  out[B] must be zeroed by the caller. */
 int atmvfi_l1_mean(const float* a, const float* b, float* out, int B, int64_t per_sample, void* stream);
 
+/* The encoder's full-resolution stem in one launch: feat_extracts.0.0 (3 -> C0, 3x3 + PReLU), feat_extracts.0.1 (C0 -> C0, 3x3 + PReLU) and
+ * feat_extracts.1.0 (C0 -> C1, 3x3 stride 2 + PReLU) of shared_feat_extraction (network_base.py:99-110, 342-352), (C0, C1) = (24, 48) or
+ * (16, 32).  x: the NHWC4-packed frames [F, H, W, 4] (atmvfi_pack_frames), H and W even.  The two full-resolution C0-channel maps never
+ * leave the chip (LDS); the result is written as split planes (chunk-major, out_plane_rows >= F * H/2 * W/2 rows per 32-channel chunk),
+ * rows = pixels (f, y, x) of the half-resolution map.  All three layers use the f16x3 split (x = hi + lo'/1024, three 16-bit MFMAs per
+ * product, fp32 accumulation).  Weights as the host packs them (atm-vfi_amd/hip_ops.py::HipOps.pack_stem), fp16 hi / lo' planes:
+ *   w1 [round_up(C0, 16)][32], k = (ky * 3 + kx) * 3 + ci (27 values, then zeros);  w2 [NS][round_up(C0, 16)][32] and w3 [NS][C1][32],
+ *   NS = ceil(9 C0 / 32) k-steps of 32 k-values, k = (ky * 3 + kx) * C0 + c, zero beyond 9 C0 and in padded rows;
+ *   b1 / p1 and b2 / p2 [round_up(C0, 16)] (bias 0, slope 1 in the padding), b3 / p3 [C1]: bias and PReLU slope of each layer. */
+int atmvfi_stem_fused(const float* x, int F, int H, int W, int C0, int C1, const void* w1_hi, const void* w1_lo, const float* b1, const float* p1,
+                      const void* w2_hi, const void* w2_lo, const float* b2, const float* p2, const void* w3_hi, const void* w3_lo,
+                      const float* b3, const float* p3, void* out_hi, void* out_lo, int64_t out_plane_rows, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Launch plans: one forward of the hot path as ONE call.
  *

@@ -36,3 +36,10 @@ def weights(schema):
             cache[variant] = schema.synthetic_state_dict(variant, seed=1)
         return cache[variant]
     return get
+
+
+def pytest_sessionstart(session):
+    # diagnostic: ATMVFI_ABORT_BT=1 chains a native-backtrace SIGABRT handler (tools/probes/abort_bt.c) behind pytest's faulthandler
+    if os.environ.get("ATMVFI_ABORT_BT") == "1":
+        import ctypes
+        ctypes.CDLL(os.path.join(ROOT, "tools", "probes", "abort_bt.so"))

@@ -1098,3 +1098,39 @@ def test_atmformer_module_reference_fixture(shift, dev):
     rb = RefineBottleneck(dim=64, window_size=8, shift_size=4, mlp_ratio=2.0).to(dev).eval()
     out = rb(torch.randn(2, 16, 24, 64, device=dev))
     assert tuple(out.shape) == (2, 16 * 24, 64) and torch.isfinite(out).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(24, 48, 2, 64, 96), (24, 48, 1, 36, 52), (16, 32, 2, 40, 72), (24, 48, 1, 16, 32), (16, 32, 1, 2, 2),
+                                  (24, 48, 3, 70, 34)], ids=lambda c: f"c{c[0]}_{c[1]}_f{c[2]}_{c[3]}x{c[4]}")
+def test_stem_fused(case, dev):
+    """atmvfi_stem_fused (feat_extracts.0.0 -> 0.1 -> 1.0, network_base.py:99-110, in one launch, the two full-resolution maps in LDS)
+    against the three layers in torch fp32: whole tiles, ragged tiles (sizes that are no multiples of the 16 x 32 full-resolution
+    tile), a map smaller than one tile, both variants' channel counts, several frames.  Image borders are where the zero padding of
+    EVERY layer has to be right (a layer-1 value outside the image is 0, not conv(0) + bias)."""
+    c0, c1, f, h, w = case
+    g = torch.Generator().manual_seed(100 * c0 + h + w)
+    x = torch.zeros(f, h, w, 4)
+    x[..., :3] = torch.rand(f, h, w, 3, generator=g)
+    ws = [rnd(g, c0, 3, 3, 3, scale=0.6), rnd(g, c0, c0, 3, 3, scale=0.25), rnd(g, c1, c0, 3, 3, scale=0.25)]
+    bs = [rnd(g, c, scale=0.3) for c in (c0, c0, c1)]
+    ps = [0.25 + rnd(g, c, scale=0.2) for c in (c0, c0, c1)]
+    t = x[..., :3].permute(0, 3, 1, 2).double()
+    for wt, b, p, st in zip(ws, bs, ps, (1, 1, 2)):
+        t = torch.nn.functional.prelu(torch.nn.functional.conv2d(t, wt.double(), b.double(), stride=st, padding=1), p.double())
+    want = t.permute(0, 2, 3, 1).reshape(-1, c1).float()
+    hip = hip_ops.HipOps(dev)
+    args = []
+    for wt, b, p in zip(ws, bs, ps):
+        args += [wt.to(dev), b.to(dev), p.to(dev)]
+    pk = hip.pack_stem(*args)
+    out = hip_ops.Planes.alloc(f * (h // 2) * (w // 2), c1, dev)
+    hip.stem_fused(x.to(dev), pk, out)
+    torch.cuda.synchronize()
+    got = out.to_float().cpu()
+    err = (got - want).abs().max().item()
+    assert err <= 3e-5 * max(1.0, want.abs().max().item()), f"max|d| {err:.3e} (|ref| max {want.abs().max().item():.2f})"
+    # the planes' pad channels and spare row stay zero
+    assert out.t[:, :, out.rows:].abs().max().item() == 0
+    if c1 % 32:
+        assert out.t[:, -1, :, c1 % 32:].abs().max().item() == 0

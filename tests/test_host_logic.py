@@ -427,3 +427,10 @@ def test_launch_plan_recorder_on_the_host():
         plan.add_op(Fn("atmvfi_linear"), (ctypes.byref(hip_ops.GemmParams(out=0x9000 + 8)), None))
     with pytest.raises(hip_ops.PlanUnsupported):
         plan.add_op(Fn("atmvfi_version"), (None,))
+    # a pointer that does not point INTO its tensor (the compact view of the 3x3 plane kernel: buffer - 4 * out_cmin) is classified by
+    # the tensor it belongs to, not by the allocation its raw value happens to fall into
+    n0 = len(plan.patches)
+    plan.add_op(Fn("atmvfi_pack_frames"), (ctypes.c_void_p(0x9000 + 32), None, None, 1, 4, 4, None), {0: 0x50000})      # raw value inside the output slot, tensor static
+    assert len(plan.patches) == n0
+    plan.add_op(Fn("atmvfi_pack_frames"), (ctypes.c_void_p(0x9000 - 224), None, None, 1, 4, 4, None), {0: 0x9000})       # tensor IS the output slot, pointer in front of it
+    assert plan.patches[-1] == (len(plan.ops_list) - 1, 0, 2, -224)
