@@ -139,8 +139,34 @@ def check_pp(asm_text):
     return problems
 
 
+def check_no_slp_pairs(asm_text, what):
+    """No packed fp32 instruction with a LOW-half operand select (v_pk_*_f32 ... op_sel:[..]): the library's own f32x2 code only ever
+    broadcasts through op_sel_hi; op_sel:[..] on fp32 pairs is the shape the SLP vectorizer builds when it pairs (x, y) chains, and
+    the one build that had it was wrong on the hardware (csrc/Makefile).  The library is compiled with -fno-slp-vectorize."""
+    bad = [l.strip() for l in asm_text.splitlines() if re.search(r"\bv_pk_(add|mul|fma)_f32\b.*\bop_sel:\[", l)]
+    return [f"{what}: {len(bad)} packed fp32 instruction(s) with a low-half operand select, e.g. '{bad[0]}'"] if bad else []
+
+
+def makefile_flags():
+    """The compiler flags the library is built with (csrc/Makefile CXXFLAGS), so that this guard looks at the code that ships."""
+    for line in open(os.path.join(CSRC, "Makefile")):
+        if line.startswith("CXXFLAGS"):
+            fl = line.split("=", 1)[1].split()
+            return [f for f in fl if f.startswith("-f") and f != "-fPIC"]
+    raise SystemExit("check_isa: CXXFLAGS not found in csrc/Makefile")
+
+
+def file_flags(src):
+    """Per-file additions (FLAGS_<file> in the Makefile)."""
+    stem = os.path.splitext(src)[0]
+    for line in open(os.path.join(CSRC, "Makefile")):
+        if line.startswith(f"FLAGS_{stem} "):
+            return line.split("=", 1)[1].split()
+    return []
+
+
 def compile_asm(src, out):
-    cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", f"-I{ROOT}/include",
+    cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", *makefile_flags(), *file_flags(src), f"-I{ROOT}/include",
            "-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", out]
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return open(out).read()
@@ -149,8 +175,18 @@ def compile_asm(src, out):
 def main():
     with tempfile.TemporaryDirectory() as td:
         problems = check(compile_asm("conv3x3_f16x3_row.hip", os.path.join(td, "row.s")))
-        problems += check_planes(compile_asm("conv3x3_planes.hip", os.path.join(td, "planes.s")))
-        problems += check_pp(compile_asm("gemm_pp.hip", os.path.join(td, "pp.s")))
+        planes = compile_asm("conv3x3_planes.hip", os.path.join(td, "planes.s"))
+        problems += check_planes(planes)
+        problems += check_no_slp_pairs(planes, "conv3x3_planes.hip")
+        pp = compile_asm("gemm_pp.hip", os.path.join(td, "pp.s"))
+        problems += check_pp(pp)
+        if "-fno-slp-vectorize" not in makefile_flags():
+            problems.append("csrc/Makefile: CXXFLAGS lost -fno-slp-vectorize")
+        for name, text in (("gemm_pp.hip", pp), ("attention.hip", compile_asm("attention.hip", os.path.join(td, "attn.s"))),
+                           ("stem.hip", compile_asm("stem.hip", os.path.join(td, "stem.s")))):
+            problems += check_no_slp_pairs(text, name)
+            if name == "stem.hip" and re.search(r"scratch_(load|store)", text):
+                problems.append("stem.hip: register spill (a scratch reload is a vector-memory operation: its wait covers the next tile's patch loads)")
     for p in problems:
         print("ISA check:", p)
     print("ISA check: ok" if not problems else f"ISA check: {len(problems)} problem(s)")
