@@ -342,16 +342,24 @@ def main():
             # (sha256 over atm-vfi_amd/csrc, stamped into the file); otherwise `traffic` stays null rather than going stale.
             try:
                 if key == ("base", 1088, 1920, True):
-                    pmc_file = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")
-                    pmc_all = json.load(open(pmc_file))
-                    fresh = pmc_all.get("csrc_sha256") == csrc_digest()
-                    pmc = pmc_all["per_forward"]
+                    import glob
+                    digest = csrc_digest()
+                    pmc_all, pmc_file = None, None
+                    for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic*.json")), reverse=True):
+                        try:
+                            j = json.load(open(cand))
+                        except Exception:
+                            continue
+                        if j.get("csrc_sha256") == digest:
+                            pmc_all, pmc_file = j, os.path.basename(cand)
+                            break
                     for fam in fam_out:
                         kn = fam.split(" ")[0]
-                        if kn in pmc:
-                            fam_out[fam]["traffic"] = round(pmc[kn]["traffic_GB_per_launch"] * 1e9) if fresh else None
-                            fam_out[fam]["traffic_unit"] = ("bytes/launch (PMC, profiles/r02_pmc_hbm_traffic.json, same kernel sources)" if fresh else
-                                                            "null: the committed PMC passes were taken on other kernel sources")
+                        if pmc_all is not None and kn in pmc_all["per_forward"]:
+                            fam_out[fam]["traffic"] = round(pmc_all["per_forward"][kn]["traffic_GB_per_launch"] * 1e9)
+                            fam_out[fam]["traffic_unit"] = f"bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/{pmc_file}, taken on this build: same source digest)"
+                        else:
+                            fam_out[fam]["traffic_unit"] = "null: no committed PMC pass was taken on this build (source digest differs)"
             except Exception:
                 pass
             if fam_out:

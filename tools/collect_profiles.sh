@@ -1,7 +1,7 @@
 # One gpurun call = one evidence set (same box): bench line, rocprofv3 kernel stats, HBM traffic (two PMC passes).
 #   bash tools/collect_profiles.sh <tag>        -> gpurun_out/<tag>_{bench.json,kernel_stats.csv,pmc_hbm_traffic.json}
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench_err.txt
