@@ -412,6 +412,16 @@ class Network(BlockRunner, nn.Module):
             P["pk:proj.0.weight:planes"] = ops.pack_weight(GEMM_CONV, wpp.contiguous())
         if hasattr(ops, "pack_stem") and getattr(ops, "split_planes_ok", False):
             P["stem"] = ops.pack_stem(*(sd[f"feat_extracts.{a}.{b}"].detach() for a in ("0.0", "0.1", "1.0") for b in ("0.weight", "0.bias", "1.weight")))
+        # f16x3 contraction operands saturate at +-65504 (deviation 2).  Weights are known here: say so once per
+        # parameter version if a checkpoint comes near; for activations there is f16x3_deviation() below.
+        if isinstance(ops, HipOps):
+            wmax = float(torch.stack([sd[sp.key].detach().abs().max() for sp in S.param_schema(self._v)
+                                      if not sp.is_buffer and sp.key.endswith(".weight") and len(sp.shape) >= 2]).max())
+            self.weight_abs_max = wmax
+            if wmax > 16384.0:
+                import warnings
+                warnings.warn(f"atm-vfi_amd: largest |weight| of this checkpoint is {wmax:.0f}; the f16x3 engines saturate operands at "
+                              "65504 -- check Network.f16x3_deviation(im0, im1) or use set_precision('f32')")
         for st in (1, 2):     # leading PReLU of decoder stages 1-2, applied on the deconv's input load
             P[f"inprelu:{st}"] = ops.pad_channels(sd[f"upsample_pyramid.{st}.0.weight"])
         self._prepared = P
@@ -707,6 +717,20 @@ class Network(BlockRunner, nn.Module):
         meets in the ATMFormers.  Not with the ensemble (three input scales).  Not part of the reference's API; off by default."""
         self._frame_cache_on = bool(flag)
         self._frame_cache = None
+
+    def f16x3_deviation(self, im0: torch.Tensor, im1: torch.Tensor) -> float:
+        """max |I_t(f16x3) - I_t(exact fp32 engine)| on this frame pair: the run-time check that a checkpoint's activations stay inside
+        the fp16 range of the split engines (an operand beyond 65504 saturates silently there; on the stress weights the largest
+        |activation| is 24).  Costs one forward on each engine; expect ~1e-4, investigate above 1e-3."""
+        keep = self._precision
+        try:
+            self.set_precision("f32")
+            ref = self.forward(im0, im1)["I_t"].clone()
+            self.set_precision("f16x3")
+            got = self.forward(im0, im1)["I_t"]
+            return float((got - ref).abs().max())
+        finally:
+            self.set_precision(keep)
 
     def enable_plans(self, flag: bool = True):
         """Launch plans (default on): once a (shape, mode, weights) combination has run twice, its forward is recorded

@@ -384,6 +384,21 @@ def test_model_moved_to_other_device_drops_device_state(dev, weights):
     assert torch.equal(net(a.to(dev), b.to(dev))["I_t"], o1)
 
 
+def test_f16x3_deviation_and_weight_range_warning(dev, weights):
+    """Network.f16x3_deviation: the split engines against the exact-fp32 engine on one pair (the run-time range check of DESIGN.md
+    section 1, deviation 2); and a checkpoint whose weights come near the fp16 range is announced when its weights are packed."""
+    net = pkg.NetworkLite()
+    net.load_state_dict(weights("lite"), strict=True)
+    net.to(dev).eval()
+    a, b = [t.to(dev) for t in pairs.smooth_pair(1, 128, 192, seed=99)]
+    d = net.f16x3_deviation(a, b)
+    assert 0.0 <= d <= 2e-4 and net._precision == "f16x3" and net.weight_abs_max < 100.0
+    with torch.no_grad():
+        net.refine_head._modules["1"]._modules["0"].weight[0, 0, 0, 0] = 4.0e4
+    with pytest.warns(UserWarning, match="saturate"):
+        net(a, b)
+
+
 def _flat(out):
     return [out[k] for k in ("I_t", "opt_flow_0", "opt_flow_1", "I_t_0", "I_t_1", "occ_mask1", "occ_mask2")] + list(out["im_t_list"]) + \
         list(out["im0_warped_list"]) + list(out["im1_warped_list"])
