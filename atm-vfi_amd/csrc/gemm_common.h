@@ -271,5 +271,7 @@ bool try_launch_conv3x3_small(const GemmDev& d, int kh, int* rc, hipStream_t str
 int launch_gemm_split(const GemmDev& d, int ngemm, hipStream_t stream);
 // gemm_pp.hip (the same for LINEAR / DECONV rows, ping-pong wave groups)
 int launch_gemm_pp(const GemmDev& d, int ngemm, hipStream_t stream);
+// gemm_duo.hip (the same contract on 128 x 128 tiles, two workgroups per CU)
+int launch_gemm_duo(const GemmDev& d, int ngemm, hipStream_t stream);
 
 }  // namespace atmvfi

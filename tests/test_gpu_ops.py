@@ -997,13 +997,16 @@ PP_CASES = [
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("engine", [-3, -2, 0], ids=["pp", "duo", "auto"])
 @pytest.mark.parametrize("case", PP_CASES, ids=lambda c: f"{c[0]}_{c[2]}to{c[3]}")
-def test_gemm_pp_matches_reference_schedule(case, dev):
-    """gemm_pp.hip (ping-pong wave groups, persistent grid with the DMA ring flowing across tiles, LDS-transposed epilogue) against
-    the reference schedule gemm_split.hip (atmvfi_gemm_params.tile_wn = -1): same arithmetic, so bit-identical outputs, on shapes
-    with several tiles per workgroup (the op tests above fit one round of 256 workgroups)."""
+def test_gemm_pp_matches_reference_schedule(case, engine, dev):
+    """gemm_pp.hip (ping-pong wave groups, persistent grid with the DMA ring flowing across tiles, LDS-transposed epilogue) and
+    gemm_duo.hip (128 x 128 tiles, two workgroups per CU; atmvfi_gemm_params.tile_wn = -2) against the reference schedule
+    gemm_split.hip (tile_wn = -1): same arithmetic, so bit-identical outputs, on shapes with several tiles per workgroup (the op tests
+    above fit one round of 256 workgroups)."""
     kind, geom, cin, cout, ex = case
     hp, hr = hip_ops.HipOps(dev), hip_ops.HipOps(dev)
+    hp.gemm_tile_wn = engine
     hr.gemm_tile_wn = -1
     g = torch.Generator().manual_seed(cin * 1000 + cout)
     outs = []

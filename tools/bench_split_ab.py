@@ -10,7 +10,10 @@ hip_ops = importlib.import_module("atm-vfi_amd.hip_ops")
 dev = torch.device("cuda:0")
 opsB = hip_ops.HipOps(dev)
 opsA = hip_ops.HipOps(dev)
-if len(sys.argv) > 1:
+if len(sys.argv) > 1 and sys.argv[1] == "duo":
+    opsA.gemm_tile_wn = -3          # A = gemm_pp.hip, B = gemm_duo.hip (128 x 128 tiles, two workgroups per CU) of the same library
+    opsB.gemm_tile_wn = -2
+elif len(sys.argv) > 1:
     opsA.lib = hip_ops.load_library(os.path.join(ROOT, sys.argv[1]))
 else:
     opsA.gemm_tile_wn = -1          # A = the reference schedule (gemm_split.hip) of the same library
@@ -69,7 +72,8 @@ for (bn, h, w_, cin, cout) in [(1, 136, 240, 773, 389), (1, 272, 480, 389, 197),
            lambda: opsB.deconv(None, pw, None, bias=b, prelu=pr, planes=pl, sink=sb, in_shape=(bn, h, w_, cin)), [sa.t], [sb.t])
 
 # ---- strided 3x3 convs from planes into a plane sink (encoder / fusion; network_base.py:20-25, 73-85)
-for (bn, h, w_, cin, cout, stride) in [(2, 544, 960, 48, 96, 2), (2, 272, 480, 96, 192, 2), (2, 136, 240, 192, 384, 2), (2, 272, 480, 96, 96, 4)]:
+for (bn, h, w_, cin, cout, stride) in [(2, 544, 960, 48, 96, 2), (2, 272, 480, 96, 192, 2), (2, 136, 240, 192, 384, 2), (2, 272, 480, 96, 96, 4),
+                                       (1, 1088, 1920, 64, 64, 2), (1, 544, 960, 256, 128, 2), (1, 272, 480, 512, 256, 2)]:
     x = (torch.rand(bn * h * w_, cin, generator=g) * 2 - 1).to(dev)
     wt = ((torch.rand(cout, cin, 3, 3, generator=g) * 2 - 1) / (9 * cin) ** 0.5).to(dev)
     b = (torch.rand(cout, generator=g) - 0.5).to(dev)
