@@ -27,6 +27,15 @@ __device__ __forceinline__ void dma16(const unsigned char* src, unsigned char* l
 __device__ __forceinline__ void lds_write16f(unsigned addr, const f32x4& v) {
     asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
+#ifdef ATMVFI_STAMP
+// Diagnostic build only (`make stamp`, tools/stamp_duo.py): shader-clock sums per phase of the k-loop, per wave
+static unsigned long long* g_duo_stamp = nullptr;
+extern "C" void atmvfi_debug_set_duo_stamp_buffer(void* p) { g_duo_stamp = (unsigned long long*)p; }
+#define DUO_SUB(k) do { if (a.stamp) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); sub[k] += t_ - sub_t; sub_t = t_; __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define DUO_SUB(k) do { } while (0)
+#endif
+
 template <int OFF>
 __device__ __forceinline__ void lds_read16f(f32x4& d, unsigned addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
@@ -151,8 +160,13 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(const GemmDev a) {
             cor[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     const int nk = a.nchunks32;
+#ifdef ATMVFI_STAMP
+    unsigned long long sub[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sub_t = 0, t_begin = 0;
+    if (a.stamp) { t_begin = sub_t = __builtin_amdgcn_s_memtime(); }
+#endif
     issue_stage(0);
     if (nk > 1) issue_stage(1);
+    DUO_SUB(0);
     f16x8 xh[4], xl[4], wh[4], wl[4];
     const unsigned xfrag = lds_offset(smem) + (unsigned)((64 * wm + r) * 64 + ((g ^ swz64(r)) << 4));
     const unsigned wfrag = lds_offset(smem) + (unsigned)(W_HI + (64 * wn + r) * 64 + ((g ^ swz64(r)) << 4));
@@ -161,6 +175,7 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(const GemmDev a) {
         if (u + 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        DUO_SUB(1);
         const unsigned off = (unsigned)((u & 1) * STAGE);
         static_for<0, 4>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
@@ -176,8 +191,11 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(const GemmDev a) {
                      : "+v"(xh[0]), "+v"(xh[1]), "+v"(xh[2]), "+v"(xh[3]), "+v"(xl[0]), "+v"(xl[1]), "+v"(xl[2]), "+v"(xl[3]));
 #pragma unroll
         for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(wh[j]), "+v"(wl[j]));
+        DUO_SUB(2);
         __builtin_amdgcn_s_barrier();                   // every wave has its fragments: the buffer may be refilled
+        DUO_SUB(3);
         if (u + 2 < nk) issue_stage(u & 1);
+        DUO_SUB(4);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -191,6 +209,7 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(const GemmDev a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) cor[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xl[i], cor[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
+        DUO_SUB(5);
     }
     {
         __builtin_amdgcn_s_barrier();                       // every wave is past its last fragment read (the transposition reuses stage 0)
@@ -522,6 +541,14 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(const GemmDev a) {
             store_rows(std::false_type{});
         }
     }
+#ifdef ATMVFI_STAMP
+    DUO_SUB(6);
+    if (a.stamp && lane == 0) {
+        unsigned long long* o = a.stamp + ((long long)blockIdx.x * 4 + wave) * 8;
+        for (int k = 0; k < 7; ++k) o[k] = sub[k];
+        o[7] = sub_t - t_begin;
+    }
+#endif
 }
 
 }  // namespace
@@ -540,6 +567,9 @@ static int launch_duo(const GemmDev& d, int ngemm, hipStream_t s) {
     dd.pfit32 = d.out_hi && (long long)d.out_plane_rows * 64 < (1ll << 32);
     dd.fit32 = d.out && !d.out_row_map && d.out_rpg == 0 && d.mode != ATMVFI_GEMM_DECONV && (d.M + 1) * (long long)d.out_ld * 4 < (1ll << 32) &&
                (!d.residual || (d.M + 1) * (long long)d.res_ld * 4 < (1ll << 32));
+#ifdef ATMVFI_STAMP
+    dd.stamp = g_duo_stamp;
+#endif
     dd.nblocks = (ngemm + BN - 1) / BN;
     const long long mgroups = (atmvfi::ceil_div64(d.M, BM) + 7) / 8;
     ATMVFI_REQUIRE(mgroups * 8 * dd.nblocks < (1LL << 31), ATMVFI_EINVAL, "gemm_duo: grid too large");
