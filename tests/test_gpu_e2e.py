@@ -243,6 +243,58 @@ def test_exact_fp32_engine_end_to_end(dev, weights):
     assert (out["I_t"] - out2["I_t"]).abs().max().item() <= 2e-4
 
 
+@pytest.mark.parametrize("variant,name", [("base", "base_128x192_g"), ("lite", "lite_128x192_g_b2")])
+def test_fallback_kernel_selections_end_to_end(variant, name, dev, weights):
+    """The forward's kernel selections other than the default one, each against the reference's outputs: (1) what a batch beyond
+    2^26 plane rows takes (`Network._rows_fit_planes` False: 3x3 convs and deconvs on the fp32-input kernels -- batch 4 at 4K), (2) every
+    split-plane switch off (the round-1 forward: fp32 maps between all layers), (3) the three stem layers as separate launches,
+    (4) launch plans off.  All within the parity budget of the golden fixture and within 2e-4 of the default selection."""
+    cases = [c for c in G.e2e_cases() if c["name"] == name]
+    if not cases:
+        pytest.skip(f"no fixture {name}")
+    case = cases[0]
+    gold = G.load_npz(case["name"])
+    im0, im1 = G.case_inputs(case)
+    net = (pkg.NetworkBase if variant == "base" else pkg.NetworkLite)()
+    net.load_state_dict(weights(variant), strict=True)
+    net.to(dev).eval()
+    net.global_motion = case["global"]
+    ref = net(im0.to(dev), im1.to(dev))["I_t"].clone()
+    G.compare_e2e(net(im0.to(dev), im1.to(dev)), gold, case["step"], TOL, TOL_FLOW)
+
+    def check(tag):
+        out = net(im0.to(dev), im1.to(dev))
+        torch.cuda.synchronize()
+        errs = G.compare_e2e(out, gold, case["step"], TOL, TOL_FLOW)
+        d = (out["I_t"] - ref).abs().max().item()
+        print(variant, tag, {k: f"{v:.1e}" for k, v in errs.items()}, f"vs default {d:.1e}")
+        assert d <= 2e-4, (tag, d)
+
+    # (1) the selection of a batch whose plane rows do not fit 32-bit byte offsets: the flag is recomputed by every forward, so the
+    # test pins it through the property the forward reads
+    cls = type(net)
+    orig = cls._plane_convs
+    try:
+        cls._plane_convs = lambda self, ops: False
+        net._plans.clear(); net._graphs.clear()
+        check("rows beyond 2^26 (fp32-input 3x3 kernels)")
+    finally:
+        cls._plane_convs = orig
+    # (2) every plane switch off
+    saved = (net.use_plane_convs, net.use_plane_deconvs, net.use_unet_planes, net.use_split_planes)
+    net.use_plane_convs = net.use_plane_deconvs = net.use_unet_planes = net.use_split_planes = False
+    check("all split-plane paths off")
+    net.use_plane_convs, net.use_plane_deconvs, net.use_unet_planes, net.use_split_planes = saved
+    # (3) separate stem launches, (4) no plans
+    net.use_fused_stem = False
+    check("stem as three launches")
+    net.use_fused_stem = True
+    net.enable_plans(False)
+    check("launch plans off")
+    net.enable_plans(True)
+    check("default again")
+
+
 def test_graph_replay_equals_eager(dev, weights):
     """Network.enable_graphs(): the captured HIP graph must reproduce the eager forward bit for bit, follow new inputs,
     new shapes and a changed parameter (the graph is re-captured when the packed weights are refreshed)."""
