@@ -291,7 +291,12 @@ def main():
                                    f"global {'on' if net.global_motion else 'off'}, fp32, random frame pairs, stress weights seed 1",
                        "pairs_per_step": world, "parallelism": f"frame-batch dp{world} + all-gather of the {'uint8' if args.gather_u8 else 'fp32'} output frames, one step behind the forward (sharding.PipelinedGather)" if collective else "single GPU"},
         }
-        result["launch"] = "eager (one hipLaunchKernel per op)" if not args.graph else "HIP graph replay (captured forward, inputs copied into its static buffers inside the timed region)"
+        if args.graph:
+            result["launch"] = "HIP graph replay (captured forward, inputs copied into its static buffers inside the timed region)"
+        elif getattr(net, "use_plans", False) and getattr(net, "_plans", None):
+            result["launch"] = "launch plan (the recorded forward replayed by one atmvfi_plan_run call per step: the same ~120 kernel launches, fresh output tensors)"
+        else:
+            result["launch"] = "eager (one C-ABI call per op)"
         if flops:
             result["forward_tflops"] = round(flops * fps / world / 1e12, 2)     # per-GPU algorithmic rate of the whole forward
             result["forward_frac_of_f32_mfma_peak"] = round(flops * fps / world / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
@@ -321,7 +326,7 @@ def main():
                 "conv3x3_f16x3_row_kernel": (["conv3x3_f16x3"], PEAK_F16_MFMA_TFLOPS / 3.0),
                 "stem_kernel (feat_extracts.0.0 -> 0.1 -> 1.0 in one launch, the full-resolution maps in LDS)": (["stem_fused"], PEAK_F16_MFMA_TFLOPS / 3.0),
                 "gemm_f16x3_kernel (fp32-input rows: strided conv2d)": (["linear_f16x3", "deconv2x2_f16x3", "conv2d_f16x3"], PEAK_F16_MFMA_TFLOPS / 3.0),
-                "gemm_pp_kernel (nn.Linear / ConvTranspose2d / strided Conv2d rows from split planes: LDS-DMA, ping-pong wave groups, persistent)": (["linear_split", "deconv2x2_split", "conv2d_split"], PEAK_F16_MFMA_TFLOPS / 3.0),
+                "gemm_pp_kernel + gemm_duo_kernel (nn.Linear / ConvTranspose2d / strided Conv2d rows from split planes by LDS-DMA: 256x128 tiles, ping-pong wave groups, persistent grid; 128x128 tiles, two workgroups per CU, where that grid would be under-filled)": (["linear_split", "deconv2x2_split", "conv2d_split"], PEAK_F16_MFMA_TFLOPS / 3.0),
                 "gemm_mfma_f32 (exact-fp32 engine)": (["conv2d", "linear", "deconv2x2"], PEAK_F32_MFMA_TFLOPS),
             }
             fam_out = {}
@@ -354,9 +359,12 @@ def main():
                             pmc_all, pmc_file = j, os.path.basename(cand)
                             break
                     for fam in fam_out:
-                        kn = fam.split(" ")[0]
-                        if pmc_all is not None and kn in pmc_all["per_forward"]:
-                            fam_out[fam]["traffic"] = round(pmc_all["per_forward"][kn]["traffic_GB_per_launch"] * 1e9)
+                        # the family's kernels as rocprofv3 names them: the words ending in "_kernel" in front of the parenthesis
+                        kns = [w for w in fam.split(" (")[0].split(" ") if w.endswith("_kernel")]
+                        rows = [pmc_all["per_forward"][k] for k in kns if pmc_all is not None and k in pmc_all["per_forward"]]
+                        if rows:
+                            fam_out[fam]["traffic"] = round(sum(r["traffic_GB_per_launch"] * r["launches"] for r in rows) /
+                                                            sum(r["launches"] for r in rows) * 1e9)
                             fam_out[fam]["traffic_unit"] = f"bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/{pmc_file}, taken on this build: same source digest)"
                         else:
                             fam_out[fam]["traffic_unit"] = "null: no committed PMC pass was taken on this build (source digest differs)"
