@@ -433,6 +433,205 @@ __global__ __launch_bounds__(256) void warp_blend_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------
+// The same warps with LDS-STAGED SOURCE TILES (the north star's form of flow_warp.py:50-60): a workgroup owns a 32 x 8 tile of output
+// pixels; it reduces the bounding box of its lanes' bilinear taps (cross-lane minima, one LDS atomic per wave), loads that box of every source plane with
+// 16-byte row loads into LDS (up to 64 x 24 source pixels: flows of about +-15 px horizontally, +-8 vertically around the tile) and
+// takes the four taps of every pixel from LDS -- ~5 coalesced dwordx4 loads per lane and source instead of 12 gathered dwords.  A tile
+// whose flows reach further than the box gathers from global memory as the direct kernels do (a workgroup-uniform decision, per
+// source).  Taps, weights and the order of the four multiply-adds are those of sample_plane: results are bit-identical to the direct
+// kernels (tests/test_gpu_ops.py::test_tiled_warps_equal_direct_warps).  Needs W % 4 == 0 and 16-byte aligned planes.
+// ---------------------------------------------------------------------------------------
+constexpr int WT_W = 32, WT_H = 8;            // output tile of a workgroup (256 lanes)
+constexpr int WB_W = 64, WB_H = 24;           // staged box per source plane, pixels
+constexpr int WB_PLANE = WB_W * WB_H;
+
+struct StagedBox {
+    int ax0, y0, nv, h;      // columns ax0 .. ax0 + 4 nv - 1 (ax0 a multiple of 4), rows y0 .. y0 + h - 1
+    bool ok;                 // it fits the LDS box (an empty box -- no live tap in the tile -- counts as staged)
+};
+
+__device__ __forceinline__ void box_reset(int* bx) {       // {x lo, x hi, y lo, y hi}
+    bx[0] = 0x7fffffff; bx[1] = -0x7fffffff; bx[2] = 0x7fffffff; bx[3] = -0x7fffffff;
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+    for (int o = 32; o; o >>= 1) { const int u = __shfl_xor(v, o); v = u < v ? u : v; }
+    return v;
+}
+__device__ __forceinline__ void box_add(int* bx, const Taps& t, bool live, int W, int H) {
+    // the wave's extremes by cross-lane exchange, then one LDS atomic per wave and bound (64 lanes on one LDS word serialise)
+    const bool any = live && (t.in00 || t.in01 || t.in10 || t.in11);      // some tap inside the image: x0 in [-1, W-1], y0 in [-1, H-1]
+    const int xlo = any ? (t.x0 < 0 ? 0 : t.x0) : 0x7fffffff;
+    const int xhi = any ? (t.x0 + 1 > W - 1 ? W - 1 : t.x0 + 1) : -0x7fffffff;
+    const int ylo = any ? (t.y0 < 0 ? 0 : t.y0) : 0x7fffffff;
+    const int yhi = any ? (t.y0 + 1 > H - 1 ? H - 1 : t.y0 + 1) : -0x7fffffff;
+    const int a = wave_min_i32(xlo), b = -wave_min_i32(-xhi), c = wave_min_i32(ylo), d = -wave_min_i32(-yhi);
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&bx[0], a);
+        atomicMax(&bx[1], b);
+        atomicMin(&bx[2], c);
+        atomicMax(&bx[3], d);
+    }
+}
+__device__ __forceinline__ StagedBox box_get(const int* bx) {
+    StagedBox b;
+    if (bx[0] > bx[1]) { b.ax0 = 0; b.y0 = 0; b.nv = 0; b.h = 0; b.ok = true; return b; }
+    b.ax0 = bx[0] & ~3;
+    b.y0 = bx[2];
+    b.nv = ((bx[1] - b.ax0) >> 2) + 1;
+    b.h = bx[3] - bx[2] + 1;
+    b.ok = b.nv <= WB_W / 4 && b.h <= WB_H;
+    return b;
+}
+// nch planes (plane stride hw floats) of the box into tile[ch][row][WB_W]; all 256 lanes of the workgroup take part
+__device__ __forceinline__ void box_stage(float* tile, const float* __restrict__ src, long long hw, int W, int nch, const StagedBox& b, int tid) {
+    const int per = b.h * b.nv, total = nch * per;
+    for (int i = tid; i < total; i += 256) {
+        const int ch = i / per, rem = i - ch * per;
+        const int r = rem / b.nv, v = rem - r * b.nv;
+        const f32x4 q = *reinterpret_cast<const f32x4*>(src + ch * hw + (long long)(b.y0 + r) * W + b.ax0 + 4 * v);
+        *reinterpret_cast<f32x4*>(tile + ch * WB_PLANE + r * WB_W + 4 * v) = q;
+    }
+}
+__device__ __forceinline__ float sample_tile(const float* tile_plane, const Taps& t, const StagedBox& b) {
+    float v = 0.f;
+    const float* p = tile_plane + (t.y0 - b.y0) * WB_W + (t.x0 - b.ax0);
+    if (t.in00) v += p[0] * t.w00;
+    if (t.in01) v += p[1] * t.w01;
+    if (t.in10) v += p[WB_W] * t.w10;
+    if (t.in11) v += p[WB_W + 1] * t.w11;
+    return v;
+}
+// tile origin of this workgroup: blockIdx.x = (b * tiles_y + ty) * tiles_x + tx
+__device__ __forceinline__ void tile_pixel(int H, int W, int& b, int& x, int& y, bool& live) {
+    const int tiles_x = (W + WT_W - 1) / WT_W, tiles_y = (H + WT_H - 1) / WT_H;
+    const int t = blockIdx.x, tx = t % tiles_x, r = t / tiles_x;
+    b = r / tiles_y;
+    x = tx * WT_W + (threadIdx.x & (WT_W - 1));
+    y = (r - b * tiles_y) * WT_H + (threadIdx.x >> 5);
+    live = x < W && y < H;
+}
+
+__global__ __launch_bounds__(256) void flow_warp_tiled_kernel(const float* __restrict__ src, const float* __restrict__ flow,
+                                                              long long flow_bstride, int flow_pstride, int flow_cstride,
+                                                              float* __restrict__ dst, int B, int C, int H, int W) {
+    fp16_saturate_on();
+    __shared__ __attribute__((aligned(16))) float tile[3 * WB_PLANE];
+    __shared__ int bx[4];
+    const int tid = threadIdx.x;
+    const long long hw = (long long)H * W;
+    int b, x, y;
+    bool live;
+    tile_pixel(H, W, b, x, y, live);
+    const long long pix = (long long)(live ? y : 0) * W + (live ? x : 0);
+    if (tid == 0) box_reset(bx);
+    const float* fp = flow + b * flow_bstride + pix * flow_pstride;
+    const Taps t = make_taps((float)x + fp[0], (float)y + fp[flow_cstride], W, H);
+    __syncthreads();
+    box_add(bx, t, live, W, H);
+    __syncthreads();
+    const StagedBox sb = box_get(bx);
+    for (int c0 = 0; c0 < C; c0 += 3) {
+        const int nch = C - c0 < 3 ? C - c0 : 3;
+        const float* sp = src + ((long long)b * C + c0) * hw;
+        if (sb.ok) {
+            if (c0) __syncthreads();                         // the previous group's taps have been read
+            box_stage(tile, sp, hw, W, nch, sb, tid);
+            __syncthreads();
+        }
+        if (live)
+            for (int c = 0; c < nch; ++c)
+                dst[((long long)b * C + c0 + c) * hw + pix] = sb.ok ? sample_tile(tile + c * WB_PLANE, t, sb) : sample_plane(sp + c * hw, t, W);
+    }
+}
+
+__global__ __launch_bounds__(256) void warp_blend_tiled_kernel(const float* __restrict__ im0, const float* __restrict__ im1,
+                                                               const float* __restrict__ motion, int motion_ld, long long motion_bstride,
+                                                               float* __restrict__ i0w, float* __restrict__ i1w, float* __restrict__ it,
+                                                               float* __restrict__ f0o, float* __restrict__ f1o,
+                                                               float* __restrict__ m1o, float* __restrict__ m2o,
+                                                               const float* __restrict__ orig0, const float* __restrict__ orig1,
+                                                               float* __restrict__ pack15, int pack_ld, _Float16* __restrict__ pack_hi,
+                                                               _Float16* __restrict__ pack_lo, long long pack_rows, int pack_c0, int B, int H,
+                                                               int W) {
+    fp16_saturate_on();
+    __shared__ __attribute__((aligned(16))) float tile[2][3 * WB_PLANE];
+    __shared__ int bx[2][4];
+    const int tid = threadIdx.x;
+    const long long hw = (long long)H * W;
+    int b, x, y;
+    bool live;
+    tile_pixel(H, W, b, x, y, live);
+    const long long pix = (long long)(live ? y : 0) * W + (live ? x : 0);
+    if (tid < 2) box_reset(bx[tid]);
+    const float* mp = motion + b * motion_bstride + pix * motion_ld;
+    const float fx0 = mp[0], fy0 = mp[1], fx1 = mp[2], fy1 = mp[3];
+    const float m1 = sigmoidf_(mp[4]);
+    const float m2 = 1.0f - m1;
+    const Taps t0 = make_taps((float)x + fx0, (float)y + fy0, W, H);
+    const Taps t1 = make_taps((float)x + fx1, (float)y + fy1, W, H);
+    __syncthreads();
+    box_add(bx[0], t0, live, W, H);
+    box_add(bx[1], t1, live, W, H);
+    __syncthreads();
+    const StagedBox s0 = box_get(bx[0]), s1 = box_get(bx[1]);
+    if (s0.ok) box_stage(tile[0], im0 + (long long)b * 3 * hw, hw, W, 3, s0, tid);
+    if (s1.ok) box_stage(tile[1], im1 + (long long)b * 3 * hw, hw, W, 3, s1, tid);
+    __syncthreads();
+    if (!live) return;
+    float a[3], c[3], o[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        const long long pl = ((long long)b * 3 + ch) * hw;
+        a[ch] = s0.ok ? sample_tile(tile[0] + ch * WB_PLANE, t0, s0) : sample_plane(im0 + pl, t0, W);
+        c[ch] = s1.ok ? sample_tile(tile[1] + ch * WB_PLANE, t1, s1) : sample_plane(im1 + pl, t1, W);
+        o[ch] = m1 * a[ch] + m2 * c[ch];
+        i0w[pl + pix] = a[ch];
+        i1w[pl + pix] = c[ch];
+        it[pl + pix] = o[ch];
+    }
+    if (f0o) {
+        f0o[((long long)b * 2) * hw + pix] = fx0;
+        f0o[((long long)b * 2 + 1) * hw + pix] = fy0;
+        f1o[((long long)b * 2) * hw + pix] = fx1;
+        f1o[((long long)b * 2 + 1) * hw + pix] = fy1;
+    }
+    if (m1o) {
+        m1o[(long long)b * hw + pix] = m1;
+        m2o[(long long)b * hw + pix] = m2;
+    }
+    if (pack15) {
+        float* pp = pack15 + ((long long)b * hw + pix) * pack_ld;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const long long pl = ((long long)b * 3 + ch) * hw + pix;
+            pp[ch] = orig0[pl];
+            pp[3 + ch] = a[ch];
+            pp[6 + ch] = orig1[pl];
+            pp[9 + ch] = c[ch];
+            pp[12 + ch] = o[ch];
+        }
+    }
+    if (pack_hi) {
+        float v16[16];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const long long pl = ((long long)b * 3 + ch) * hw + pix;
+            v16[ch] = orig0[pl];
+            v16[3 + ch] = a[ch];
+            v16[6 + ch] = orig1[pl];
+            v16[9 + ch] = c[ch];
+            v16[12 + ch] = o[ch];
+        }
+        v16[15] = 0.f;
+        const RowSink sink{nullptr, 0, pack_hi, pack_lo, pack_rows};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            sink_store4(sink, (long long)b * hw + pix, pack_c0 + 4 * q, (f32x4){v16[4 * q], v16[4 * q + 1], v16[4 * q + 2], v16[4 * q + 3]});
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // align_corners=True bilinear resize (ATen upsample_bilinear2d arithmetic), planar
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void resize_ac_kernel(const float* __restrict__ src, long long sb, long long sc, long long sy,
@@ -676,6 +875,18 @@ extern "C" int atmvfi_flow_warp(const float* src, const float* flow, int64_t flo
     return atmvfi::check_launch("flow_warp");
 }
 
+extern "C" int atmvfi_flow_warp_tiled(const float* src, const float* flow, int64_t flow_bstride, int flow_pstride,
+                                       int flow_cstride, float* dst, int B, int C, int H, int W, void* stream) {
+    ATMVFI_REQUIRE(src && flow && dst, ATMVFI_EINVAL, "flow_warp_tiled: null pointer");
+    ATMVFI_REQUIRE(B > 0 && C > 0 && H > 1 && W > 1, ATMVFI_EINVAL, "flow_warp_tiled: bad shape (H, W must be > 1)");
+    ATMVFI_REQUIRE(W % 4 == 0 && atmvfi::aligned16(src), ATMVFI_EINVAL, "flow_warp_tiled: W must be a multiple of 4 and src 16-byte aligned (got W = %d)", W);
+    const long long tiles = (long long)B * ((H + WT_H - 1) / WT_H) * ((W + WT_W - 1) / WT_W);
+    ATMVFI_REQUIRE(tiles < (1ll << 31), ATMVFI_EINVAL, "flow_warp_tiled: grid too large");
+    hipLaunchKernelGGL(flow_warp_tiled_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, src, flow, (long long)flow_bstride,
+                       flow_pstride, flow_cstride, dst, B, C, H, W);
+    return atmvfi::check_launch("flow_warp_tiled");
+}
+
 extern "C" int atmvfi_flow_warp_up2(const float* src, const float* flow, float* dst, float* flow_up, int B, int C, int H, int W, void* stream) {
     ATMVFI_REQUIRE(src && flow && dst && flow_up, ATMVFI_EINVAL, "flow_warp_up2: null pointer");
     ATMVFI_REQUIRE(B > 0 && C > 0 && H > 1 && W > 1, ATMVFI_EINVAL, "flow_warp_up2: bad shape (H, W must be > 1)");
@@ -717,6 +928,30 @@ extern "C" int atmvfi_warp_blend_planes(const float* im0, const float* im1, cons
                        motion, motion_ld, (long long)motion_bstride, i0w, i1w, it, flow0_out, flow1_out, mask1_out, mask2_out,
                        orig0, orig1, pack15, pack_ld, (_Float16*)pack_hi, (_Float16*)pack_lo, (long long)pack_rows, pack_c0, B, H, W);
     return atmvfi::check_launch("warp_blend");
+}
+extern "C" int atmvfi_warp_blend_tiled(const float* im0, const float* im1, const float* motion, int motion_ld,
+                                        int64_t motion_bstride, float* i0w, float* i1w, float* it, float* flow0_out,
+                                        float* flow1_out, float* mask1_out, float* mask2_out, const float* orig0,
+                                        const float* orig1, float* pack15, int pack_ld, void* pack_hi, void* pack_lo, int64_t pack_rows,
+                                        int pack_c0, int B, int H, int W, void* stream) {
+    ATMVFI_REQUIRE(im0 && im1 && motion && i0w && i1w && it, ATMVFI_EINVAL, "warp_blend_tiled: null pointer");
+    ATMVFI_REQUIRE(B > 0 && H > 1 && W > 1 && motion_ld >= 5, ATMVFI_EINVAL, "warp_blend_tiled: bad shape");
+    ATMVFI_REQUIRE(W % 4 == 0 && atmvfi::aligned16(im0) && atmvfi::aligned16(im1), ATMVFI_EINVAL,
+                   "warp_blend_tiled: W must be a multiple of 4 and the images 16-byte aligned (got W = %d)", W);
+    ATMVFI_REQUIRE((flow0_out == nullptr) == (flow1_out == nullptr) && (mask1_out == nullptr) == (mask2_out == nullptr),
+                   ATMVFI_EINVAL, "warp_blend_tiled: flow/mask outputs come in pairs");
+    if (pack15) ATMVFI_REQUIRE(orig0 && orig1 && pack_ld >= 15, ATMVFI_EINVAL, "warp_blend_tiled: pack15 needs orig0/orig1 and ld >= 15");
+    ATMVFI_REQUIRE((pack_hi == nullptr) == (pack_lo == nullptr), ATMVFI_EINVAL, "warp_blend_tiled: the plane sink needs both planes");
+    if (pack_hi)
+        ATMVFI_REQUIRE(orig0 && orig1 && pack_rows >= (int64_t)B * H * W && pack_c0 >= 0 && pack_c0 % 4 == 0 && atmvfi::aligned16(pack_hi) &&
+                           atmvfi::aligned16(pack_lo), ATMVFI_EINVAL,
+                       "warp_blend_tiled: plane sink needs orig0/orig1, rows >= B*H*W, a channel offset that is a multiple of 4, aligned planes");
+    const long long tiles = (long long)B * ((H + WT_H - 1) / WT_H) * ((W + WT_W - 1) / WT_W);
+    ATMVFI_REQUIRE(tiles < (1ll << 31), ATMVFI_EINVAL, "warp_blend_tiled: grid too large");
+    hipLaunchKernelGGL(warp_blend_tiled_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, im0, im1,
+                       motion, motion_ld, (long long)motion_bstride, i0w, i1w, it, flow0_out, flow1_out, mask1_out, mask2_out,
+                       orig0, orig1, pack15, pack_ld, (_Float16*)pack_hi, (_Float16*)pack_lo, (long long)pack_rows, pack_c0, B, H, W);
+    return atmvfi::check_launch("warp_blend_tiled");
 }
 extern "C" int atmvfi_warp_blend(const float* im0, const float* im1, const float* motion, int motion_ld,
                                   int64_t motion_bstride, float* i0w, float* i1w, float* it, float* flow0_out,

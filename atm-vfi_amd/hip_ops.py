@@ -104,11 +104,14 @@ SIGNATURES = {
     "atmvfi_window_attn_self": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
     "atmvfi_motion_head": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_l, c_i, c_l, c_i, c_f]),
     "atmvfi_flow_warp": (c_i, [c_f, c_f, c_l, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_f]),
+    "atmvfi_flow_warp_tiled": (c_i, [c_f, c_f, c_l, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_f]),
     "atmvfi_flow_warp_nhwc": (c_i, [c_f, c_i, c_l, c_f, c_l, c_i, c_i, c_f, c_i, c_l, c_i, c_i, c_i, c_i, c_f]),
     "atmvfi_warp_blend": (c_i, [c_f, c_f, c_f, c_i, c_l, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i,
                                 c_i, c_i, c_i, c_f]),
     "atmvfi_warp_blend_planes": (c_i, [c_f, c_f, c_f, c_i, c_l, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i,
                                        c_f, c_f, c_l, c_i, c_i, c_i, c_i, c_f]),
+    "atmvfi_warp_blend_tiled": (c_i, [c_f, c_f, c_f, c_i, c_l, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i,
+                                      c_f, c_f, c_l, c_i, c_i, c_i, c_i, c_f]),
     "atmvfi_resize_bilinear_ac": (c_i, [c_f, c_l, c_l, c_l, c_l, c_f, c_i, c_i, c_i, c_i, c_i, c_i, ctypes.c_float, c_f]),
     "atmvfi_frame_u8_to_f32": (c_i, [c_f, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_f]),
     "atmvfi_frame_f32_to_u8": (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_f]),
@@ -435,6 +438,7 @@ class HipOps:
         # fp32-input f16x3 GEMM; None / 0 = the library's cost model
         self.conv3_instance = None
         self.gemm_tile_wn = 0
+        self.warp_tiles = os.environ.get("ATMVFI_WARP_TILES", "1") != "0"     # A/B switch: planar warps with LDS-staged source tiles
         self.recording: Optional[LaunchPlan] = None     # when set: every launch is also appended to this plan
 
     # ------------------------------------------------------------------ launch plans
@@ -907,6 +911,11 @@ class HipOps:
                   _ptr(b0), _ptr(w1), _ptr(b1), _ptr(out), old, ogs, orpg, rows, motion.shape[1], self._stream())
 
     # ------------------------------------------------------------------ warps
+    def _tiled_warp_ok(self, w, *planes) -> bool:
+        """The LDS-staged warps (`atmvfi_flow_warp_tiled`, `atmvfi_warp_blend_tiled`; bit-identical to the direct ones) take rows by
+        16-byte loads: W a multiple of 4, planes 16-byte aligned.  ``warp_tiles = False`` is the A/B switch."""
+        return self.warp_tiles and w % 4 == 0 and all(t.data_ptr() % 16 == 0 for t in planes)
+
     def flow_warp(self, src, flow, dst):
         _chk(src, "flow_warp.src"); _chk(dst, "flow_warp.dst")
         b, c, h, w = src.shape
@@ -914,7 +923,8 @@ class HipOps:
             raise ValueError("flow_warp: src/dst must be contiguous NCHW of equal shape")
         bs, ps, cs = flow_view(flow, h, w, "flow_warp.flow")
         meta = {"bytes": 4.0 * b * h * w * (2 * c + 2)}
-        self._run("flow_warp", meta, self.lib.atmvfi_flow_warp, _ptr(src), _ptr(flow), bs, ps, cs, _ptr(dst), b, c, h, w, self._stream())
+        fn = self.lib.atmvfi_flow_warp_tiled if self._tiled_warp_ok(w, src) else self.lib.atmvfi_flow_warp
+        self._run("flow_warp", meta, fn, _ptr(src), _ptr(flow), bs, ps, cs, _ptr(dst), b, c, h, w, self._stream())
 
     def flow_warp_up2(self, src, flow, dst, flow_up):
         """flow_warp(src, flow) -> dst and the flow up-sampled x2 (values doubled) -> flow_up, one launch; all contiguous planar."""
@@ -955,7 +965,8 @@ class HipOps:
             if pack_planes.rows != b * h * w or pack_c0 % 4 or pack_c0 + 16 > pack_planes.chunks * 32:
                 raise ValueError("warp_blend: the plane sink must hold B*H*W rows and 16 channels at the offset")
             _planar(orig0, 3, "warp_blend.orig0"); _planar(orig1, 3, "warp_blend.orig1")
-        self._run("warp_blend", meta, self.lib.atmvfi_warp_blend_planes, _ptr(im0), _ptr(im1), _ptr(motion), mld, motion.stride(0),
+        fn = self.lib.atmvfi_warp_blend_tiled if self._tiled_warp_ok(w, im0, im1) else self.lib.atmvfi_warp_blend_planes
+        self._run("warp_blend", meta, fn, _ptr(im0), _ptr(im1), _ptr(motion), mld, motion.stride(0),
                   _ptr(i0w), _ptr(i1w), _ptr(it), _ptr(flow0), _ptr(flow1), _ptr(mask1), _ptr(mask2), _ptr(orig0), _ptr(orig1),
                   _ptr(pack15), pld, pack_planes.t[0].data_ptr() if pack_planes is not None else None,
                   pack_planes.t[1].data_ptr() if pack_planes is not None else None,

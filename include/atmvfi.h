@@ -280,6 +280,12 @@ int atmvfi_motion_head(const float* motion /*[rows, heads, 2]*/, const int32_t* 
  * ---------------------------------------------------------------------------------- */
 int atmvfi_flow_warp(const float* src /*[B,C,H,W]*/, const float* flow, int64_t flow_bstride,
                      int flow_pstride, int flow_cstride, float* dst, int B, int C, int H, int W, void* stream);
+/* atmvfi_flow_warp with LDS-STAGED SOURCE TILES (the same signature and bit-identical results): a workgroup owns 32 x 8 output pixels,
+ * stages the bounding box of their bilinear taps (up to 64 x 24 source pixels per plane, 16-byte row loads) in LDS and takes the taps
+ * from there; tiles whose flows reach further gather from global memory.  Needs W % 4 == 0 and a 16-byte aligned src (ATMVFI_EINVAL
+ * otherwise: the caller uses atmvfi_flow_warp). */
+int atmvfi_flow_warp_tiled(const float* src /*[B,C,H,W]*/, const float* flow, int64_t flow_bstride,
+                           int flow_pstride, int flow_cstride, float* dst, int B, int C, int H, int W, void* stream);
 int atmvfi_flow_warp_nhwc(const float* src, int src_ld, int64_t src_bstride,
                           const float* flow, int64_t flow_bstride, int flow_pstride, int flow_cstride,
                           float* dst, int dst_ld, int64_t dst_bstride, int B, int C, int H, int W, void* stream);
@@ -303,6 +309,12 @@ int atmvfi_warp_blend_planes(const float* im0, const float* im1, const float* mo
                              float* i0w, float* i1w, float* it, float* flow0_out, float* flow1_out, float* mask1_out, float* mask2_out,
                              const float* orig0, const float* orig1, float* pack15, int pack_ld, void* pack_hi, void* pack_lo,
                              int64_t pack_rows, int pack_c0, int B, int H, int W, void* stream);
+/* atmvfi_warp_blend_planes with LDS-staged source tiles of both images (see atmvfi_flow_warp_tiled): the same signature, bit-identical
+ * results; W % 4 == 0, im0 / im1 16-byte aligned. */
+int atmvfi_warp_blend_tiled(const float* im0, const float* im1, const float* motion, int motion_ld, int64_t motion_bstride,
+                            float* i0w, float* i1w, float* it, float* flow0_out, float* flow1_out, float* mask1_out, float* mask2_out,
+                            const float* orig0, const float* orig1, float* pack15, int pack_ld, void* pack_hi, void* pack_lo,
+                            int64_t pack_rows, int pack_c0, int B, int H, int W, void* stream);
 #define atmvfi_blend atmvfi_warp_blend   /* SURVEY.md section 8b name */
 
 /* Bilinear resize with align_corners=True, src = dst*(in-1)/(out-1), values * value_scale:

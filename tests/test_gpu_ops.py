@@ -939,6 +939,46 @@ def test_flow_warp_up2_equals_two_launches(hip, dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 40, 96), (1, 37, 44), (3, 8, 4), (1, 136, 256)], ids=lambda s: f"{s[0]}x{s[1]}x{s[2]}")
+@pytest.mark.parametrize("amp", [1.5, 9.0, 60.0], ids=["flows~1px", "flows~9px", "flows~60px"])
+def test_tiled_warps_equal_direct_warps(shape, amp, hip, dev):
+    """flow_warp / warp_blend with LDS-staged source tiles (atmvfi_flow_warp_tiled, atmvfi_warp_blend_tiled) == the direct-gather kernels,
+    bit for bit: flows inside the staged box, flows beyond it (per-tile fallback to global gathers), taps that leave the image, inf / NaN
+    flows, ragged tiles (H not a multiple of 8, W not a multiple of 32), several channel groups."""
+    b, h, w = shape
+    g = torch.Generator().manual_seed(int(amp * 10) + h * w)
+    low = torch.randn(b, 5, max(2, h // 8), max(2, w // 8), generator=g)
+    mot = torch.nn.functional.interpolate(low, size=(h, w), mode="bilinear", align_corners=True) * amp
+    mot[0, 0, 0, 0] = float("inf"); mot[0, 1, h // 2, w // 2] = float("nan"); mot[-1, 2, -1, -1] = -1e9; mot[0, 3, 1, :] = 500.0
+    mot[:, :, :2, : w // 2] *= 30.0            # one corner with far-reaching flows beside quiet tiles
+    motion = mot.permute(0, 2, 3, 1).contiguous().to(dev)
+    im0, im1 = torch.rand(b, 3, h, w, generator=g).to(dev), torch.rand(b, 3, h, w, generator=g).to(dev)
+    src = torch.rand(b, 7, h, w, generator=g).to(dev)
+    res = {}
+    for tiles in (False, True):
+        hip.warp_tiles = tiles
+        outs = [torch.full((b, 3, h, w), 7.0, device=dev) for _ in range(3)]
+        f0, f1 = (torch.full((b, 2, h, w), 7.0, device=dev) for _ in range(2))
+        m1, m2 = (torch.full((b, 1, h, w), 7.0, device=dev) for _ in range(2))
+        pl = hip_ops.Planes.alloc(b * h * w, 32, dev)
+        pl.t.zero_()
+        hip.warp_blend(im0, im1, motion, *outs, f0, f1, m1, m2, im0, im1, None, pack_planes=pl, pack_c0=8)
+        pack = torch.full((b, h, w, 20), 7.0, device=dev)
+        outs2 = [torch.full((b, 3, h, w), 7.0, device=dev) for _ in range(3)]
+        hip.warp_blend(im0, im1, motion, *outs2, None, None, None, None, im0, im1, pack[..., 2:17])
+        # flow_warp: 7 channels = three staging groups, planar flow and the NHWC motion view
+        d1, d2 = torch.full((b, 7, h, w), 7.0, device=dev), torch.full((b, 7, h, w), 7.0, device=dev)
+        hip.flow_warp(src, mot[:, 2:4].contiguous().to(dev), d1)
+        hip.flow_warp(src, motion[..., 0:2].permute(0, 3, 1, 2), d2)
+        torch.cuda.synchronize()
+        res[tiles] = [*outs, f0, f1, m1, m2, pl.t.clone(), pack, *outs2, d1, d2]
+    hip.warp_tiles = True
+    for i, (x, y) in enumerate(zip(res[False], res[True])):
+        assert torch.equal(torch.nan_to_num(x.float(), nan=-3.0), torch.nan_to_num(y.float(), nan=-3.0)), f"output {i} differs"
+    assert not torch.isnan(res[True][0]).any()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(1, 64, 96), (2, 136, 248), (1, 8, 8)], ids=lambda s: f"{s[0]}x{s[1]}x{s[2]}")
 def test_image_pyramid_equals_sequential_resizes(shape, hip, dev):
     """One launch for the x0.5 pyramid levels 1..3 of both frames == F.interpolate-style resizes applied level by level, bit for bit."""

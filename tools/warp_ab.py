@@ -20,17 +20,19 @@ for amp in (4.0, 24.0):
         hip_ops.load_library.__defaults__ = (path,)
         if hasattr(hip_ops.load_library, "cache_clear"): hip_ops.load_library.cache_clear()
         ops = hip_ops.HipOps(dev)
-        outs = [torch.empty(B, 3, H, W, device=dev) for _ in range(3)]
-        f0, f1 = (torch.empty(B, 2, H, W, device=dev) for _ in range(2))
-        m1, m2 = (torch.empty(B, 1, H, W, device=dev) for _ in range(2))
-        pl = hip_ops.Planes.alloc(B * H * W, 32, dev)
-        def call():
-            ops.warp_blend(im0, im1, motion, *outs, f0, f1, m1, m2, im0, im1, None, pack_planes=pl, pack_c0=8)
-        for _ in range(5): call()
-        torch.cuda.synchronize()
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        for _ in range(50): call()
-        e.record(); torch.cuda.synchronize()
-        chk = float(outs[2].double().sum()) + float(pl.t[0].float().sum())
-        print(f"flow amplitude ~{amp:4.0f} px  {os.path.basename(path):28s} {s.elapsed_time(e) / 50 * 1e3:7.1f} us   checksum {chk:.6f}", flush=True)
+        for tiles in (False, True):
+          ops.warp_tiles = tiles
+          outs = [torch.empty(B, 3, H, W, device=dev) for _ in range(3)]
+          f0, f1 = (torch.empty(B, 2, H, W, device=dev) for _ in range(2))
+          m1, m2 = (torch.empty(B, 1, H, W, device=dev) for _ in range(2))
+          pl = hip_ops.Planes.alloc(B * H * W, 32, dev)
+          def call():
+              ops.warp_blend(im0, im1, motion, *outs, f0, f1, m1, m2, im0, im1, None, pack_planes=pl, pack_c0=8)
+          for _ in range(5): call()
+          torch.cuda.synchronize()
+          s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+          s.record()
+          for _ in range(50): call()
+          e.record(); torch.cuda.synchronize()
+          chk = float(outs[2].double().sum()) + float(pl.t[0].float().sum())
+          print(f"flow amplitude ~{amp:4.0f} px  {os.path.basename(path):20s} {'LDS-staged tiles' if tiles else 'direct gathers  '} {s.elapsed_time(e) / 50 * 1e3:7.1f} us   checksum {chk:.6f}", flush=True)
