@@ -173,6 +173,7 @@ def dry_run(args, dist):
 
 def main():
     args = parse()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (read when the runtime starts): RCCL's intra-node transport needs it
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(self_launch(args))
     import torch.distributed as dist
