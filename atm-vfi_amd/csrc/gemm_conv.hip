@@ -349,8 +349,8 @@ extern "C" int atmvfi_gemm(const atmvfi_gemm_params* p, void* stream) {
     d.out_plane_rows = p->out_plane_rows;
     d.out_c0 = p->out_plane_c0;
     d.out_gc = p->out_plane_gc;
-    ATMVFI_REQUIRE(p->tile_wn >= -3 && p->tile_wn <= 8 && (p->tile_wn >= 0 || planes), ATMVFI_EINVAL,
-                   "gemm: tile_wn 0 (auto), 1..8, or (split-plane input) -1 reference schedule / -2 gemm_duo / -3 gemm_pp, got %d", p->tile_wn);
+    ATMVFI_REQUIRE(p->tile_wn >= -4 && p->tile_wn <= 8 && (p->tile_wn >= 0 || planes), ATMVFI_EINVAL,
+                   "gemm: tile_wn 0 (auto), 1..8, or (split-plane input) -1 reference schedule / -2 gemm_duo (128-column tiles) / -3 gemm_pp / -4 gemm_duo (64-column tiles), got %d", p->tile_wn);
     d.force_wn = p->tile_wn;
     d.fit32 = 0;
     d.pfit32 = 0;

@@ -3,7 +3,8 @@
 // order of products: bit-identical results), the same 64 x 64 wave tile and the same epilogue code -- but 128 x 128 tiles on 256 threads,
 // two 32-KiB LDS stages, one tile per workgroup and no phase control: two workgroups share a CU, so one's prologue, fragment reads and
 // epilogue (a third of a K = 384 tile in gemm_pp.hip, where all eight waves of the CU are in the epilogue together) run under the other's
-// MFMAs.  Selected per call with atmvfi_gemm_params.tile_wn = -2 (A/B against gemm_pp.hip: tools/bench_split_ab.py).
+// MFMAs.  Chosen per launch by launch_gemm_split (gemm_split.hip); atmvfi_gemm_params.tile_wn = -2 / -4 force its 128- / 64-column form
+// (A/B against gemm_pp.hip: tools/bench_split_ab.py, tools/duo_rule.py, tools/narrow_ab.py).
 #include "common.h"
 #include "gemm_common.h"
 
@@ -14,10 +15,12 @@ namespace {
 using atmvfi::GemmDev;
 
 constexpr float LO_UNSCALE = 1.0f / 1024.0f;
-constexpr int BM = 128, BN = 128;
-constexpr int STAGE = (2 * BM + 2 * BN) * 64;          // bytes: [A hi 128 rows][A lo][W hi 128 rows][W lo], 64 B per row
-constexpr int A_LO = BM * 64, W_HI = 2 * BM * 64, W_LO = W_HI + BN * 64;
-constexpr int CST_FLOATS = atmvfi::gemm_const_floats(BN) + BM;      // bias / slope of the column block + the tile's row-map entries
+constexpr int BM = 128;
+// BN = 128: 4 waves as 2 x 2 of 64 x 64; BN = 64 (layers of at most 64 columns: half of a 128-column tile would be padding): 4 waves as
+// 4 x 1 of 32 x 64, 24-KiB stages, three workgroups per CU
+constexpr int stage_bytes(int BN) { return (2 * BM + 2 * BN) * 64; }   // [A hi 128 rows][A lo][W hi BN rows][W lo], 64 B per row
+constexpr int A_LO = BM * 64, W_HI = 2 * BM * 64;
+constexpr int cst_floats(int BN) { return atmvfi::gemm_const_floats(BN) + BM; }      // bias / slope of the column block + the tile's row-map entries
 
 __device__ __forceinline__ int swz64(int row) { return ((row >> 2) & 1) << 1; }
 __device__ __forceinline__ void dma16(const unsigned char* src, unsigned char* lds_wave_base) {
@@ -41,8 +44,13 @@ __device__ __forceinline__ void lds_read16f(f32x4& d, unsigned addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
 }
 
-template <bool CONVM>
+template <bool CONVM, int BN>
 __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(const GemmDev a) {
+    constexpr int STAGE = stage_bytes(BN), W_LO = W_HI + BN * 64;
+    constexpr int MI = BN == 128 ? 4 : 2;           // 16-row MFMA tiles per wave along M
+    constexpr int NWN = BN / 64;                    // waves along N (64 columns each)
+    constexpr int WROWS = 16 * MI;
+    constexpr int PIW = BN / 64;                    // 16-row DMA pieces of a W plane per wave (A: always 2)
     fp16_saturate_on();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -50,7 +58,7 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(const GemmDev a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15;
     const int g = lane >> 4;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / NWN, wn = wave % NWN;
 
     // XCD-aware tile order of gemm_pp.hip (virtual block v: xcd = v & 7, slot = v >> 3, row tile = (slot / nblocks) * 8 + xcd, column
     // block = slot % nblocks: the column blocks of one row tile meet in one L2), one tile per workgroup
@@ -89,16 +97,18 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(const GemmDev a) {
         } else {
             aoff[i] = (unsigned)m * 64u + ls16;
         }
-        int n = n0 + (i * 4 + wave) * 16 + (lane >> 2);
-        if (n >= a.wrows) n = a.wrows - 1;
-        wsoff[i] = (unsigned)n * 64u + ls16;
+        if (i < PIW) {
+            int n = n0 + (i * 4 + wave) * 16 + (lane >> 2);
+            if (n >= a.wrows) n = a.wrows - 1;
+            wsoff[i] = (unsigned)n * 64u + ls16;
+        }
     }
     const unsigned char* pa_hi = reinterpret_cast<const unsigned char*>(a.a_hi);
     const unsigned char* pa_lo = reinterpret_cast<const unsigned char*>(a.a_lo);
     const unsigned char* pw_hi = reinterpret_cast<const unsigned char*>(a.w_hi);
     const unsigned char* pw_lo = reinterpret_cast<const unsigned char*>(a.w_lo);
     const long long a_step = (long long)a.in_ld * 64, w_step = (long long)a.wrows * 64;
-    auto issue_stage = [&](int buf) {                               // 8 pieces per wave
+    auto issue_stage = [&](int buf) {                               // 4 + 2 PIW pieces per wave
         unsigned char* dst = smem + buf * STAGE + wave * 1024;
         if constexpr (CONVM) {
             const bool second = c_chunk >= a.split_chunks;
@@ -132,9 +142,9 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(const GemmDev a) {
             pa_lo += a_step;
         }
         dma16(pw_hi + wsoff[0], dst + W_HI);
-        dma16(pw_hi + wsoff[1], dst + W_HI + 4 * 1024);
+        if constexpr (PIW == 2) dma16(pw_hi + wsoff[1], dst + W_HI + 4 * 1024);
         dma16(pw_lo + wsoff[0], dst + W_LO);
-        dma16(pw_lo + wsoff[1], dst + W_LO + 4 * 1024);
+        if constexpr (PIW == 2) dma16(pw_lo + wsoff[1], dst + W_LO + 4 * 1024);
         pw_hi += w_step;
         pw_lo += w_step;
     };
@@ -151,9 +161,9 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(const GemmDev a) {
         }
     }
 
-    f32x4 acc[4][4], cor[4][4];
+    f32x4 acc[MI][4], cor[MI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -167,17 +177,17 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(const GemmDev a) {
     issue_stage(0);
     if (nk > 1) issue_stage(1);
     DUO_SUB(0);
-    f16x8 xh[4], xl[4], wh[4], wl[4];
-    const unsigned xfrag = lds_offset(smem) + (unsigned)((64 * wm + r) * 64 + ((g ^ swz64(r)) << 4));
+    f16x8 xh[MI], xl[MI], wh[4], wl[4];
+    const unsigned xfrag = lds_offset(smem) + (unsigned)((WROWS * wm + r) * 64 + ((g ^ swz64(r)) << 4));
     const unsigned wfrag = lds_offset(smem) + (unsigned)(W_HI + (64 * wn + r) * 64 + ((g ^ swz64(r)) << 4));
     for (int u = 0; u < nk; ++u) {
         // this wave's pieces of stage u have landed (8 newer ones, stage u + 1, may stay in flight), then everybody's
-        if (u + 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (u + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + 2 * PIW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         DUO_SUB(1);
         const unsigned off = (unsigned)((u & 1) * STAGE);
-        static_for<0, 4>([&](auto ic) {
+        static_for<0, MI>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             lds_read16<i * 1024>(xh[i], xfrag + off);
             lds_read16<i * 1024 + A_LO>(xl[i], xfrag + off);
@@ -187,8 +197,8 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(const GemmDev a) {
             lds_read16<j * 1024>(wh[j], wfrag + off);
             lds_read16<j * 1024 + BN * 64>(wl[j], wfrag + off);
         });
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(xh[0]), "+v"(xh[1]), "+v"(xh[2]), "+v"(xh[3]), "+v"(xl[0]), "+v"(xl[1]), "+v"(xl[2]), "+v"(xl[3]));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xh[0]), "+v"(xh[1]), "+v"(xl[0]), "+v"(xl[1]));
+        if constexpr (MI == 4) asm volatile("" : "+v"(xh[2]), "+v"(xh[3]), "+v"(xl[2]), "+v"(xl[3]));
 #pragma unroll
         for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(wh[j]), "+v"(wl[j]));
         DUO_SUB(2);
@@ -198,14 +208,14 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(const GemmDev a) {
         DUO_SUB(4);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 cor[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j], xh[i], cor[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xh[i], acc[i][j], 0, 0, 0);
             }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) cor[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xl[i], cor[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
@@ -229,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(const GemmDev a) {
         // residual vectors in one batch of unconditional loads before the first store (one wait per tile; vmcnt counts stores on
         // gfx9, so a wait per row would drain the previous row's stores).
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 acc[i][j] = acc[i][j] + cor[i][j] * LO_UNSCALE;
@@ -246,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(const GemmDev a) {
                 wad[k] = wbase + (unsigned)((((4 * k + g) ^ r) & 15) << 4);               // row r, slot (4 j + g) ^ r
                 rad[k] = rbase + (unsigned)(k * 1024) + (unsigned)(((r ^ (4 * k + g)) & 15) << 4);   // row 4 q + g, slot r ^ (4 q + g)
             }
-            static_for<0, 4>([&](auto ic) {
+            static_for<0, MI>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 static_for<0, 4>([&](auto jc) {
                     constexpr int j = decltype(jc)::value;
@@ -259,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(const GemmDev a) {
             });
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(acc[i][q]));
         }
@@ -269,17 +279,17 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(const GemmDev a) {
         const atmvfi::ChanPos cp = atmvfi::gemm_chan_pos(a, nb);
         const f32x4 bvec = *reinterpret_cast<const f32x4*>(cst + cl);
         const f32x4 pvec = *reinterpret_cast<const f32x4*>(cst + BN + cl);
-        const int mrow = m0 + 64 * wm + g;                       // row of (i, q) = (0, 0); (i, q) adds 16 i + 4 q
-        int ro[4][4];              // output row: the row map's entry, or (unmapped) the row itself; < 0: nothing to store
+        const int mrow = m0 + WROWS * wm + g;                       // row of (i, q) = (0, 0); (i, q) adds 16 i + 4 q
+        int ro[MI][4];              // output row: the row map's entry, or (unmapped) the row itself; < 0: nothing to store
         if (mapped) {                 // (the test outside the loops: inside, hipcc makes it a scalar branch per row)
-            const int* mp = reinterpret_cast<const int*>(cst + atmvfi::gemm_const_floats(BN)) + 64 * wm + g;
+            const int* mp = reinterpret_cast<const int*>(cst + atmvfi::gemm_const_floats(BN)) + WROWS * wm + g;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) ro[i][q] = (mrow + 16 * i + 4 * q) < M ? mp[16 * i + 4 * q] : -1;
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int m = mrow + 16 * i + 4 * q;
@@ -287,9 +297,9 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(const GemmDev a) {
                 }
         }
         const bool vec_res = !CONVM && a.residual && (a.Cout & 3) == 0 && a.mode != ATMVFI_GEMM_DECONV;
-        f32x4 res[4][4];
+        f32x4 res[MI][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int q = 0; q < 4; ++q) res[i][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (vec_res && a.fit32 && m0 + BM <= M) {
@@ -298,19 +308,19 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(const GemmDev a) {
             unsigned voff = nb < a.Cout ? ((unsigned)mrow * (unsigned)a.res_ld + (unsigned)nb) * 4u : 0u;
             const unsigned step = nb < a.Cout ? (unsigned)a.res_ld * 16u : 0u;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     res[i][q] = *reinterpret_cast<const f32x4*>(rb + voff);
                     voff += step;
                 }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(res[i][q]));
         } else if (vec_res) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int m = mrow + 16 * i + 4 * q;
@@ -320,7 +330,7 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(const GemmDev a) {
             // every vector is "used" here, dead rows' too: a load left pending on some path makes hipcc guard the next tile's first
             // write to its register with s_waitcnt vmcnt(0), which would also wait for this tile's stores
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(res[i][q]));
         }
@@ -338,7 +348,7 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(const GemmDev a) {
         auto store_rows = [&](auto ragged_tag) {
             constexpr bool RAGGED = decltype(ragged_tag)::value;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int m = mrow + 16 * i + 4 * q;
@@ -396,7 +406,7 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(const GemmDev a) {
                     unsigned voff = ((unsigned)mrow * (unsigned)a.out_ld + (unsigned)nb) * 4u;
                     const unsigned step = (unsigned)a.out_ld * 16u;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < MI; ++i)
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             *reinterpret_cast<f32x4*>(ob + voff) = finish(i, q);
@@ -408,7 +418,7 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(const GemmDev a) {
                 float* obase = a.out + nb;
                 const bool col_ok = nb < a.Cout;
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const f32x4 v = finish(i, q);
@@ -431,7 +441,7 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(const GemmDev a) {
                     unsigned char* ph = reinterpret_cast<unsigned char*>(a.out_hi + cpart);
                     unsigned char* pl = reinterpret_cast<unsigned char*>(a.out_lo + cpart);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < MI; ++i)
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const f32x4 v = finish(i, q);
@@ -449,7 +459,7 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(const GemmDev a) {
                 auto rows = [&](auto f32_tag) {
                     constexpr bool F32 = decltype(f32_tag)::value;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < MI; ++i)
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const f32x4 v = finish(i, q);
@@ -489,7 +499,7 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(const GemmDev a) {
                     unsigned rowbase = ((unsigned)dn * (unsigned)a.Ho + 2u * (unsigned)dy) * (unsigned)a.Wo + (unsigned)qoff;
                     const unsigned rstep = 2u * (unsigned)a.Wo;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < MI; ++i)
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             // (no residual on this path; channels past Cout inside the group of 4 are already zero: their weight
@@ -510,7 +520,7 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(const GemmDev a) {
                         }
                 } else
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         f32x4 v = finish(i, q);
@@ -553,10 +563,10 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(const GemmDev a) {
 
 }  // namespace
 
-template <bool CONVM>
+template <bool CONVM, int BN>
 static int launch_duo(const GemmDev& d, int ngemm, hipStream_t s) {
-    const size_t lds = (size_t)2 * STAGE + CST_FLOATS * sizeof(float);
-    const hipError_t attr_err = atmvfi::allow_dynamic_lds<gemm_duo_kernel<CONVM>>(lds);
+    const size_t lds = (size_t)2 * stage_bytes(BN) + cst_floats(BN) * sizeof(float);
+    const hipError_t attr_err = atmvfi::allow_dynamic_lds<gemm_duo_kernel<CONVM, BN>>(lds);
     ATMVFI_REQUIRE(attr_err == hipSuccess, ATMVFI_ELAUNCH, "gemm_duo: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
     ATMVFI_REQUIRE((long long)d.in_ld * 64 < (1ll << 32) && (long long)d.wrows * 64 < (1ll << 32) &&
                        (!d.a_hi2 || (long long)d.in_ld2 * 64 < (1ll << 32)) && d.M < (1ll << 26), ATMVFI_EINVAL,
@@ -574,10 +584,13 @@ static int launch_duo(const GemmDev& d, int ngemm, hipStream_t s) {
     const long long mgroups = (atmvfi::ceil_div64(d.M, BM) + 7) / 8;
     ATMVFI_REQUIRE(mgroups * 8 * dd.nblocks < (1LL << 31), ATMVFI_EINVAL, "gemm_duo: grid too large");
     dd.vblocks = (int)(mgroups * 8 * dd.nblocks);
-    hipLaunchKernelGGL(gemm_duo_kernel<CONVM>, dim3((unsigned)dd.vblocks), dim3(256), lds, s, dd);
+    hipLaunchKernelGGL((gemm_duo_kernel<CONVM, BN>), dim3((unsigned)dd.vblocks), dim3(256), lds, s, dd);
     return atmvfi::check_launch("gemm_duo");
 }
 
 int atmvfi::launch_gemm_duo(const GemmDev& d, int ngemm, hipStream_t s) {
-    return d.mode == ATMVFI_GEMM_CONV ? launch_duo<true>(d, ngemm, s) : launch_duo<false>(d, ngemm, s);
+    // at most 64 GEMM columns: 64-column tiles (tile_wn = -2 forces the 128-column form for the A/B, -4 the 64-column one)
+    if ((ngemm <= 64 && d.force_wn != -2) || d.force_wn == -4)
+        return d.mode == ATMVFI_GEMM_CONV ? launch_duo<true, 64>(d, ngemm, s) : launch_duo<false, 64>(d, ngemm, s);
+    return d.mode == ATMVFI_GEMM_CONV ? launch_duo<true, 128>(d, ngemm, s) : launch_duo<false, 128>(d, ngemm, s);
 }

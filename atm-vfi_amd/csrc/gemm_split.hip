@@ -442,19 +442,21 @@ int launch_split(const GemmDev& d, int ngemm, hipStream_t s) {
 }  // namespace
 
 int atmvfi::launch_gemm_split(const GemmDev& d, int ngemm, hipStream_t s) {
-    // force_wn: -1 this file (the reference schedule: tools / A-B only), -2 gemm_duo.hip, -3 gemm_pp.hip; 0 = choose.  The three give
+    // force_wn: -1 this file (the reference schedule: tools / A-B only), -2 / -4 gemm_duo.hip with 128- / 64-column tiles, -3 gemm_pp.hip;
+    // 0 = choose.  The three give
     // bit-identical results, so the choice is a matter of time only.  Per launch (tools/duo_rule.py, both kernels timed inside a forward):
     //   * on a grid that fills the chip many times over the ping-pong kernel wins by 0-16 % (up to 57 % at K = 4608);
     //   * its persistent grid works in rounds of one 256 x 128 tile per CU, and a launch of 1.4 or 2.2 rounds pays for 2 or 3; the
     //     128 x 128 kernel's unit is half of that and two of them share a CU, so it wins whenever its own round count (+8 % for its
     //     lower per-tile rate, +15 % more for K >= 2048, + a fifth of a tile when a CU's last tile runs alone) comes out below;
-    //   * narrow short-K layers (N <= 64: half of the 128-column tile is empty, the launch is epilogue-bound) always go to the 128 x
-    //     128 kernel (the refiner's 64 -> 64 stride-2 conv at 1080p: 0.308 -> 0.261 ms).
+    //   * layers of at most 64 columns always go to gemm_duo.hip, which runs them on 128 x 64 tiles (half of a 128-column tile would be
+    //     padding: the refiner's 64 -> 64 stride-2 conv at 1080p 0.331 -> 0.248 ms, a 256 -> 64 conv at K = 2304 74 -> 52 us;
+    //     tools/narrow_ab.py).
     // End to end: network_lite 256 x 256 +11 %, 256 x 448 +10 %, network_base 540p +3 %, 1080p +1 % (tools/small_gemm_ab.py).
-    if (d.force_wn == -2) return launch_gemm_duo(d, ngemm, s);
+    if (d.force_wn == -2 || d.force_wn == -4) return launch_gemm_duo(d, ngemm, s);
     if (d.force_wn == -3) return launch_gemm_pp(d, ngemm, s);
     if (d.force_wn == 0) {
-        if (ngemm <= 64 && d.nchunks32 <= 36) return launch_gemm_duo(d, ngemm, s);
+        if (ngemm <= 64) return launch_gemm_duo(d, ngemm, s);
         const long long cus = cu_count(), ntile = (ngemm + 127) / 128;
         const long long pp_rounds = ceil_div64(ceil_div64(d.M, 256) * ntile, cus);
         const long long duo_per_cu = ceil_div64(ceil_div64(d.M, 128) * ntile, cus);

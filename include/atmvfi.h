@@ -104,9 +104,9 @@ typedef struct atmvfi_gemm_params {
     int32_t out_plane_c0, out_plane_gc;
     /* F16X3, fp32 input: n-tiles of 16 columns per 256-row workgroup tile, 0 = cost model (default), 1..8 = forced (sweeps).
        F16X3, split-plane input: 0 = chosen per launch between the ping-pong kernel (gemm_pp.hip: 256 x 128 tiles, persistent grid) and
-       gemm_duo.hip (128 x 128 tiles, two workgroups per CU: grids that would leave half of the CUs idle, narrow short-K layers);
-       -3 / -2 force the one / the other, -1 the reference schedule (gemm_split.hip).  All three have the same arithmetic: bit-identical
-       results (parity tests, same-process A/B). */
+       gemm_duo.hip (128 x 128 tiles, two workgroups per CU: grids that would leave half of the CUs idle; 128 x 64 tiles for layers of
+       at most 64 columns); -3 forces gemm_pp.hip, -2 / -4 gemm_duo.hip with 128- / 64-column tiles, -1 the reference schedule
+       (gemm_split.hip).  All have the same arithmetic: bit-identical results (parity tests, same-process A/B). */
     int32_t tile_wn;
     /* CONV mode on split-plane input (in_hi / in_lo): rows are input pixels n*H*W + y*W + x, in_ld > N*H*W and row N*H*W of every chunk
        is zero (taps outside the image read it).  Optionally the input channels come from TWO plane buffers (a torch.cat of the

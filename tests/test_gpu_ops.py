@@ -1037,7 +1037,7 @@ PP_CASES = [
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("engine", [-3, -2, 0], ids=["pp", "duo", "auto"])
+@pytest.mark.parametrize("engine", [-3, -2, -4, 0], ids=["pp", "duo", "duo64", "auto"])
 @pytest.mark.parametrize("case", PP_CASES, ids=lambda c: f"{c[0]}_{c[2]}to{c[3]}")
 def test_gemm_pp_matches_reference_schedule(case, engine, dev):
     """gemm_pp.hip (ping-pong wave groups, persistent grid with the DMA ring flowing across tiles, LDS-transposed epilogue) and
