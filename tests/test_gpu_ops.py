@@ -939,7 +939,7 @@ def test_flow_warp_up2_equals_two_launches(hip, dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(2, 40, 96), (1, 37, 44), (3, 8, 4), (1, 136, 256)], ids=lambda s: f"{s[0]}x{s[1]}x{s[2]}")
+@pytest.mark.parametrize("shape", [(2, 40, 96), (1, 37, 44), (3, 8, 4), (1, 136, 256), (1, 1088, 1920)], ids=lambda s: f"{s[0]}x{s[1]}x{s[2]}")
 @pytest.mark.parametrize("amp", [1.5, 9.0, 60.0], ids=["flows~1px", "flows~9px", "flows~60px"])
 def test_tiled_warps_equal_direct_warps(shape, amp, hip, dev):
     """flow_warp / warp_blend with LDS-staged source tiles (atmvfi_flow_warp_tiled, atmvfi_warp_blend_tiled) == the direct-gather kernels,
