@@ -545,6 +545,60 @@ __global__ __launch_bounds__(256) void flow_warp_tiled_kernel(const float* __res
     }
 }
 
+// flow_warp_up2_kernel with the warp half on LDS-staged tiles: workgroups 0 .. ntiles-1 warp one 32 x 8 tile each (as
+// flow_warp_tiled_kernel), the others up-sample the flow (grid-stride over the 2 B x 2H x 2W outputs, the arithmetic of resize_ac_kernel)
+__global__ __launch_bounds__(256) void flow_warp_up2_tiled_kernel(const float* __restrict__ src, const float* __restrict__ flow, float* __restrict__ dst,
+                                                                  float* __restrict__ flow_up, int B, int C, int H, int W, int ntiles) {
+    fp16_saturate_on();
+    __shared__ __attribute__((aligned(16))) float tile[3 * WB_PLANE];
+    __shared__ int bx[4];
+    const long long hw = (long long)H * W;
+    if ((int)blockIdx.x < ntiles) {
+        const int tid = threadIdx.x;
+        int b, x, y;
+        bool live;
+        tile_pixel(H, W, b, x, y, live);
+        const long long pix = (long long)(live ? y : 0) * W + (live ? x : 0);
+        if (tid == 0) box_reset(bx);
+        const float* fp = flow + (long long)b * 2 * hw + pix;
+        const Taps t = make_taps((float)x + fp[0], (float)y + fp[hw], W, H);
+        __syncthreads();
+        box_add(bx, t, live, W, H);
+        __syncthreads();
+        const StagedBox sb = box_get(bx);
+        for (int c0 = 0; c0 < C; c0 += 3) {
+            const int nch = C - c0 < 3 ? C - c0 : 3;
+            const float* sp = src + ((long long)b * C + c0) * hw;
+            if (sb.ok) {
+                if (c0) __syncthreads();
+                box_stage(tile, sp, hw, W, nch, sb, tid);
+                __syncthreads();
+            }
+            if (live)
+                for (int c = 0; c < nch; ++c)
+                    dst[((long long)b * C + c0 + c) * hw + pix] = sb.ok ? sample_tile(tile + c * WB_PLANE, t, sb) : sample_plane(sp + c * hw, t, W);
+        }
+        return;
+    }
+    const int Ho = 2 * H, Wo = 2 * W;
+    const long long ohw = (long long)Ho * Wo;
+    const long long nup = (long long)B * 2 * ohw;
+    const float sh = (float)(H - 1) / (float)(Ho - 1), sw = (float)(W - 1) / (float)(Wo - 1);
+    for (long long e = (long long)(blockIdx.x - ntiles) * blockDim.x + threadIdx.x; e < nup; e += (long long)(gridDim.x - ntiles) * blockDim.x) {
+        const int p = (int)(e / ohw);                    // plane b * 2 + c
+        const long long pix = e - (long long)p * ohw;
+        const int oy = (int)(pix / Wo), ox = (int)(pix - (long long)oy * Wo);
+        const float ry = sh * (float)oy, rx = sw * (float)ox;
+        const int y0 = (int)ry, x0 = (int)rx;
+        const int yp = (y0 < H - 1) ? 1 : 0, xp = (x0 < W - 1) ? 1 : 0;
+        const float ly = ry - (float)y0, lx = rx - (float)x0;
+        const float hy = 1.0f - ly, hx = 1.0f - lx;
+        const float* s = flow + (long long)p * hw + (long long)y0 * W + x0;
+        const float v = hy * (hx * s[0] + lx * s[xp]) + ly * (hx * s[yp * W] + lx * s[yp * W + xp]);
+        flow_up[e] = v * 2.0f;
+    }
+}
+
 __global__ __launch_bounds__(256) void warp_blend_tiled_kernel(const float* __restrict__ im0, const float* __restrict__ im1,
                                                                const float* __restrict__ motion, int motion_ld, long long motion_bstride,
                                                                float* __restrict__ i0w, float* __restrict__ i1w, float* __restrict__ it,
@@ -893,6 +947,18 @@ extern "C" int atmvfi_flow_warp_up2(const float* src, const float* flow, float* 
     hipLaunchKernelGGL(flow_warp_up2_kernel, dim3(grid_for((long long)B * H * W * 9)), dim3(256), 0, (hipStream_t)stream, src, flow, dst, flow_up,
                        B, C, H, W);
     return atmvfi::check_launch("flow_warp_up2");
+}
+
+extern "C" int atmvfi_flow_warp_up2_tiled(const float* src, const float* flow, float* dst, float* flow_up, int B, int C, int H, int W, void* stream) {
+    ATMVFI_REQUIRE(src && flow && dst && flow_up, ATMVFI_EINVAL, "flow_warp_up2_tiled: null pointer");
+    ATMVFI_REQUIRE(B > 0 && C > 0 && H > 1 && W > 1, ATMVFI_EINVAL, "flow_warp_up2_tiled: bad shape (H, W must be > 1)");
+    ATMVFI_REQUIRE(W % 4 == 0 && atmvfi::aligned16(src), ATMVFI_EINVAL, "flow_warp_up2_tiled: W must be a multiple of 4 and src 16-byte aligned (got W = %d)", W);
+    const long long tiles = (long long)B * ((H + WT_H - 1) / WT_H) * ((W + WT_W - 1) / WT_W);
+    const long long upblocks = grid_for((long long)B * H * W * 8);
+    ATMVFI_REQUIRE(tiles + upblocks < (1ll << 31), ATMVFI_EINVAL, "flow_warp_up2_tiled: grid too large");
+    hipLaunchKernelGGL(flow_warp_up2_tiled_kernel, dim3((unsigned)(tiles + upblocks)), dim3(256), 0, (hipStream_t)stream, src, flow, dst, flow_up,
+                       B, C, H, W, (int)tiles);
+    return atmvfi::check_launch("flow_warp_up2_tiled");
 }
 
 extern "C" int atmvfi_flow_warp_nhwc(const float* src, int src_ld, int64_t src_bstride, const float* flow,

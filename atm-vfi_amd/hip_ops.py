@@ -92,6 +92,7 @@ SIGNATURES = {
     "atmvfi_conv3x3_f16x3": (c_i, [c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_l, c_f, c_i, c_i, c_f]),
     "atmvfi_conv3x3_planes": (c_i, [c_f, c_f, c_l, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_l, c_i, c_f, c_i, c_i, c_f]),
     "atmvfi_flow_warp_up2": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
+    "atmvfi_flow_warp_up2_tiled": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     "atmvfi_image_pyramid": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f]),
     "atmvfi_head1x1_planes": (c_i, [c_f, c_f, c_l, c_l, c_i, c_f, c_f, c_i, c_f, c_i, c_f]),
     "atmvfi_conv3x3_planes2": (c_i, [c_f, c_f, c_l, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_l, c_i, c_f, c_f, c_f, c_l, c_i, c_i, c_i, c_f]),
@@ -933,7 +934,8 @@ class HipOps:
                 or tuple(flow_up.shape) != (b, 2, 2 * h, 2 * w)):
             raise ValueError("flow_warp_up2: contiguous src/dst [B,C,H,W], flow [B,2,H,W], flow_up [B,2,2H,2W] expected")
         meta = {"bytes": 4.0 * b * h * w * (2 * c + 2 + 8)}
-        self._run("flow_warp_up2", meta, self.lib.atmvfi_flow_warp_up2, _ptr(src), _ptr(flow), _ptr(dst), _ptr(flow_up), b, c, h, w, self._stream())
+        fn = self.lib.atmvfi_flow_warp_up2_tiled if self._tiled_warp_ok(w, src) else self.lib.atmvfi_flow_warp_up2
+        self._run("flow_warp_up2", meta, fn, _ptr(src), _ptr(flow), _ptr(dst), _ptr(flow_up), b, c, h, w, self._stream())
 
     def flow_warp_nhwc(self, src, flow, dst):
         ld, b, h, w, c = nhwc_view(src, "flow_warp_nhwc.src")

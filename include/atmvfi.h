@@ -335,6 +335,8 @@ int atmvfi_image_pyramid(const float* im0, const float* im1, float* l1, float* l
  * to [B,2,2H,2W] with its values doubled (upsample_flow, network_base.py:11-18) into flow_up, in one launch: one step of the global
  * flow's walk down the image pyramid (network_base.py:468-485).  Bit-identical to atmvfi_flow_warp + atmvfi_resize_bilinear_ac(x2). */
 int atmvfi_flow_warp_up2(const float* src, const float* flow, float* dst, float* flow_up, int B, int C, int H, int W, void* stream);
+/* The same with the warp half on LDS-staged source tiles (atmvfi_flow_warp_tiled): bit-identical; W % 4 == 0, src 16-byte aligned. */
+int atmvfi_flow_warp_up2_tiled(const float* src, const float* flow, float* dst, float* flow_up, int B, int C, int H, int W, void* stream);
 
 /* torch.cat([im0, im1], 0) (network_base.py:451) fused with NCHW -> NHWC4 (4th channel 0). */
 int atmvfi_pack_frames(const float* im0, const float* im1, float* dst /*[2B,H,W,4]*/, int B, int H, int W, void* stream);

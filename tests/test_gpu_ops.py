@@ -923,19 +923,26 @@ def test_conv_from_two_plane_sources(hip, dev):
 
 
 @pytest.mark.gpu
-def test_flow_warp_up2_equals_two_launches(hip, dev):
-    """flow_warp + x2 flow up-sampling in one launch == the two kernels, bit for bit (incl. flows that leave the image)."""
+@pytest.mark.parametrize("shape", [(2, 3, 17, 29), (2, 3, 17, 28), (1, 3, 68, 120), (1, 5, 34, 60)], ids=lambda s: "x".join(map(str, s)))
+def test_flow_warp_up2_equals_two_launches(shape, hip, dev):
+    """flow_warp + x2 flow up-sampling in one launch == the two kernels, bit for bit (incl. flows that leave the image); with W a
+    multiple of 4 the launch is the LDS-staged form (atmvfi_flow_warp_up2_tiled), which must equal the direct one as well."""
     g = torch.Generator().manual_seed(99)
-    b, c, h, w = 2, 3, 17, 29
+    b, c, h, w = shape
     src = torch.rand(b, c, h, w, generator=g).to(dev)
     flow = ((torch.rand(b, 2, h, w, generator=g) - 0.5) * 12).to(dev)
     flow[0, :, 0, 0] = 1e6
+    flow[0, :, h // 2:, : w // 2] *= 8.0            # a region whose flows leave the staged box
+    hip.warp_tiles = False
     d0, u0 = torch.empty_like(src), torch.empty(b, 2, 2 * h, 2 * w, device=dev)
-    d1, u1 = torch.full_like(src, 3.0), torch.full((b, 2, 2 * h, 2 * w), 3.0, device=dev)
     hip.flow_warp(src, flow, d0); hip.resize(flow, u0, 2.0)
-    hip.flow_warp_up2(src, flow, d1, u1)
-    torch.cuda.synchronize()
-    assert torch.equal(d0, d1) and torch.equal(u0, u1)
+    for tiles in (False, True):
+        hip.warp_tiles = tiles
+        d1, u1 = torch.full_like(src, 3.0), torch.full((b, 2, 2 * h, 2 * w), 3.0, device=dev)
+        hip.flow_warp_up2(src, flow, d1, u1)
+        torch.cuda.synchronize()
+        assert torch.equal(d0, d1) and torch.equal(u0, u1), f"tiles={tiles}"
+    hip.warp_tiles = True
 
 
 @pytest.mark.gpu
