@@ -31,6 +31,8 @@ import time
 import numpy as np
 import torch
 
+_REAL_STDOUT = sys.stdout          # main() replaces it by a private copy of file descriptor 1 (see there)
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for _p in (ROOT, os.path.join(ROOT, "tests")):
     if _p not in sys.path:
@@ -165,10 +167,12 @@ def dry_run(args, dist):
         assert t.item() == world
         dist.barrier()
         dist.destroy_process_group()
+    if os.environ.get("ATMVFI_BENCH_DRY_NOISE") == "1":                  # (launcher self-test) what RCCL's version banner does
+        os.write(1, b"noise written to file descriptor 1 by a native library\n")
     print(f"rank {rank} of {world}: rendezvous at {os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')} ok", flush=True)
     if rank == 0:
         print(json.dumps({"metric": "dry-run (launcher self-test, nothing measured)", "value": None, "n_gpus": world,
-                          "steps": args.steps, "warmup": args.warmup}), flush=True)
+                          "steps": args.steps, "warmup": args.warmup}), file=_REAL_STDOUT, flush=True)
 
 
 def main():
@@ -176,6 +180,13 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (read when the runtime starts): RCCL's intra-node transport needs it
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(self_launch(args))
+    # Rank 0's stdout carries ONE JSON line and nothing else.  Native libraries write there too (RCCL prints a five-line version banner to
+    # file descriptor 1 when its communicator starts), so descriptor 1 is pointed at stderr for the run and the line goes out through a saved
+    # copy of the real stdout at the end.
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     import torch.distributed as dist
 
     if args.dry_run:
@@ -428,7 +439,7 @@ def main():
                                                 f"{med:.2f} s per forward (runs {', '.join(f'{t:.2f}' for t in runs)})"}
         if collective:
             result["collective_backend"] = dist.get_backend()
-        print(json.dumps(result), flush=True)
+        print(json.dumps(result), file=_REAL_STDOUT, flush=True)
     if collective:
         dist.barrier()                      # rank 0's instrumented pass is over: nobody tears the communicator down under it
         dist.destroy_process_group()

@@ -336,6 +336,23 @@ def test_bench_launcher_reports_a_failed_rank():
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
 
 
+def test_bench_stdout_is_one_json_line_whatever_native_code_prints():
+    """Rank 0's stdout must be exactly one JSON line: RCCL writes a version banner to file descriptor 1 when its communicator starts
+    (seen on the GPU box), so bench.py points descriptor 1 at stderr and prints through a saved copy.  Direct form and self-launch."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, ATMVFI_BENCH_DRY_NOISE="1")
+    env.pop("WORLD_SIZE", None)
+    for argv in (["--dry-run"], ["--dry-run", "--gpus", "2"]):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.strip()]
+        assert len(lines) == 1, r.stdout
+        assert json.loads(lines[0])["n_gpus"] == (2 if "--gpus" in argv else 1)
+        assert "noise written to file descriptor 1" in r.stderr
+
+
 def test_bench_single_rank_does_not_spawn_and_rejects_a_wrong_world():
     r = _bench("--gpus", "1", "--dry-run")
     assert r.returncode == 0 and "torch.distributed.run" not in r.stderr and r.stdout.count('"metric"') == 1
