@@ -4,6 +4,7 @@
  (3) size-independent properties at full size (run-to-run determinism, per-pair independence).
 Tolerance is the north star's: max|d| <= 1e-3 per pixel on fp32 ``I_t``."""
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -402,6 +403,34 @@ def test_frame_cache_is_exact_and_video_distributed_single_rank(nets, dev):
         got = list(host_io.interpolate_video_2x_distributed(frames, net, 0, 1, block=2))
         assert len(got) == len(want) == 11 and all(np.array_equal(p, q) for p, q in zip(got, want)), g
     net.global_motion = True
+
+
+def test_video_distributed_under_rccl_one_rank(nets, dev):
+    """interpolate_video_2x_distributed under a real RCCL communicator (one rank: what a one-GPU box can exercise): sharding.HostGather's
+    all-gather on its side stream and the pinned host copies must reproduce interpolate_video_2x frame for frame."""
+    import socket
+    import torch.distributed as dist
+    if dist.is_initialized():
+        pytest.skip("a process group is already initialised in this process")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    net = nets["lite"]
+    net.global_motion, net.ensemble_global_motion = True, False
+    rng = np.random.default_rng(3)
+    frames = [rng.integers(0, 256, (270, 480, 3), dtype=np.uint8) for _ in range(7)]
+    ref = list(host_io.interpolate_video_2x(frames, net))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        for block in (1, 3):
+            got = list(host_io.interpolate_video_2x_distributed(frames, net, rank=0, world=1, block=block))
+            assert len(got) == len(ref) == 13
+            assert all(np.array_equal(a, b) for a, b in zip(got, ref)), f"block {block}"
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
 
 
 def test_flip_tta_on_the_hip_path(nets, dev, weights):
