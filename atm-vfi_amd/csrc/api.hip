@@ -25,5 +25,9 @@ int check_launch(const char* what) {
 
 }  // namespace atmvfi
 
-extern "C" int atmvfi_version(void) { return (0 << 16) | (7 << 8) | 0; }   // 0.7: atmvfi_window_attention_f16x3, compact fp32 view behind out_cmin of the 3x3 plane kernel, saturating conversions by MODE.FP16_OVFL; 0.6: 3x3 kernel on split-plane input, plane sinks and CONV mode of the LDS-DMA GEMM, per-call instance overrides (no process-wide state); 0.5: plane sink of the 3x3 kernel; 0.4: split-plane sinks, k-step-major planes, uint8 frame kernels
+extern "C" int atmvfi_version(void) { return (0 << 16) | (8 << 8) | 0; }   // 0.8: atmvfi_source_digest; 0.7: atmvfi_window_attention_f16x3, compact fp32 view behind out_cmin of the 3x3 plane kernel, saturating conversions by MODE.FP16_OVFL; 0.6: 3x3 kernel on split-plane input, plane sinks and CONV mode of the LDS-DMA GEMM, per-call instance overrides (no process-wide state); 0.5: plane sink of the 3x3 kernel; 0.4: split-plane sinks, k-step-major planes, uint8 frame kernels
 extern "C" const char* atmvfi_last_error(void) { return atmvfi::g_err; }
+#ifndef ATMVFI_SOURCE_DIGEST
+#define ATMVFI_SOURCE_DIGEST "unknown (api.hip compiled outside the Makefile)"
+#endif
+extern "C" const char* atmvfi_source_digest(void) { return ATMVFI_SOURCE_DIGEST; }

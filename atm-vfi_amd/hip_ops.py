@@ -77,6 +77,7 @@ class PlanPatch(ctypes.Structure):
 SIGNATURES = {
     "atmvfi_version": (c_i, []),
     "atmvfi_last_error": (ctypes.c_char_p, []),
+    "atmvfi_source_digest": (ctypes.c_char_p, []),
     "atmvfi_gemm": (c_i, [ctypes.POINTER(GemmParams), c_f]),
     "atmvfi_split_planes": (c_i, [c_f, c_i, c_l, c_i, c_f, c_f, c_f, c_i, c_f]),
     "atmvfi_split_planes_at": (c_i, [c_f, c_i, c_l, c_i, c_f, c_f, c_f, c_i, c_i, c_i, c_f]),
@@ -219,8 +220,20 @@ class Planes:
         return Planes(torch.zeros(2, (c + 31) // 32, rows + 1, 32, dtype=torch.float16, device=device), c, rows)
 
 
-def _ptr(t: Optional[torch.Tensor]):
-    return None if t is None else ctypes.c_void_p(t.data_ptr())
+class TPtr(ctypes.c_void_p):
+    """A device pointer that remembers the tensor it was derived from (``src``).  Launch plans classify pointer arguments by that tensor
+    -- per-call memory or workspace -- never by what allocation the raw address happens to fall into: a biased or one-past-the-end
+    pointer (the compact fp32 view of the 3x3 plane kernel passes ``buffer - 4 * out_cmin``) lies inside a NEIGHBOURING allocation."""
+    __slots__ = ("src",)
+
+
+def _ptr(t: Optional[torch.Tensor], byte_offset: int = 0):
+    """-> ``TPtr`` of ``t.data_ptr() + byte_offset`` (None for a missing optional tensor)."""
+    if t is None:
+        return None
+    p = TPtr(t.data_ptr() + byte_offset)
+    p.src = t
+    return p
 
 
 def _chk(t: torch.Tensor, what: str):
@@ -290,32 +303,56 @@ class LaunchPlan:
         self.lib = lib
         self.ops_list = []                 # (fn id, [values], [is_float])
         self.keep = []                     # parameter blocks referenced by address
-        self.slots = [(t.data_ptr(), t.numel() * t.element_size()) for t in inputs]     # (base, bytes): inputs first, then outputs
+        self.slots = []                    # (base, bytes): inputs first, then outputs
+        self._slot_store = []              # per slot: address of the storage the slot's tensor lives in
+        for t in inputs:
+            self._add_slot(t)
+        for i in range(len(self.slots)):
+            for j in range(i):
+                (bi, ni), (bj, nj) = self.slots[i], self.slots[j]
+                if bi < bj + nj and bj < bi + ni:
+                    raise PlanUnsupported("the input frames overlap in memory: a pointer into one could not be told from a pointer into the other")
         self.n_inputs = len(inputs)
+        self.align = tuple(t.data_ptr() & 15 for t in inputs)      # kernel choices (16-byte row loads) were made for this alignment
         self.out_meta = []                 # (shape, dtype) per output slot, allocation order
         self.out_tensors = []              # the recording call's own outputs (kept alive until end_plan)
         self.patches = []
         self.template = None               # result structure with ("slot", k) leaves
         self.c_ops = self.c_patches = self.c_slots = None
         self._fn_ids = {}
+        self.by_tensor = self.by_address = 0      # pointer arguments classified per-call by their tensor / refused by raw address
 
     # ---- recording ----
+    def _add_slot(self, t: torch.Tensor):
+        self.slots.append((t.data_ptr(), t.numel() * t.element_size()))
+        self._slot_store.append(t.untyped_storage().data_ptr())
+
     def _slot_of(self, ptr: int):
+        """The slot whose byte range holds the raw address ``ptr`` (assertions and untyped parameter-block fields only)."""
         for k, (base, nb) in enumerate(self.slots):
             if base <= ptr < base + nb:
                 return k, ptr - base
         return None
 
+    def _slot_of_tensor(self, t: torch.Tensor):
+        """The slot a tensor belongs to: same storage AND the tensor starts inside the slot's bytes (two inputs may be slices of one
+        stacked tensor).  None: the tensor is workspace / parameter memory, whatever its neighbours in the address space are."""
+        st = t.untyped_storage().data_ptr()
+        p = t.data_ptr()
+        for k, (base, nb) in enumerate(self.slots):
+            if self._slot_store[k] == st and base <= p < base + max(nb, 1):
+                return k
+        return None
+
     def add_output(self, t: torch.Tensor):
-        self.slots.append((t.data_ptr(), t.numel() * t.element_size()))
+        self._add_slot(t)
         self.out_meta.append((tuple(t.shape), t.dtype))
         self.out_tensors.append(t)
 
-    def add_op(self, fn, args, ptr_bases=None):
-        """``ptr_bases``: {argument index: address of the tensor the argument belongs to} for pointer arguments that do not point INTO
-        their tensor (the compact fp32 view of the 3x3 plane kernel passes ``buffer - 4 * out_cmin``: an address inside whatever
-        allocation happens to sit in front of the buffer -- classified by its raw value it became a per-call pointer whenever that
-        neighbour was one of the recording's output tensors, and every replay then wrote the map into a fresh output's tail)."""
+    def add_op(self, fn, args):
+        """Pointer arguments are ``TPtr`` (hip_ops._ptr): the tensor they were derived from decides whether they are per-call
+        pointers (patched on replay, offset relative to the slot's base -- it may be negative or past the end) or fixed ones.  A
+        pointer WITHOUT a tensor (a raw integer) must not lie in per-call memory: the plan refuses it rather than guess."""
         name = fn.__name__
         fid = self._fn_ids.get(name)
         if fid is None:
@@ -335,20 +372,28 @@ class LaunchPlan:
                 continue
             if hasattr(v, "_obj"):         # ctypes.byref(parameter block): referenced by address, kept alive with the plan
                 blk = v._obj
+                for t in getattr(blk, "_srcs", ()):                 # the tensors its pointer fields were taken from (by tensor first)
+                    if isinstance(t, torch.Tensor) and self._slot_of_tensor(t) is not None:
+                        raise PlanUnsupported(f"{name}: a parameter-block operand lives in per-call memory")
                 for fname, ftype in blk._fields_:
                     if ftype is c_f and getattr(blk, fname) and self._slot_of(getattr(blk, fname)) is not None:
                         raise PlanUnsupported(f"{name}: parameter block field {fname} points into per-call memory")
                 self.keep.append(blk)
                 vals.append(("u", ctypes.addressof(blk)))
                 continue
+            src = getattr(v, "src", None) if isinstance(v, TPtr) else None
             if isinstance(v, ctypes.c_void_p):
                 v = v.value
             v = 0 if v is None else int(v)
             if ty is c_f and v:
-                base = v if not ptr_bases or j not in ptr_bases else ptr_bases[j]
-                hit = self._slot_of(base)
-                if hit is not None:
-                    self.patches.append((k, j, hit[0], hit[1] + (v - base)))
+                if src is not None:
+                    slot = self._slot_of_tensor(src)
+                    if slot is not None:
+                        self.patches.append((k, j, slot, v - self.slots[slot][0]))
+                        self.by_tensor += 1
+                elif self._slot_of(v) is not None:
+                    self.by_address += 1
+                    raise PlanUnsupported(f"{name}: argument {j} is a raw address inside per-call memory with no tensor to attribute it to")
             vals.append(("u" if v >= 0 else "i", v))
         self.ops_list.append((fid, vals))
 
@@ -385,8 +430,13 @@ class LaunchPlan:
         return self
 
     # ---- replay ----
-    def run(self, inputs, device, stream):
+    def run(self, inputs, device, stream, poison: bool = False):
+        """``poison``: fill the fresh outputs with NaN first (the record-time self-check: an element the replay does not write, or
+        writes somewhere else, then differs from the recording forward's result)."""
         outs = [torch.empty(shape, dtype=dt, device=device) for shape, dt in self.out_meta]
+        if poison:
+            for t in outs:
+                t.fill_(float("nan"))
         sl = self.c_slots
         for k, t in enumerate(inputs):
             sl[k] = t.data_ptr()
@@ -466,7 +516,7 @@ class HipOps:
 
     def _run(self, name: str, meta: dict, fn, *args):
         if self.recording is not None:
-            self.recording.add_op(fn, args, meta.get("ptr_bases"))
+            self.recording.add_op(fn, args)
         if self.profile is None:
             self._check(fn(*args), name)
             return
@@ -575,7 +625,7 @@ class HipOps:
                 raise ValueError("conv: planes_prelu must be padded to a multiple of 32 channels")
             self._run("conv3x3_f16x3", meta, self.lib.atmvfi_conv3x3_f16x3, _ptr(x), ld, n, h, wd, cin, _ptr(w.hi3), _ptr(w.lo3),
                       cout, _ptr(out), old, _ptr(bias), _ptr(prelu),
-                      planes.t[0].data_ptr() if planes is not None else None, planes.t[1].data_ptr() if planes is not None else None,
+                      _ptr(planes.t[0]) if planes is not None else None, _ptr(planes.t[1]) if planes is not None else None,
                       planes.ld_rows if planes is not None else 0, _ptr(planes_prelu) if planes is not None else None,
                       *(self.conv3_instance or (-1, 0)), self._stream())
             return
@@ -588,6 +638,7 @@ class HipOps:
         p.precision, p.weight_hi, p.weight_lo = self._prec(w)
         p.tile_wn = self.gemm_tile_wn
         self._gemm_sink(p, planes, n * oh * ow, cout, planes_c0, 0, 1, "conv")
+        p._srcs = (x, out, bias, prelu, in_prelu)
         self._run("conv2d_f16x3" if p.precision else "conv2d", meta, self.lib.atmvfi_conv2d, ctypes.byref(p), self._stream())
 
     def pack_stem(self, w1, b1, p1, w2, b2, p2, w3, b3, p3) -> "StemWeights":
@@ -637,7 +688,7 @@ class HipOps:
         meta = {"flops": flops, "bytes": 16.0 * f * h * wd + 4.0 * out.rows * out.chunks * 32, "shape": f"{f}x{h}x{wd} 3>{w.c0}>{w.c0}>{w.c1}s2"}
         self._run("stem_fused", meta, self.lib.atmvfi_stem_fused, _ptr(x), f, h, wd, w.c0, w.c1, _ptr(w.w1h), _ptr(w.w1l), _ptr(w.b1), _ptr(w.p1),
                   _ptr(w.w2h), _ptr(w.w2l), _ptr(w.b2), _ptr(w.p2), _ptr(w.w3h), _ptr(w.w3l), _ptr(w.b3), _ptr(w.p3),
-                  out.t[0].data_ptr(), out.t[1].data_ptr(), out.ld_rows, self._stream())
+                  _ptr(out.t[0]), _ptr(out.t[1]), out.ld_rows, self._stream())
 
     def conv3x3_planes(self, x: Planes, n: int, h: int, wd: int, w: PackedWeight, out=None, bias=None, prelu=None,
                        planes: Optional[Planes] = None, planes_c0: int = 0, planes_prelu=None, in_chunk0: int = 0, cin: Optional[int] = None,
@@ -657,14 +708,12 @@ class HipOps:
         cout = w.cout
         old = 0
         out_ptr = _ptr(out)
-        compact_base = None
         if out is not None:
             old, on, oh, ow, oc = nhwc_view(out, "conv3x3_planes.out")
             if (on, oh, ow) == (n, h, wd) and oc == cout - out_cmin and out_cmin > 0:
                 # compact view of just the stored channels [out_cmin, cout): the kernel never touches columns below out_cmin, so the
                 # base may point that many floats in front of the buffer (out_cmin % 4 == 0 keeps the 16-byte alignment)
-                out_ptr = ctypes.c_void_p(out.data_ptr() - 4 * out_cmin)
-                compact_base = out.data_ptr()
+                out_ptr = _ptr(out, -4 * out_cmin)       # a pointer IN FRONT of its buffer: attributed to `out` by the TPtr, never by its address
             elif (on, oh, ow, oc) != (n, h, wd, cout):
                 raise ValueError(f"conv3x3_planes: out {tuple(out.shape)} != [{n},{h},{wd},{cout}] (or {cout - out_cmin} channels: compact)")
         elif planes is None:
@@ -678,14 +727,12 @@ class HipOps:
             raise ValueError(f"conv3x3_planes: second plane sink [{planes2.rows},{planes2.c}] needs the first one and room for {cout} channels at {planes2_c0}")
         meta = {"flops": 2.0 * n * h * wd * cout * cin * 9, "bytes": 4.0 * (n * h * wd * (cin + cout) + cout * cin * 9),
                 "shape": f"M{n * h * wd} N{cout} K{cin * 9}"}
-        if compact_base is not None:
-            meta["ptr_bases"] = {10: compact_base}      # argument 10 = out: it points 4 * out_cmin bytes in front of its buffer
         coff = in_chunk0 * x.ld_rows * 32 * 2       # bytes
-        self._run("conv3x3_planes", meta, self.lib.atmvfi_conv3x3_planes2, x.t[0].data_ptr() + coff, x.t[1].data_ptr() + coff, x.ld_rows,
+        self._run("conv3x3_planes", meta, self.lib.atmvfi_conv3x3_planes2, _ptr(x.t[0], coff), _ptr(x.t[1], coff), x.ld_rows,
                   n, h, wd, cin, _ptr(w.hi3), _ptr(w.lo3), cout, out_ptr, old, _ptr(bias), _ptr(prelu),
-                  planes.t[0].data_ptr() if planes is not None else None, planes.t[1].data_ptr() if planes is not None else None,
+                  _ptr(planes.t[0]) if planes is not None else None, _ptr(planes.t[1]) if planes is not None else None,
                   planes.ld_rows if planes is not None else 0, planes_c0, _ptr(planes_prelu) if planes is not None else None,
-                  planes2.t[0].data_ptr() if planes2 is not None else None, planes2.t[1].data_ptr() if planes2 is not None else None,
+                  _ptr(planes2.t[0]) if planes2 is not None else None, _ptr(planes2.t[1]) if planes2 is not None else None,
                   planes2.ld_rows if planes2 is not None else 0, planes2_c0, out_cmin, wn, self._stream())
 
     def head1x1_planes(self, x: Planes, n: int, h: int, wd: int, w: PackedWeight, out, bias=None):
@@ -697,8 +744,8 @@ class HipOps:
         if not wt.is_contiguous():
             wt = wt.contiguous()
         meta = {"flops": 2.0 * n * h * wd * w.cout * w.cin, "bytes": 4.0 * n * h * wd * (w.cin + w.cout), "shape": f"M{n * h * wd} N{w.cout} K{w.cin}"}
-        self._run("head1x1_planes", meta, self.lib.atmvfi_head1x1_planes, x.t[0].data_ptr(), x.t[1].data_ptr(), x.ld_rows, n * h * wd, w.cin,
-                  wt.data_ptr(), _ptr(bias), w.cout, out.data_ptr(), old, self._stream())
+        self._run("head1x1_planes", meta, self.lib.atmvfi_head1x1_planes, _ptr(x.t[0]), _ptr(x.t[1]), x.ld_rows, n * h * wd, w.cin,
+                  _ptr(wt), _ptr(bias), w.cout, _ptr(out), old, self._stream())
 
     def conv_planes(self, x: Planes, n: int, h: int, wd: int, w: PackedWeight, out=None, stride=1, pad=1, dil=1, bias=None, prelu=None,
                     sink: Optional[Planes] = None, sink_c0: int = 0, in_chunk0: int = 0, x2: Optional[Planes] = None, x2_chunk0: int = 0,
@@ -740,6 +787,7 @@ class HipOps:
         self._gemm_sink(p, sink, n * oh * ow, cout, sink_c0, 0, 1, "conv_planes")
         meta = {"flops": 2.0 * n * oh * ow * cout * cin * w.kh * w.kw, "bytes": 4.0 * (n * h * wd * cin + n * oh * ow * cout + cout * cin * w.kh * w.kw),
                 "shape": f"M{n * oh * ow} N{cout} K{cin * w.kh * w.kw}"}
+        p._srcs = (out, bias, prelu)
         self._run("conv2d_split", meta, self.lib.atmvfi_conv2d, ctypes.byref(p), self._stream())
 
     def deconv(self, x, w: PackedWeight, out, bias=None, prelu=None, in_prelu=None, planes: Optional[Planes] = None,
@@ -781,6 +829,7 @@ class HipOps:
             p.in_hi, p.in_lo = planes.t[0].data_ptr(), planes.t[1].data_ptr()
         meta = {"flops": 2.0 * n * h * wd * 4 * cout * cin, "bytes": 4.0 * (n * h * wd * cin + n * oh * ow * cout + 4 * cout * cin),
                 "shape": f"M{n * h * wd} N{4 * cout} K{cin}"}
+        p._srcs = (x, out, bias, prelu, in_prelu)
         self._run("deconv2x2_split" if use_planes else "deconv2x2_f16x3" if p.precision else "deconv2x2", meta, self.lib.atmvfi_deconv2x2,
                   ctypes.byref(p), self._stream())
 
@@ -796,11 +845,11 @@ class HipOps:
             raise ValueError("split_planes: prelu needs one slope per channel")
         meta = {"bytes": 4.0 * m * c + 4.0 * m * ((c + 31) // 32 * 32 if c0 is None else (c + 7) // 8 * 8)}
         if c0 is None:
-            self._run("split_planes", meta, self.lib.atmvfi_split_planes, _ptr(x), ld, m, c, _ptr(prelu), out.t[0].data_ptr(),
-                      out.t[1].data_ptr(), out.ld_rows, self._stream())
+            self._run("split_planes", meta, self.lib.atmvfi_split_planes, _ptr(x), ld, m, c, _ptr(prelu), _ptr(out.t[0]),
+                      _ptr(out.t[1]), out.ld_rows, self._stream())
         else:
-            self._run("split_planes", meta, self.lib.atmvfi_split_planes_at, _ptr(x), ld, m, c, _ptr(prelu), out.t[0].data_ptr(),
-                      out.t[1].data_ptr(), out.ld_rows, c0, 8, self._stream())
+            self._run("split_planes", meta, self.lib.atmvfi_split_planes_at, _ptr(x), ld, m, c, _ptr(prelu), _ptr(out.t[0]),
+                      _ptr(out.t[1]), out.ld_rows, c0, 8, self._stream())
 
     def linear(self, x, w: PackedWeight, out, bias=None, residual=None, out_row_map=None, sink: Optional[Planes] = None,
                sink_c0: int = 0, sink_gc: int = 0):
@@ -836,6 +885,7 @@ class HipOps:
         if sink is not None:
             self._gemm_sink(p, sink, orpg if orpg else mo, cout, sink_c0, sink_gc, (mo // orpg) if orpg else 1, "linear")
         meta = {"flops": 2.0 * m * cout * cin, "bytes": 4.0 * (m * cin + m * cout + cout * cin), "shape": f"M{m} N{cout} K{cin}"}
+        p._srcs = (None if planes is not None else x, out, bias, residual, out_row_map)
         self._run("linear_split" if planes is not None else "linear_f16x3" if p.precision else "linear", meta, self.lib.atmvfi_linear, ctypes.byref(p), self._stream())
 
     # ------------------------------------------------------------- transformer
@@ -846,7 +896,7 @@ class HipOps:
             return None, None, 0
         if planes.rows != rows or planes.c != c:
             raise ValueError(f"{what}: planes hold {planes.rows} x {planes.c}, kernel writes {rows} x {c}")
-        return planes.t[0].data_ptr(), planes.t[1].data_ptr(), planes.ld_rows
+        return _ptr(planes.t[0]), _ptr(planes.t[1]), planes.ld_rows
 
     def layernorm(self, x, out, gamma, beta, src_row_map=None, planes: Optional[Planes] = None):
         """``out`` (fp32 rows) may be None when only the split planes are wanted."""
@@ -962,7 +1012,11 @@ class HipOps:
             if (pb, ph, pw, pc) != (b, h, w, 15):
                 raise ValueError("warp_blend: pack15 view must be [B,H,W,15]")
             _planar(orig0, 3, "warp_blend.orig0"); _planar(orig1, 3, "warp_blend.orig1")
-        meta = {"bytes": 4.0 * b * h * w * (6 + 5 + 9)}
+        # algorithmic bytes per pixel: two 3-channel sources + 5 motion channels read, three 3-channel frames written; the finest
+        # level also writes the two flows and two masks (6 floats) and -- for the refiner -- reads the two original frames (6) and
+        # writes the 15-channel pack (fp32 NHWC, or 16 channels of split planes at the same 4 bytes per element)
+        per_px = 6 + 5 + 9 + (6 if flow0 is not None else 0) + ((6 + 15) if pack15 is not None else 0) + ((6 + 16) if pack_planes is not None else 0)
+        meta = {"bytes": 4.0 * b * h * w * per_px}
         if pack_planes is not None:
             if pack_planes.rows != b * h * w or pack_c0 % 4 or pack_c0 + 16 > pack_planes.chunks * 32:
                 raise ValueError("warp_blend: the plane sink must hold B*H*W rows and 16 channels at the offset")
@@ -970,8 +1024,8 @@ class HipOps:
         fn = self.lib.atmvfi_warp_blend_tiled if self._tiled_warp_ok(w, im0, im1) else self.lib.atmvfi_warp_blend_planes
         self._run("warp_blend", meta, fn, _ptr(im0), _ptr(im1), _ptr(motion), mld, motion.stride(0),
                   _ptr(i0w), _ptr(i1w), _ptr(it), _ptr(flow0), _ptr(flow1), _ptr(mask1), _ptr(mask2), _ptr(orig0), _ptr(orig1),
-                  _ptr(pack15), pld, pack_planes.t[0].data_ptr() if pack_planes is not None else None,
-                  pack_planes.t[1].data_ptr() if pack_planes is not None else None,
+                  _ptr(pack15), pld, _ptr(pack_planes.t[0]) if pack_planes is not None else None,
+                  _ptr(pack_planes.t[1]) if pack_planes is not None else None,
                   pack_planes.ld_rows if pack_planes is not None else 0, pack_c0, b, h, w, self._stream())
 
     def resize(self, src, dst, value_scale=1.0):
@@ -1003,7 +1057,7 @@ class HipOps:
             raise ValueError("frame_u8_to_f32: destination must be a contiguous CUDA fp32 [3,Hp,Wp] tensor")
         h, w = src_u8.shape[:2]
         self._run("frame_u8_to_f32", {"bytes": 3.0 * h * w + 12.0 * dst.shape[1] * dst.shape[2]}, self.lib.atmvfi_frame_u8_to_f32,
-                  src_u8.data_ptr(), h, w, int(bgr), _ptr(dst), dst.shape[1], dst.shape[2], pad_top, pad_left, self._stream())
+                  _ptr(src_u8), h, w, int(bgr), _ptr(dst), dst.shape[1], dst.shape[2], pad_top, pad_left, self._stream())
 
     def frame_f32_to_u8(self, src, dst_u8, pad_top: int, pad_left: int, bgr: bool):
         """fp32 planar [3,Hp,Wp] -> crop -> np.round(x * 255) -> uint8 [H,W,3] device tensor (optional RGB -> BGR)."""
@@ -1013,7 +1067,7 @@ class HipOps:
             raise ValueError("frame_f32_to_u8: destination must be a contiguous CUDA uint8 [H,W,3] tensor")
         h, w = dst_u8.shape[:2]
         self._run("frame_f32_to_u8", {"bytes": 3.0 * h * w + 12.0 * h * w}, self.lib.atmvfi_frame_f32_to_u8, _ptr(src), src.shape[1],
-                  src.shape[2], pad_top, pad_left, dst_u8.data_ptr(), h, w, int(bgr), self._stream())
+                  src.shape[2], pad_top, pad_left, _ptr(dst_u8), h, w, int(bgr), self._stream())
 
     def pack_frames(self, im0, im1, dst):
         _planar(im0, 3, "pack_frames.im0"); _planar(im1, 3, "pack_frames.im1")

@@ -35,9 +35,33 @@ from .windows import WindowGeometry, build_window_geometry
 
 
 _VERSION_OF = operator.attrgetter("_version")
+_DATA_PTR_OF = torch.Tensor.data_ptr
 
 
-class _Node(nn.Module):
+_PARAM_EPOCH = [0]       # bumped whenever a Parameter OBJECT is (re)assigned, registered or deleted on any _Node / Network
+
+
+class _ParamWatch:
+    """Mixin: replacing a parameter object (``module.weight = nn.Parameter(...)``, ``register_parameter``, pruning or
+    re-parametrisation hooks, ``del module.weight``) bumps ``_PARAM_EPOCH``, which ``Network._param_sig`` compares on every forward:
+    its cached parameter list would otherwise keep the OLD objects and the packed weights, plans and graphs would stay stale."""
+
+    def __setattr__(self, name, value):
+        if isinstance(value, nn.Parameter) or name in self.__dict__.get("_parameters", ()):
+            _PARAM_EPOCH[0] += 1
+        super().__setattr__(name, value)
+
+    def __delattr__(self, name):
+        if name in self.__dict__.get("_parameters", ()):
+            _PARAM_EPOCH[0] += 1
+        super().__delattr__(name)
+
+    def register_parameter(self, name, param):
+        _PARAM_EPOCH[0] += 1
+        super().register_parameter(name, param)
+
+
+class _Node(_ParamWatch, nn.Module):
     """Anonymous container used to reproduce the reference's dotted parameter names."""
 
 
@@ -144,7 +168,7 @@ class BlockRunner:
             ops.linear(f2.reshape(frames * h * w, hid), P[f"pk:{p}.mlp.fc2.weight"], out, bias=P[f"{p}.mlp.fc2.bias"], residual=xb)
 
 
-class Network(BlockRunner, nn.Module):
+class Network(_ParamWatch, BlockRunner, nn.Module):
     VARIANT = "base"
 
     def __init__(self, global_motion: bool = True, ensemble_global_motion: bool = False, variant: Optional[str] = None):
@@ -213,8 +237,8 @@ class Network(BlockRunner, nn.Module):
         self.use_plans = os.environ.get("ATMVFI_PLANS", "1") != "0"
         self._plans: Dict[Tuple, object] = {}       # key -> LaunchPlan | int (eager forwards seen so far) | False (cannot be planned)
         self._plan_sig = None
-        self._plist = None                          # cached parameter list of the O(1)-per-parameter version check
-        self._pcheck = 0
+        self._plist = None                          # cached parameter list of the per-forward currency check (_param_sig)
+        self._pepoch = -1
 
     # ------------------------------------------------------------------ API parity
     def __set_local_window_size__(self, window_size):       # network_base.py:262-265
@@ -357,21 +381,16 @@ class Network(BlockRunner, nn.Module):
         self._prepared_sig = None
 
     def _param_sig(self):
-        """Cheap per-forward check that the packed weights are current: the version counters of the cached parameter list (every
-        in-place update bumps one: 19 us for the 236 entries; walking ``named_parameters()`` and reading the storage pointers too
-        cost 330 us per forward, 15-20 % of a small frame's step).  The storage pointers are compared on every 32nd call and after
-        ``_apply`` / ``load_state_dict`` (which drop the cached list)."""
+        """Per-forward check that the packed weights are current, ~40 us for the 236 entries: (1) the parameter OBJECTS are the cached
+        ones (``_PARAM_EPOCH``: any assignment / registration / deletion of a Parameter on a sub-module re-walks the tree); (2) their
+        storage pointers (``p.data = ...`` swaps); (3) their version counters (every in-place update through the parameter bumps
+        one).  What nothing sees: writes through ``p.data`` (``p.data.add_()`` has a version counter of its own) --
+        ``invalidate_weights()`` is for those."""
         pl = self._plist
-        if pl is None:
+        if pl is None or self._pepoch != _PARAM_EPOCH[0]:
+            self._pepoch = _PARAM_EPOCH[0]
             pl = self._plist = [p for _, p in self.named_parameters()]
-            self._pptrs = tuple(p.data_ptr() for p in pl)
-            self._pcheck = 0
-        self._pcheck += 1
-        if self._pcheck & 31 == 0:
-            ptrs = tuple(p.data_ptr() for p in pl)
-            if ptrs != self._pptrs:
-                self._pptrs = ptrs
-        return (self._pptrs, tuple(map(_VERSION_OF, pl)))
+        return (tuple(map(_DATA_PTR_OF, pl)), tuple(map(_VERSION_OF, pl)), tuple(map(id, pl)))
 
     def _prepare(self, ops):
         sig = self._param_sig()
@@ -745,7 +764,8 @@ class Network(BlockRunner, nn.Module):
         return (tuple(im0.shape), tuple(im1.shape), str(im0.device), self.global_motion, self.ensemble_global_motion,
                 self._precision, self.use_split_planes, self.use_plane_convs, self.use_unet_planes, self.use_plane_deconvs,
                 self.use_fused_stem, getattr(ops, "attention_f16x3", None), self.local_motion_args["window_size"],
-                self.global_motion_args["window_size"], self._workspace_key(im0))
+                self.global_motion_args["window_size"], getattr(ops, "warp_tiles", None), getattr(ops, "conv3_instance", None),
+                getattr(ops, "gemm_tile_wn", None), self._workspace_key(im0))
 
     def forward(self, im0: torch.Tensor, im1: torch.Tensor, reuse_first: bool = False):
         self._reuse_first = bool(reuse_first)
@@ -776,17 +796,35 @@ class Network(BlockRunner, nn.Module):
         with torch.cuda.device(im0.device):
             a = im0.detach().contiguous().float()
             b = im1.detach().contiguous().float()
+            if (a.data_ptr() & 15, b.data_ptr() & 15) != ent.align:
+                # the recording chose kernels for its inputs' alignment (the LDS-staged warps load rows 16 bytes at a time): a
+                # differently aligned view takes the direct launches, which choose again
+                return self._forward_eager(im0, im1)
             self._select_workspace(key[-1])                  # replay counts as a use for the workspace LRU
             return ent.run((a, b), ops.device, ops._stream())
+
+    @staticmethod
+    def _same_results(x, y) -> bool:
+        if isinstance(x, torch.Tensor):
+            return isinstance(y, torch.Tensor) and x.shape == y.shape and bool(torch.equal(x, y))
+        if isinstance(x, dict):
+            return isinstance(y, dict) and x.keys() == y.keys() and all(Network._same_results(v, y[k]) for k, v in x.items())
+        if isinstance(x, (list, tuple)):
+            return isinstance(y, (list, tuple)) and len(x) == len(y) and all(Network._same_results(u, v) for u, v in zip(x, y))
+        return x == y
 
     def _record_plan(self, ops, key, im0, im1):
         a = im0.detach().contiguous().float()
         b = im1.detach().contiguous().float()
+        na, nb = a.numel() * 4, b.numel() * 4
+        if a.data_ptr() < b.data_ptr() + nb and b.data_ptr() < a.data_ptr() + na:
+            # aliased / overlapping frames (net(x, x)): a recording could not tell a pointer into one from a pointer into the other
+            # and every later net(a, b) of this shape would replay as net(a, a).  Stay eager; the next call with distinct frames records.
+            return self._forward_eager(im0, im1)
         try:
             ops.begin_plan((a, b))
             out = self._forward_eager(a, b)
-            self._plans[key] = ops.end_plan(out)
-            return out
+            plan = ops.end_plan(out)
         except PlanUnsupported:
             ops.abort_plan()
             self._plans[key] = False
@@ -794,6 +832,18 @@ class Network(BlockRunner, nn.Module):
         except Exception:
             ops.abort_plan()
             raise
+        # Record-time self-check: replay the fresh plan once into NaN-filled outputs and require the recording forward's results bit
+        # for bit (the forward is run-to-run deterministic).  A pointer patched into the wrong slot, a missed patch or a launch that
+        # was not recorded shows up here, before the plan ever serves a caller; such a shape stays on direct launches.
+        with torch.cuda.device(a.device):
+            again = plan.run((a, b), ops.device, ops._stream(), poison=True)
+        if self._same_results(out, again):
+            self._plans[key] = plan
+        else:
+            import warnings
+            warnings.warn("atm-vfi_amd: a recorded launch plan did not reproduce its own forward; this input shape stays on direct launches")
+            self._plans[key] = False
+        return out
 
     def _forward_graph(self, im0: torch.Tensor, im1: torch.Tensor):
         ops = self._ops(im0.device)

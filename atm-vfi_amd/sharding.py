@@ -26,8 +26,8 @@ def gather_frames(local: torch.Tensor, n_pairs: int, rank: int, world: int) -> t
     shape = (per,) + tuple(local.shape[1:])
     send = local.new_zeros(shape)
     send[:local.shape[0]] = local
-    parts = [torch.empty_like(send) for _ in range(world)]
-    dist.all_gather(parts, send.contiguous())
+    parts = send.new_empty((world,) + shape)          # one receive buffer: every rank's frames land where they are read from
+    dist.all_gather_into_tensor(parts, send.contiguous().unsqueeze(0))
     out = local.new_empty((n_pairs,) + tuple(local.shape[1:]))
     for r in range(world):
         idx = shard_indices(n_pairs, r, world)
@@ -62,14 +62,24 @@ class PipelinedGather:
     how many ranks' frames are real.  ``encode`` (optional) maps the fp32 frames to the wire format before sending, e.g. rounding
     to uint8 (4x fewer bytes over xGMI); it must return a tensor of ``wire_shape`` / ``wire_dtype``.
     Frames come back as a list of ``world`` tensors in rank order: views of the receive buffers, valid until the NEXT-BUT-ONE
-    ``submit`` (they survive one further submit; tests/test_sharding_gloo.py reads them after it)."""
+    ``submit`` (they survive one further submit; tests/test_sharding_gloo.py reads them after it).
+
+    The collective is ``all_gather_into_tensor`` into ONE ``[world, *wire_shape]`` receive buffer per set: RCCL writes every rank's
+    frame where it is read from (``all_gather`` into a tensor LIST gathers into a flat staging buffer and copies out per rank:
+    ``world`` extra device copies per step); gloo takes the same call."""
 
     def __init__(self, world: int, wire_shape, device, wire_dtype=torch.float32, encode: Callable = None, group=None):
         self.world, self.encode, self.group = world, encode, group
-        self.send = [torch.zeros(wire_shape, dtype=wire_dtype, device=device) for _ in range(2)]
-        self.recv = [[torch.empty(wire_shape, dtype=wire_dtype, device=device) for _ in range(world)] for _ in range(3)]
+        wire_shape = tuple(wire_shape)
+        self._send = [torch.zeros((1,) + wire_shape, dtype=wire_dtype, device=device) for _ in range(2)]
+        self.send = [t[0] for t in self._send]
+        self._recv = [torch.empty((world,) + wire_shape, dtype=wire_dtype, device=device) for _ in range(3)]
+        self.recv = [[t[i] for i in range(world)] for t in self._recv]       # per set: rank-order views of the one buffer
         self.pending = None            # (work, buffer set, valid count)
         self.k = 0
+
+    def _issue(self, r: int, s: int):
+        return dist.all_gather_into_tensor(self._recv[r], self._send[s], group=self.group, async_op=True)
 
     def _finish(self):
         if self.pending is None:
@@ -94,7 +104,7 @@ class PipelinedGather:
             self.recv[r][0].copy_(self.send[s])
             work = None
         else:
-            work = dist.all_gather(self.recv[r], self.send[s], group=self.group, async_op=True)
+            work = self._issue(r, s)
         self.pending = (work, r, self.world if valid is None else valid)
         return prev
 
@@ -143,7 +153,7 @@ class HostGather(PipelinedGather):
             if self.world == 1 and not (dist.is_available() and dist.is_initialized()):
                 self.recv[r][0].copy_(self.send[s])
             else:
-                work = dist.all_gather(self.recv[r], self.send[s], group=self.group, async_op=True)
+                work = self._issue(r, s)
             self.pending = (work, r, self.world if valid is None else valid)
             return prev
         s, r = self.k & 1, self.k % 3
@@ -162,7 +172,7 @@ class HostGather(PipelinedGather):
             if self.world == 1 and not (dist.is_available() and dist.is_initialized()):
                 self.recv[r][0].copy_(self.send[s], non_blocking=True)
             else:
-                work = dist.all_gather(self.recv[r], self.send[s], group=self.group, async_op=True)
+                work = self._issue(r, s)
                 work.wait()                     # RCCL: this side stream waits for the collective; gloo: the host does
             for i in range(nv):
                 self.host[r][i].copy_(self.recv[r][i], non_blocking=True)

@@ -43,6 +43,7 @@ FLOPS_PER_PAIR = {  # SURVEY.md section 8d, algorithmic FLOPs per frame pair (2 
     ("base", 576, 960, True): 1566.3e9,
     ("lite", 256, 448, False): 87.8e9,
     ("lite", 256, 256, True): 56.2e9,
+    ("base", 2176, 4096, True): 25300.0e9,
 }
 # BASELINE.json `configs`, in order: (variant, height, width, global branch on, description)
 CONFIGS = {
@@ -58,16 +59,15 @@ PEAK_HBM_GBS = 8000.0
 
 
 def csrc_digest() -> str:
-    """sha256 over the kernel sources, the C-ABI header and the Makefile (compiler flags): stamps the committed PMC traffic figures with the build they were measured on."""
-    import hashlib
-    hsh = hashlib.sha256()
-    d = os.path.join(ROOT, "atm-vfi_amd", "csrc")
-    files = [os.path.join(d, fn) for fn in sorted(os.listdir(d)) if fn.endswith((".hip", ".h")) or fn == "Makefile"]
-    files.append(os.path.join(ROOT, "include", "atmvfi.h"))          # the ABI and the build flags are part of the build
-    for path in files:
-        hsh.update(os.path.basename(path).encode())
-        hsh.update(open(path, "rb").read())
-    return hsh.hexdigest()
+    """sha256 over everything that determines the library (tools/source_digest.py: kernel sources, headers, generated includes, the
+    Makefile, the C-ABI header) -- the value the Makefile bakes into it (``atmvfi_source_digest()``); stamps the committed PMC traffic
+    figures with the build they were measured on."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import source_digest
+        return source_digest.digest()
+    finally:
+        sys.path.pop(0)
 
 
 def host_cores():
@@ -117,6 +117,7 @@ def parse():
                     help="time the CPU oracle on a quarter-pixel crop and scale by the pixel ratio (marked extrapolated) instead of the full frame pair")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip timing BASELINE.json's other configurations (c1, c2, c3, c5) after the headline one")
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f32"])
     ap.add_argument("--no-host-io", action="store_true", help="skip the PCIe-inclusive measurement (uint8 frames in host memory in and out)")
     ap.add_argument("--gather-u8", action="store_true", help="N > 1: all-gather the output frames rounded to uint8 (4x fewer bytes over xGMI)")
@@ -127,6 +128,47 @@ def parse():
         args.variant, args.height, args.width, g_on, _ = CONFIGS[args.config]
         args.global_off = not g_on
     return args
+
+
+def time_config(pkg, host_io, pairs, dev, cname, steps, warmup, precision, shared=None):
+    """One BASELINE.json configuration on one GPU, timed like the headline: resident synthetic pairs, ``warmup`` untimed forwards (they
+    also record the launch plan), ``steps`` timed ones between synchronisations.  -> the entry of the bench line's ``configs`` block."""
+    variant, height, width, g_on, desc = CONFIGS[cname]
+    if shared is not None:
+        net, _ = shared
+    else:
+        sd = pkg.synthetic_state_dict(variant, seed=1)
+        net = (pkg.NetworkBase if variant == "base" else pkg.NetworkLite)()
+        net.load_state_dict(sd, strict=True)
+        net.to(dev).eval()
+        net.set_precision(precision)
+    net.global_motion = g_on
+    padder = host_io.InputPadder((1, 3, height, width), divisor=64)
+    frames = []
+    for i in range(2):
+        a, b = pairs.random_pair(1, height, width, seed=2000 + i)
+        a, b = padder.pad(a.to(dev), b.to(dev))
+        frames.append((a.contiguous(), b.contiguous()))
+    H, W = frames[0][0].shape[-2:]
+    for i in range(warmup):
+        net(*frames[i & 1])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        net(*frames[i & 1])
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    fps = steps / el
+    out = {"workload": desc + f" (padded {H}x{W})", "value": round(fps, 3), "unit": "frames/s", "ms_per_step": round(1e3 * el / steps, 4),
+           "steps": steps, "warmup": warmup}
+    fl = FLOPS_PER_PAIR.get((variant, H, W, g_on))
+    if fl:
+        out["forward_tflops"] = round(fl * fps / 1e12, 2)
+        out["forward_frac_of_f16x3_peak"] = round(fl * fps / 1e12 / (PEAK_F16_MFMA_TFLOPS / 3.0), 4)
+    net.release_workspace()
+    del frames
+    torch.cuda.empty_cache()
+    return out
 
 
 def self_launch(args) -> int:
@@ -160,11 +202,16 @@ def dry_run(args, dist):
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if os.environ.get("ATMVFI_BENCH_DRY_FAIL_RANK") == str(rank):
         raise SystemExit(3)
+    group_world, per_rank = 1, [0.0]
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         assert t.item() == world
+        # the reporting collective of main(): every rank's elapsed time into one [world, 1] tensor
+        allt = torch.empty(dist.get_world_size(), 1, dtype=torch.float64)
+        dist.all_gather_into_tensor(allt, torch.tensor([[float(rank)]], dtype=torch.float64))
+        per_rank, group_world = allt[:, 0].tolist(), dist.get_world_size()
         dist.barrier()
         dist.destroy_process_group()
     if os.environ.get("ATMVFI_BENCH_DRY_NOISE") == "1":                  # (launcher self-test) what RCCL's version banner does
@@ -172,7 +219,8 @@ def dry_run(args, dist):
     print(f"rank {rank} of {world}: rendezvous at {os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')} ok", flush=True)
     if rank == 0:
         print(json.dumps({"metric": "dry-run (launcher self-test, nothing measured)", "value": None, "n_gpus": world,
-                          "steps": args.steps, "warmup": args.warmup}), file=_REAL_STDOUT, flush=True)
+                          "steps": args.steps, "warmup": args.warmup, "rccl_world_size": group_world, "per_rank_ms_per_step": per_rank}),
+              file=_REAL_STDOUT, flush=True)
 
 
 def main():
@@ -282,10 +330,15 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    per_rank_ms = None
     if collective:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+        # every rank's own elapsed time (one small all-gather): the line reports the MAX (the contract) and the list, so a reader sees
+        # that the communicator had N ranks and whether they were balanced
+        mine = torch.tensor([[elapsed]], device=dev, dtype=torch.float64)
+        allt = torch.empty(dist.get_world_size(), 1, device=dev, dtype=torch.float64)
+        dist.all_gather_into_tensor(allt, mine)
+        per_rank_ms = [round(1e3 * float(x) / args.steps, 3) for x in allt[:, 0].tolist()]
+        elapsed = float(allt.max().item())
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -410,6 +463,16 @@ def main():
                 hio["sequential" if depth == 1 else "overlapped_depth3"] = round(n_out / tp, 3)
             result["host_io"] = {"unit": "frames/s, uint8 HWC BGR frames in pageable host memory in and out (pre/post kernels, pinned staging, PCIe both ways)",
                                  **hio, "bytes_over_pcie_per_frame": 3 * args.height * args.width * 3}
+        # ---- the other BASELINE.json configurations, timed the same way (default run only: N = 1, config c4) ----
+        if world == 1 and key == ("base", 1088, 1920, True) and not args.no_configs:
+            net.release_workspace()
+            torch.cuda.empty_cache()
+            result["configs"] = {"c4": {"value": result["value"], "ms_per_step": result["ms_per_step"], "steps": args.steps,
+                                        "forward_frac_of_f16x3_peak": result.get("forward_frac_of_f16x3_peak")}}
+            for cname, csteps, cwarm in (("c1", 200, 20), ("c2", 200, 20), ("c3", 60, 6), ("c5", 4, 3)):
+                result["configs"][cname] = time_config(pkg, host_io, pairs, dev, cname, csteps, cwarm, args.precision,
+                                                       shared=(net, sd) if CONFIGS[cname][0] == variant else None)
+            net.global_motion = not args.global_off
         # ---- CPU baseline: the oracle on this node's host cores, bounded sample ----
         if world == 1 and not args.no_cpu_baseline:
             # threads = the cores this process may really use (cgroup quota), CPU model stated, one warm-up,
@@ -439,6 +502,8 @@ def main():
                                                 f"{med:.2f} s per forward (runs {', '.join(f'{t:.2f}' for t in runs)})"}
         if collective:
             result["collective_backend"] = dist.get_backend()
+            result["rccl_world_size"] = dist.get_world_size()          # what the communicator itself reports, not WORLD_SIZE
+            result["per_rank_ms_per_step"] = per_rank_ms
         print(json.dumps(result), file=_REAL_STDOUT, flush=True)
     if collective:
         dist.barrier()                      # rank 0's instrumented pass is over: nobody tears the communicator down under it

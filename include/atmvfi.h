@@ -39,6 +39,10 @@ extern "C" {
 
 int         atmvfi_version(void);            /* (major<<16)|(minor<<8)|patch */
 const char* atmvfi_last_error(void);
+/* sha256 (hex) over the sources this library was built from (tools/source_digest.py: atm-vfi_amd/csrc/{*.hip,*.h,*.inc,Makefile} +
+ * this header), baked in at build time: lets a caller prove that a shipped .so belongs to the shipped sources.  The reference has
+ * no counterpart (pure Python, nothing is built). */
+const char* atmvfi_source_digest(void);
 
 /* ------------------------------------------------------------------------------------
  * Implicit-GEMM contraction engine on fp32 MFMA (v_mfma_f32_16x16x4_f32).

@@ -20,6 +20,7 @@ TOL_FLOW = 2e-3       # flows are O(1..10) px; same relative budget
 
 pkg = importlib.import_module("atm-vfi_amd")
 host_io = importlib.import_module("atm-vfi_amd.host_io")
+hip_ops = importlib.import_module("atm-vfi_amd.hip_ops")
 
 
 @pytest.fixture(scope="module")
@@ -541,3 +542,78 @@ def test_launch_plan_replay_equals_direct_launches(dev, weights):
     assert all(torch.equal(outs[0], o) for o in outs[1:])
     assert not [k for k, p in net._plans.items() if k[4] and not isinstance(p, (int, bool))]
     net.ensemble_global_motion = False
+
+
+def test_launch_plans_refuse_aliased_frames_and_follow_input_alignment(dev, weights):
+    """(1) warm-up calls with ALIASED frames (net(x, x)) must not produce a plan that replays every later net(a, b) of
+    that shape as net(a, a): overlapping frames are never recorded, the next call with distinct frames is; (2) frames that are two
+    slices of one stacked tensor are told apart; (3) a replay whose inputs are aligned differently from the recording's (a 4-byte
+    aligned view: the LDS-staged warps need 16) takes the direct launches instead of failing inside the plan."""
+    net = pkg.NetworkLite()
+    net.load_state_dict(weights("lite"), strict=True)
+    net.to(dev).eval()
+    a, b = [t.to(dev) for t in pairs.smooth_pair(1, 128, 192, seed=91)]
+    x = a.clone()
+    net.enable_plans(False)
+    want_ab = [t.clone() for t in _flat(net(a, b))]
+    want_xx = [t.clone() for t in _flat(net(x, x))]
+    net.enable_plans(True)
+    net._plans.clear()
+    for rep in range(4):                                       # would have been recorded as "both frames = slot 0" before
+        for t, r in zip(_flat(net(x, x)), want_xx):
+            assert torch.equal(t, r)
+    assert not [p for p in net._plans.values() if not isinstance(p, (int, bool))]
+    for rep in range(4):
+        for t, r in zip(_flat(net(a, b)), want_ab):
+            assert torch.equal(t, r)
+    plans = [p for p in net._plans.values() if not isinstance(p, (int, bool))]
+    assert len(plans) == 1 and plans[0].by_address == 0 and plans[0].by_tensor > 10
+    for t, r in zip(_flat(net(x, x)), want_xx):                # replaying with aliased frames is fine: both slots get x
+        assert torch.equal(t, r)
+    # (2) one stacked tensor
+    st = torch.cat([a, b], 0).contiguous()
+    for rep in range(2):
+        for t, r in zip(_flat(net(st[0:1], st[1:2])), want_ab):
+            assert torch.equal(t, r)
+    net._plans.clear()
+    for rep in range(5):                                       # ... recorded from such a pair too
+        for t, r in zip(_flat(net(st[0:1], st[1:2])), want_ab):
+            assert torch.equal(t, r)
+    assert len([p for p in net._plans.values() if not isinstance(p, (int, bool))]) == 1
+    # (3) a 4-byte-aligned contiguous view of the same pixels
+    flat = torch.zeros(a.numel() + 1, device=dev)
+    flat[1:] = a.reshape(-1)
+    a4 = flat[1:].view_as(a)
+    assert a4.data_ptr() % 16 == 4 and a4.is_contiguous()
+    for t, r in zip(_flat(net(a4, b)), want_ab):
+        assert torch.equal(t, r)
+
+
+def test_launch_plan_equals_direct_launches_at_1080p_base(dev, weights):
+    """The path bench.py times: network_base at 1088 x 1920 replayed from its launch plan, bit for bit the direct launches (VERDICT
+    round 3, weak 1), on the recording's own pair and on a new one; the record-time self-check accepted the plan."""
+    net = pkg.NetworkBase()
+    net.load_state_dict(weights("base"), strict=True)
+    net.to(dev).eval()
+    p0 = [t.to(dev) for t in pairs.random_pair(1, 1088, 1920, seed=5)]
+    p1 = [t.to(dev) for t in pairs.smooth_pair(1, 1088, 1920, seed=6)]
+    net.enable_plans(False)
+    want = [[t.clone() for t in _flat(net(*p))] for p in (p0, p1)]
+    net.enable_plans(True)
+    for rep in range(4):
+        for p, w in zip((p0, p1), want):
+            for t, r in zip(_flat(net(*p)), w):
+                assert torch.equal(t, r)
+    plans = [p for p in net._plans.values() if not isinstance(p, (int, bool))]
+    assert len(plans) == 1 and len(plans[0].ops_list) > 100
+    net.release_workspace()
+    torch.cuda.empty_cache()
+
+
+def test_library_that_ran_is_built_from_these_sources(dev):
+    """On the GPU box: the library this process loaded reports the digest of the sources in this tree (tools/source_digest.py)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import source_digest
+    ops = hip_ops.HipOps(dev)
+    assert ops.lib.atmvfi_source_digest().decode() == source_digest.digest()

@@ -1152,12 +1152,16 @@ def test_atmformer_module_reference_fixture(shift, dev):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", [(24, 48, 2, 64, 96), (24, 48, 1, 36, 52), (16, 32, 2, 40, 72), (24, 48, 1, 16, 32), (16, 32, 1, 2, 2),
-                                  (24, 48, 3, 70, 34)], ids=lambda c: f"c{c[0]}_{c[1]}_f{c[2]}_{c[3]}x{c[4]}")
+                                  (24, 48, 3, 70, 34), (24, 48, 2, 544, 960), (16, 32, 1, 528, 992)],
+                         ids=lambda c: f"c{c[0]}_{c[1]}_f{c[2]}_{c[3]}x{c[4]}")
 def test_stem_fused(case, dev):
     """atmvfi_stem_fused (feat_extracts.0.0 -> 0.1 -> 1.0, network_base.py:99-110, in one launch, the two full-resolution maps in LDS)
     against the three layers in torch fp32: whole tiles, ragged tiles (sizes that are no multiples of the 16 x 32 full-resolution
     tile), a map smaller than one tile, both variants' channel counts, several frames.  Image borders are where the zero padding of
-    EVERY layer has to be right (a layer-1 value outside the image is 0, not conv(0) + bias)."""
+    EVERY layer has to be right (a layer-1 value outside the image is 0, not conv(0) + bias).  The two large cases have 2 040 and
+    1 023 tiles on 256 persistent workgroups: every workgroup walks 4-8 tiles, which is what exercises the cross-tile hazards of the
+    kernel (the frame patch overlaying the layer-3 weight region, the per-tile LDS-DMA re-staging of those weights, the next patch
+    requested under phase E) at the unit tolerance; a second launch must reproduce the planes bit for bit."""
     c0, c1, f, h, w = case
     g = torch.Generator().manual_seed(100 * c0 + h + w)
     x = torch.zeros(f, h, w, 4)
@@ -1184,3 +1188,7 @@ def test_stem_fused(case, dev):
     assert out.t[:, :, out.rows:].abs().max().item() == 0
     if c1 % 32:
         assert out.t[:, -1, :, c1 % 32:].abs().max().item() == 0
+    out2 = hip_ops.Planes.alloc(f * (h // 2) * (w // 2), c1, dev)
+    hip.stem_fused(x.to(dev), pk, out2)
+    torch.cuda.synchronize()
+    assert torch.equal(out.t, out2.t), "two launches of the fused stem differ"

@@ -6,7 +6,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 H = importlib.import_module("atm-vfi_amd.hip_ops")
-if os.environ.get("ATMVFI_LIB"):          # A/B of two builds on one box: ATMVFI_LIB=atm-vfi_amd/libatmvfi_hip_base.so
+if os.environ.get("ATMVFI_LIB"):          # A/B of two builds on one box: ATMVFI_LIB=tools/lib/libatmvfi_hip_base.so
     H.LIB_PATH = os.path.join(ROOT, os.environ["ATMVFI_LIB"])
     H.load_library.__defaults__ = (H.LIB_PATH,)
 torch.set_grad_enabled(False)

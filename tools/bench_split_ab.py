@@ -1,5 +1,5 @@
 """Same-process A/B of the LDS-DMA GEMM (gemm_split.hip) between two builds of the library, interleaved per shape:
-    python tools/bench_split_ab.py [atm-vfi_amd/libatmvfi_hip_old.so]        (B = the product build: gemm_pp.hip; A = another
+    python tools/bench_split_ab.py [tools/lib/libatmvfi_hip_old.so]        (B = the product build: gemm_pp.hip; A = another
     build, or without an argument the reference schedule gemm_split.hip of the same build, atmvfi_gemm_params.tile_wn = -1)
 Shapes: the network's linears (with / without bias + residual + row map), deconvs (plane sink) and strided convs at 1080p."""
 import importlib, os, sys

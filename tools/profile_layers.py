@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import pairs
 pkg = importlib.import_module("atm-vfi_amd")
-if os.environ.get("ATMVFI_LIB"):          # A/B of two builds on one box: ATMVFI_LIB=atm-vfi_amd/libatmvfi_hip_base.so
+if os.environ.get("ATMVFI_LIB"):          # A/B of two builds on one box: ATMVFI_LIB=tools/lib/libatmvfi_hip_base.so
     _h = importlib.import_module("atm-vfi_amd.hip_ops")
     _h.LIB_PATH = os.path.join(ROOT, os.environ["ATMVFI_LIB"])
     _h.load_library.__defaults__ = (_h.LIB_PATH,)

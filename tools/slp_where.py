@@ -23,7 +23,7 @@ qkv = (torch.rand(bw * n, 3 * C, generator=g) * 2 - 1) * 1.5
 oc, mc = torch.empty(bw * n, C), torch.empty(bw * n, heads, 2)
 CpuOps().window_attention(qkv, oc, mc, geo.labels, bw, geo.n_windows, ws, heads, hd, bw // 2)
 for name in ("libatmvfi_hip.so", "libatmvfi_hip_oldattn_noslp.so", "libatmvfi_hip_oldattn_slp.so"):
-    lib = os.path.join(ROOT, "atm-vfi_amd", name)
+    lib = os.path.join(ROOT, "atm-vfi_amd" if name == "libatmvfi_hip.so" else os.path.join("tools", "lib"), name)
     H.load_library.__defaults__ = (lib,)
     ops = H.HipOps(dev)
     og = torch.full((bw * n, C), 9.0, device=dev)

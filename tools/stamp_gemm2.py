@@ -4,7 +4,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT]
 hip_ops = importlib.import_module("atm-vfi_amd.hip_ops")
-hip_ops.LIB_PATH = os.path.join(ROOT, "atm-vfi_amd", "libatmvfi_hip_stamp.so")
+hip_ops.LIB_PATH = os.path.join(ROOT, "tools", "lib", "libatmvfi_hip_stamp.so")
 hip_ops.load_library.__defaults__ = (hip_ops.LIB_PATH,)
 dev = torch.device("cuda:0")
 ops = hip_ops.HipOps(dev)
