@@ -644,10 +644,15 @@ extern "C" int atmvfi_conv3x3_planes2(const void* in_hi, const void* in_lo, int6
         const int ncu = atmvfi::cu_count();
         const long long spatial = (long long)N * d.tiles_x * ((H + 15) / 16);
         float best_cost = 1e30f;
+        int best_pad = 1 << 30;
         for (int w = 1; w <= 8; ++w) {
             const int nb = (ntiles + w - 1) / w;
             const float c = (float)((spatial * nb + ncu - 1) / ncu) * ((float)w + 2.0f);
-            if (c <= best_cost) { best_cost = c; best = w; }
+            // ties go to the width with fewer padded n-tiles, then to the wider one (round 4, tools/sweep_conv3p_wn.py: the 576-wide
+            // motion-MLP layers at 136 x 240 tie between 8 tiles x 5 blocks, four of the 40 n-tiles padding, and 4 x 9: 0.608 against
+            // 0.572 ms and 0.459 against 0.427)
+            const int pad = nb * w - ntiles;
+            if (c < best_cost || (c == best_cost && pad <= best_pad)) { best_cost = c; best = w; best_pad = pad; }
         }
     }
     hipStream_t s = (hipStream_t)stream;

@@ -457,6 +457,16 @@ int atmvfi::launch_gemm_split(const GemmDev& d, int ngemm, hipStream_t s) {
     if (d.force_wn == -3) return launch_gemm_pp(d, ngemm, s);
     if (d.force_wn == 0) {
         if (ngemm <= 64) return launch_gemm_duo(d, ngemm, s);
+        // Under-filled grids (round 4, tools/gemm_engines_ab.py -> profiles/r04_gemm_engines_ab.txt: all three schedules timed on every
+        // launch of four configurations): while the 128 x 64 tiles of the launch number at most two per CU, the 128 x 64 form wins on
+        // every launch measured -- its tile is a latency chain of 0.6 us per k-step + 6 us against 0.8 + 8 (128 x 128) and 1.0 + 9
+        // (256 x 128), and the chip is not full either way.  network_lite 256 x 256: the 44 launches 0.775 -> 0.622 ms, 256 x 448
+        // 0.553 -> 0.458, network_base 576 x 960 2.47 -> 2.35, 1088 x 1920 +-0.
+        if (ceil_div64(d.M, 128) * ((ngemm + 63) / 64) <= 2 * (long long)cu_count()) {
+            GemmDev d64 = d;
+            d64.force_wn = -4;
+            return launch_gemm_duo(d64, ngemm, s);
+        }
         const long long cus = cu_count(), ntile = (ngemm + 127) / 128;
         const long long pp_rounds = ceil_div64(ceil_div64(d.M, 256) * ntile, cus);
         const long long duo_per_cu = ceil_div64(ceil_div64(d.M, 128) * ntile, cus);
