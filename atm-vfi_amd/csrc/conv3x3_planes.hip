@@ -67,6 +67,11 @@ struct Conv3PDev {
     int out_cmin;               // fp32 output: only channels >= out_cmin (multiple of 4) are stored
     int tiles_x, tiles_y, nblocks, tchunk;
     int vblocks;                // virtual blocks (tiles incl. XCD padding) walked by the persistent grid
+    // split-K (under-filled grids with long K, round 4): gridDim.y = ksplit workgroups per tile; split s takes the cps full chunks from
+    // chunk s * cps on (the last one the rest and the tap-packed tail) and stores its raw fp32 sums at out + s * part_stride; a second
+    // kernel adds the partial sums in split order and runs the epilogue.  1 = off.
+    int ksplit, cps;
+    long long part_stride;
     unsigned long long* stamp;  // diagnostic builds only (ATMVFI_STAMP)
     int dbg;                    // diagnostic builds only: ATMVFI_P3_DBG bits switch pieces of the loop off (wrong results, timing only)
 };
@@ -110,6 +115,29 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
     const int r = lane & 15;
     const int g = lane >> 4;
 
+    // operands of this workgroup's K range (split-K: blockIdx.y picks the chunk range and the partial-sum buffer; else everything)
+    const _Float16* in_hi = a.in_hi;
+    const _Float16* in_lo = a.in_lo;
+    const _Float16* w_hi = a.w_hi;
+    const _Float16* w_lo = a.w_lo;
+    float* out_f32 = a.out;
+    int nfull = a.cf >> 5;
+    int ktail = a.tail;
+    if (a.ksplit > 1) {
+        // whole chunks, dealt evenly: the first (nfull mod ksplit) ranges take one chunk more; the tap-packed tail goes with the last
+        const int sp = blockIdx.y;
+        const int rem = nfull - a.cps * a.ksplit;
+        const int c0 = sp * a.cps + (sp < rem ? sp : rem);
+        const bool last = sp == a.ksplit - 1;
+        in_hi += (long long)c0 * a.in_rows * 32;
+        in_lo += (long long)c0 * a.in_rows * 32;
+        w_hi += (long long)c0 * 9 * a.wrows * 32;
+        w_lo += (long long)c0 * 9 * a.wrows * 32;
+        nfull = a.cps + (sp < rem ? 1 : 0);
+        ktail = last ? ktail : 0;
+        out_f32 += sp * a.part_stride;
+    }
+
     // PERSISTENT GRID over the XCD-aware tile order (conv3x3_f16x3_row.hip): virtual block v -> column blocks of one tile back to
     // back on one XCD, each XCD walking a contiguous eighth of the tiles in groups of 8 tile rows, column by column.  Workgroup b
     // walks v = b, b + grid, ... (grid a multiple of 8: it stays on its XCD; the tile index only grows along the walk, so the first
@@ -120,10 +148,19 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
     const int grid = gridDim.x;
     const int per_img = a.tiles_x * a.tiles_y;
     auto decode = [&](int v, int& t_img, int& t_ox0, int& t_oy0, int& t_n0) -> bool {
-        const int slot = v >> 3;
-        const int sgrp = slot / a.nblocks;
-        const int nblk = slot - sgrp * a.nblocks;
-        int L = (v & 7) * a.tchunk + sgrp;
+        int sgrp, nblk, L;
+        if (a.ksplit > 1) {
+            // split-K launches have fewer tiles than CUs: plain order (tile = v / nblocks), so that the workgroups -- dealt round-robin
+            // over the XCDs -- spread over the whole chip instead of filling the first eighths of the XCD-aware order
+            sgrp = v / a.nblocks;
+            nblk = v - sgrp * a.nblocks;
+            L = sgrp;
+        } else {
+            const int slot = v >> 3;
+            sgrp = slot / a.nblocks;
+            nblk = slot - sgrp * a.nblocks;
+            L = (v & 7) * a.tchunk + sgrp;
+        }
         if (v >= a.vblocks || L >= a.N * per_img) return false;
         t_img = L / per_img;
         L -= t_img * per_img;
@@ -197,7 +234,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
         const int j = icc - plane * WN;
         int rg = t_n0 + 16 * j;
         if (rg >= a.wrows) rg = a.wrows - 16;                    // row groups past the packed rows: columns never stored
-        return reinterpret_cast<const unsigned char*>(plane ? a.w_lo : a.w_hi) + (long long)rg * 64;
+        return reinterpret_cast<const unsigned char*>(plane ? w_lo : w_hi) + (long long)rg * 64;
     };
 #pragma unroll
     for (int s = 0; s < SW; ++s) {
@@ -212,9 +249,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
         wdst[s] = (plane * BN + 16 * j) * 64;
     }
 
-    const int nfull = a.cf >> 5;
-    const int nchunks = nfull + (a.tail ? 1 : 0);
-    const int nk = 9 * nfull + (a.tail ? 3 : 0);
+    const int nchunks = nfull + (ktail ? 1 : 0);
+    const int nk = 9 * nfull + (ktail ? 3 : 0);
 
     int wr_off = 0;                       // ring slot (byte offset) the next weight issue goes to
     int kleft = nk - 1;                   // k-steps of the issuer's tile after the one whose weights are issued next
@@ -229,8 +265,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
         kleft = more ? kleft - 1 : (has_next ? nk - 1 : 0);
         wr_off = wr_off + WSLOT == NB * WSLOT ? 0 : wr_off + WSLOT;
     };
-    const unsigned char* hsrc_hi = reinterpret_cast<const unsigned char*>(a.in_hi);      // plane bases of the chunk whose halo is issued next
-    const unsigned char* hsrc_lo = reinterpret_cast<const unsigned char*>(a.in_lo);
+    const unsigned char* hsrc_hi = reinterpret_cast<const unsigned char*>(in_hi);      // plane bases of the chunk whose halo is issued next
+    const unsigned char* hsrc_lo = reinterpret_cast<const unsigned char*>(in_lo);
     int hbuf = 0;                         // halo buffer (byte offset) that chunk goes to
     auto issue_halo = [&](auto sc) {      // halo piece wave + 8 S (waves 2..7, S = 5: piece wave + 32 again)
         constexpr int S = decltype(sc)::value;
@@ -246,8 +282,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
             hsrc_lo += chunk_bytes;
             --chunks_left;
         } else if (has_next) {
-            hsrc_hi = reinterpret_cast<const unsigned char*>(a.in_hi);
-            hsrc_lo = reinterpret_cast<const unsigned char*>(a.in_lo);
+            hsrc_hi = reinterpret_cast<const unsigned char*>(in_hi);
+            hsrc_lo = reinterpret_cast<const unsigned char*>(in_lo);
             setup_halo(nimg, nox0, noy0);
             chunks_left = nchunks - 1;
         }
@@ -409,7 +445,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
             static_for<0, 9>([&](auto tc) { kstep(tc, std::false_type{}, std::false_type{}); });
             next_chunk();
         }
-        if (a.tail) {
+        if (ktail) {
             static_for<0, 3>([&](auto tc) { kstep(tc, std::true_type{}, std::false_type{}); });
             next_chunk();
         }
@@ -436,7 +472,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
         const int oy = oy0 + 2 * wave + i, ox = ox0 + r;
         live[i] = oy < a.H && ox < a.W;
         prow_o[i] = ((long long)img * a.H + (live[i] ? oy : 0)) * a.W + (live[i] ? ox : 0);
-        orow[i] = a.out ? a.out + prow_o[i] * a.out_ld : nullptr;
+        orow[i] = out_f32 ? out_f32 + prow_o[i] * a.out_ld : nullptr;
     }
     f32x4 vv[2][WN];
 #pragma unroll
@@ -456,7 +492,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
             vv[i][j] = v;
         }
     }
-    if (a.out) {
+    if (out_f32) {
         // fp32 NHWC rows: 16 bytes per lane, the four lanes of a pixel cover 64 contiguous bytes.  Only channels >= out_cmin are
         // wanted in fp32 (e.g. the five flow / mask channels of a decoder map whose features go on as planes).
 #pragma unroll
@@ -583,21 +619,143 @@ int launch_planes(const Conv3PDev& d, int ntiles, hipStream_t s) {
     ds.dbg = 0;
 #endif
     ATMVFI_REQUIRE(sgroups * 8 * ds.nblocks < (1LL << 31), ATMVFI_EINVAL, "conv3x3_planes: grid too large");
-    ds.vblocks = (int)(sgroups * 8 * ds.nblocks);
+    ds.vblocks = d.ksplit > 1 ? (int)((long long)d.N * d.tiles_x * ds.tiles_y * ds.nblocks) : (int)(sgroups * 8 * ds.nblocks);
     // persistent (one workgroup per CU walking its XCD's tiles, DMA streams flowing across tiles) whenever a tile has at least two
     // 32-channel chunks -- the halo stream moves on to the next tile while the last chunk is consumed; else one workgroup per tile
     const int nchunks = (d.cf >> 5) + (d.tail ? 1 : 0);
+    if (d.ksplit > 1) {
+        // split-K: one workgroup per (tile, K range), no persistence (the launch exists because the tiles alone leave CUs idle)
+        hipLaunchKernelGGL(kern, dim3((unsigned)ds.vblocks, (unsigned)d.ksplit), dim3(512), lds, s, ds);
+        return atmvfi::check_launch("conv3x3_planes (split-K)");
+    }
     const int grid = nchunks >= 2 ? std::min(ds.vblocks, atmvfi::cu_count()) : ds.vblocks;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, s, ds);
     return atmvfi::check_launch("conv3x3_planes");
 }
 
+// Split-K, second half: out = epilogue(sum over splits, in split order, of the partial sums + bias) -- the epilogue of the kernel above
+// (PReLU, fp32 rows from out_cmin on, one or two plane sinks, the first through its own PReLU; channels from Cout up to the next multiple
+// of 8 are written to the planes as zero).  One thread per (pixel, 4 channels); fixed summation order: run-to-run deterministic.
+__global__ void conv3_splitk_reduce_kernel(const float* __restrict__ part, long long part_stride, int S, long long rows, int ldp, int Cout,
+                                           const float* __restrict__ bias, const float* __restrict__ prelu, float* __restrict__ out, int out_ld,
+                                           int out_cmin, _Float16* hi, _Float16* lo, long long prows, int c0, const float* __restrict__ plane_prelu,
+                                           _Float16* hi2, _Float16* lo2, long long prows2, int c02) {
+    fp16_saturate_on();
+    const int groups = ((Cout + 7) & ~7) >> 2;
+    const long long total = rows * groups;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const long long row = idx / groups;
+        const int c = (int)(idx - row * groups) * 4;
+        const int nvalid = Cout - c;
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // per-channel vectors of the group (bias / slope arrays are 16-byte aligned and c is a multiple of 4; a ragged last group reads
+        // element by element -- selects, no indexed local arrays: hipcc turns those into LDS / scratch)
+        auto vec4 = [&](const float* a, float dflt) -> f32x4 {
+            if (!a || nvalid <= 0) return (f32x4){dflt, dflt, dflt, dflt};
+            if (nvalid >= 4) return *reinterpret_cast<const f32x4*>(a + c);
+            f32x4 o = (f32x4){a[c], dflt, dflt, dflt};
+            if (nvalid > 1) o.y = a[c + 1];
+            if (nvalid > 2) o.z = a[c + 2];
+            return o;
+        };
+        if (nvalid > 0) {
+            const float* p = part + row * ldp + c;               // ldp is a multiple of 16 floats, c of 4: 16-byte aligned
+            for (int sp = 0; sp < S; ++sp) v += *reinterpret_cast<const f32x4*>(p + sp * part_stride);
+            v += vec4(bias, 0.f);
+            if (prelu) {
+                const f32x4 sl = vec4(prelu, 1.f);
+                v.x = v.x > 0.f ? v.x : sl.x * v.x;  v.y = v.y > 0.f ? v.y : sl.y * v.y;
+                v.z = v.z > 0.f ? v.z : sl.z * v.z;  v.w = v.w > 0.f ? v.w : sl.w * v.w;
+            }
+            if (nvalid < 4) {                                       // channels past Cout: zero in the planes, never stored in fp32
+                v.y = nvalid > 1 ? v.y : 0.f;
+                v.z = nvalid > 2 ? v.z : 0.f;
+                v.w = 0.f;
+            }
+        }
+        if (out && nvalid > 0 && c + 4 > out_cmin) {
+            float* o = out + row * out_ld + c;
+            if (nvalid >= 4) *reinterpret_cast<f32x4*>(o) = v;
+            else { o[0] = v.x; if (nvalid > 1) o[1] = v.y; if (nvalid > 2) o[2] = v.z; }
+        }
+        if (hi) {
+            f32x4 u = v;
+            if (plane_prelu && nvalid > 0) {
+                const f32x4 sl = vec4(plane_prelu, 1.f);
+                u.x = u.x > 0.f ? u.x : sl.x * u.x;  u.y = u.y > 0.f ? u.y : sl.y * u.y;
+                u.z = u.z > 0.f ? u.z : sl.z * u.z;  u.w = u.w > 0.f ? u.w : sl.w * u.w;
+            }
+            sink_store4(RowSink{nullptr, 0, hi, lo, prows}, row, c0 + c, u);
+        }
+        if (hi2) sink_store4(RowSink{nullptr, 0, hi2, lo2, prows2}, row, c02 + c, v);
+    }
+}
+
+// Tile width and K split of a launch.  Width: rounds x (WN + c0), one workgroup per CU (conv3x3_f16x3_row.hip's cost model, row
+// schedule).  Split: only when the tiles of the launch leave at least half of the CUs idle and K is long (>= 8 chunks = 72 k-steps):
+// as many K ranges as fill the chip, each at least 4 chunks, at most 8 (tools/profile_layers.py at 256 x 256 / 576 x 960: the motion
+// MLPs there are 22-72 workgroups walking 200-380 k-steps each: 62 / 161 us per launch on a mostly idle chip).
+struct Conv3Plan { int wn, ksplit, cps; };
+static Conv3Plan conv3_plan(int N, int H, int W, int Cin, int Cout, int wn, bool may_split) {
+    const int ntiles = (Cout + 15) / 16;
+    const int tiles_x = (W + TW - 1) / TW;
+    const int ncu = atmvfi::cu_count();
+    const long long spatial = (long long)N * tiles_x * ((H + 15) / 16);
+    int best = wn;
+    if (best == 0) {
+        float best_cost = 1e30f;
+        int best_pad = 1 << 30;
+        for (int w = 1; w <= 8; ++w) {
+            const int nb = (ntiles + w - 1) / w;
+            const float c = (float)((spatial * nb + ncu - 1) / ncu) * ((float)w + 2.0f);
+            // ties go to the width with fewer padded n-tiles, then to the wider one (round 4, tools/sweep_conv3p_wn.py: the 576-wide
+            // motion-MLP layers at 136 x 240 tie between 8 tiles x 5 blocks, four of the 40 n-tiles padding, and 4 x 9: 0.608 against
+            // 0.572 ms and 0.459 against 0.427)
+            const int pad = nb * w - ntiles;
+            if (c < best_cost || (c == best_cost && pad <= best_pad)) { best_cost = c; best = w; best_pad = pad; }
+        }
+    }
+    Conv3Plan p{best, 1, 0};
+    const int t = Cin % 32;
+    const int nfull = (t >= 1 && t <= 8) ? (Cin - t) / 32 : (Cin + 31) / 32;
+    if (may_split && nfull >= 8) {
+        // A split launch is one round by construction; its time is the k-steps of one K range times the k-step time of the width
+        // (~ WN + 2, the same model; one unit = 0.75-0.9 us per chunk of 9 k-steps on an under-filled chip, tools/sweep_conv3p_splitk.py)
+        // plus the second kernel (~7 us = 9 units).  Splits: as many as fill the chip, each at least 4 chunks, at most 8.  Taken only
+        // when the model says at least 10 % faster than the unsplit launch at its own best width.
+        const int nb0 = (ntiles + best - 1) / best;
+        const long long unsplit = ((spatial * nb0 + ncu - 1) / ncu) * (long long)nfull * (best + 2);
+        int bw = 0, bs = 1;
+        long long bcost = 1ll << 60;
+        for (int w = (wn ? wn : 1); w <= (wn ? wn : 8); ++w) {
+            const long long tiles = spatial * ((ntiles + w - 1) / w);
+            const int S = (int)std::min<long long>(std::min<long long>(ncu / std::max<long long>(tiles, 1), nfull / 4), 8);
+            if (S < 2) continue;
+            const long long c = (long long)((nfull + S - 1) / S) * (w + 2) + 9;
+            if (c <= bcost) { bcost = c; bw = w; bs = S; }
+        }
+        if (bs >= 2 && 10 * bcost < 9 * unsplit) {
+            p.wn = bw;
+            p.ksplit = bs;
+            p.cps = nfull / bs;
+        }
+    }
+    return p;
+}
+
 }  // namespace
 
-extern "C" int atmvfi_conv3x3_planes2(const void* in_hi, const void* in_lo, int64_t in_rows, int N, int H, int W, int Cin, const void* w_hi,
+extern "C" int64_t atmvfi_conv3x3_planes_workspace_floats(int N, int H, int W, int Cin, int Cout) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+    const Conv3Plan p = conv3_plan(N, H, W, Cin, Cout, 0, true);
+    return p.ksplit > 1 ? (int64_t)p.ksplit * N * H * W * atmvfi::round_up(Cout, 16) : 0;
+}
+
+extern "C" int atmvfi_conv3x3_planes3(const void* in_hi, const void* in_lo, int64_t in_rows, int N, int H, int W, int Cin, const void* w_hi,
                                        const void* w_lo, int Cout, float* out, int out_ld, const float* bias, const float* prelu,
                                        void* out_hi, void* out_lo, int64_t plane_rows, int out_c0, const float* plane_prelu, void* out_hi2,
-                                       void* out_lo2, int64_t plane_rows2, int out_c02, int out_cmin, int wn, void* stream) {
+                                       void* out_lo2, int64_t plane_rows2, int out_c02, int out_cmin, int wn, float* workspace,
+                                       int64_t workspace_floats, void* stream) {
     ATMVFI_REQUIRE(in_hi && in_lo && w_hi && w_lo && (out || out_hi), ATMVFI_EINVAL, "conv3x3_planes: null pointer");
     ATMVFI_REQUIRE((out_hi2 == nullptr) == (out_lo2 == nullptr), ATMVFI_EINVAL, "conv3x3_planes: the second plane sink needs both planes");
     if (out_hi2)
@@ -638,34 +796,46 @@ extern "C" int atmvfi_conv3x3_planes2(const void* in_hi, const void* in_lo, int6
     d.tiles_x = (W + TW - 1) / TW;
     d.tiles_y = 0; d.nblocks = 0; d.tchunk = 0;
     const int ntiles = (Cout + 15) / 16;
-    // tile width: rounds x (WN + c0), one workgroup per CU (conv3x3_f16x3_row.hip's cost model, row schedule)
-    int best = wn;
-    if (best == 0) {
-        const int ncu = atmvfi::cu_count();
-        const long long spatial = (long long)N * d.tiles_x * ((H + 15) / 16);
-        float best_cost = 1e30f;
-        int best_pad = 1 << 30;
-        for (int w = 1; w <= 8; ++w) {
-            const int nb = (ntiles + w - 1) / w;
-            const float c = (float)((spatial * nb + ncu - 1) / ncu) * ((float)w + 2.0f);
-            // ties go to the width with fewer padded n-tiles, then to the wider one (round 4, tools/sweep_conv3p_wn.py: the 576-wide
-            // motion-MLP layers at 136 x 240 tie between 8 tiles x 5 blocks, four of the 40 n-tiles padding, and 4 x 9: 0.608 against
-            // 0.572 ms and 0.459 against 0.427)
-            const int pad = nb * w - ntiles;
-            if (c < best_cost || (c == best_cost && pad <= best_pad)) { best_cost = c; best = w; best_pad = pad; }
-        }
+    ATMVFI_REQUIRE(!workspace || atmvfi::aligned16(workspace), ATMVFI_EALIGN, "conv3x3_planes: the split-K workspace must be 16-byte aligned");
+    Conv3Plan plan = conv3_plan(N, H, W, Cin, Cout, wn, workspace != nullptr);
+    const int ldp = atmvfi::round_up(Cout, 16);
+    const long long rows = (long long)N * H * W;
+    if (plan.ksplit > 1 && (long long)plan.ksplit * rows * ldp > workspace_floats) plan = conv3_plan(N, H, W, Cin, Cout, wn, false);
+    d.ksplit = plan.ksplit; d.cps = plan.cps; d.part_stride = rows * ldp;
+    const int best = plan.wn;
+    Conv3PDev full = d;
+    if (plan.ksplit > 1) {
+        // first half: raw partial sums of every K range into the workspace (no bias, no activation, no sinks)
+        d.out = workspace; d.out_ld = ldp; d.out_cmin = 0; d.bias = nullptr; d.prelu = nullptr;
+        d.out_hi = d.out_lo = d.out_hi2 = d.out_lo2 = nullptr; d.plane_prelu = nullptr;
     }
     hipStream_t s = (hipStream_t)stream;
+    int rc;
     switch (best) {
-        case 1: return launch_planes<1>(d, ntiles, s);
-        case 2: return launch_planes<2>(d, ntiles, s);
-        case 3: return launch_planes<3>(d, ntiles, s);
-        case 4: return launch_planes<4>(d, ntiles, s);
-        case 5: return launch_planes<5>(d, ntiles, s);
-        case 6: return launch_planes<6>(d, ntiles, s);
-        case 7: return launch_planes<7>(d, ntiles, s);
-        default: return launch_planes<8>(d, ntiles, s);
+        case 1: rc = launch_planes<1>(d, ntiles, s); break;
+        case 2: rc = launch_planes<2>(d, ntiles, s); break;
+        case 3: rc = launch_planes<3>(d, ntiles, s); break;
+        case 4: rc = launch_planes<4>(d, ntiles, s); break;
+        case 5: rc = launch_planes<5>(d, ntiles, s); break;
+        case 6: rc = launch_planes<6>(d, ntiles, s); break;
+        case 7: rc = launch_planes<7>(d, ntiles, s); break;
+        default: rc = launch_planes<8>(d, ntiles, s); break;
     }
+    if (rc != ATMVFI_OK || plan.ksplit <= 1) return rc;
+    const long long groups = rows * (((Cout + 7) & ~7) >> 2);
+    const unsigned blocks = (unsigned)std::min<long long>((groups + 255) / 256, 4096);
+    hipLaunchKernelGGL(conv3_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, workspace, d.part_stride, plan.ksplit, rows, ldp, Cout,
+                       full.bias, full.prelu, full.out, full.out_ld, full.out_cmin, full.out_hi, full.out_lo, (long long)full.plane_rows,
+                       full.out_c0, full.plane_prelu, full.out_hi2, full.out_lo2, (long long)full.plane_rows2, full.out_c02);
+    return atmvfi::check_launch("conv3x3_planes (split-K reduce)");
+}
+
+extern "C" int atmvfi_conv3x3_planes2(const void* in_hi, const void* in_lo, int64_t in_rows, int N, int H, int W, int Cin, const void* w_hi,
+                                       const void* w_lo, int Cout, float* out, int out_ld, const float* bias, const float* prelu,
+                                       void* out_hi, void* out_lo, int64_t plane_rows, int out_c0, const float* plane_prelu, void* out_hi2,
+                                       void* out_lo2, int64_t plane_rows2, int out_c02, int out_cmin, int wn, void* stream) {
+    return atmvfi_conv3x3_planes3(in_hi, in_lo, in_rows, N, H, W, Cin, w_hi, w_lo, Cout, out, out_ld, bias, prelu, out_hi, out_lo, plane_rows,
+                                  out_c0, plane_prelu, out_hi2, out_lo2, plane_rows2, out_c02, out_cmin, wn, nullptr, 0, stream);
 }
 
 extern "C" int atmvfi_conv3x3_planes(const void* in_hi, const void* in_lo, int64_t in_rows, int N, int H, int W, int Cin, const void* w_hi,

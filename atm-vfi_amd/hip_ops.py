@@ -97,6 +97,8 @@ SIGNATURES = {
     "atmvfi_image_pyramid": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f]),
     "atmvfi_head1x1_planes": (c_i, [c_f, c_f, c_l, c_l, c_i, c_f, c_f, c_i, c_f, c_i, c_f]),
     "atmvfi_conv3x3_planes2": (c_i, [c_f, c_f, c_l, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_l, c_i, c_f, c_f, c_f, c_l, c_i, c_i, c_i, c_f]),
+    "atmvfi_conv3x3_planes3": (c_i, [c_f, c_f, c_l, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_l, c_i, c_f, c_f, c_f, c_l, c_i, c_i, c_i, c_f, c_l, c_f]),
+    "atmvfi_conv3x3_planes_workspace_floats": (c_l, [c_i, c_i, c_i, c_i, c_i]),
     "atmvfi_layernorm": (c_i, [c_f, c_i, c_l, c_i, c_f, c_f, c_i, c_f, c_f, c_l, c_i, c_f, c_f, c_i, c_f]),
     "atmvfi_dwconv3x3_gelu": (c_i, [c_f, c_i, c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f]),
     "atmvfi_pack_dw_weight": (c_i, [c_f, c_f, c_i, c_f]),
@@ -692,11 +694,13 @@ class HipOps:
 
     def conv3x3_planes(self, x: Planes, n: int, h: int, wd: int, w: PackedWeight, out=None, bias=None, prelu=None,
                        planes: Optional[Planes] = None, planes_c0: int = 0, planes_prelu=None, in_chunk0: int = 0, cin: Optional[int] = None,
-                       wn: int = 0, out_cmin: int = 0, planes2: Optional[Planes] = None, planes2_c0: int = 0):
+                       wn: int = 0, out_cmin: int = 0, planes2: Optional[Planes] = None, planes2_c0: int = 0,
+                       workspace: Optional[torch.Tensor] = None):
         """3x3 / stride 1 / pad 1 conv (+bias, PReLU) on split-plane input ``x`` (rows = pixels of an [n,h,wd] map; channels
         ``32*in_chunk0 .. +cin``).  ``out``: fp32 NHWC view or None; ``planes``: plane sink written at channel offset ``planes_c0``
         (its own ``planes_prelu`` applied to that copy only); ``planes2``: a second, raw plane sink.  ``out_cmin``: only channels >= it are stored in ``out``.  Needs the spare
-        zero row of ``Planes.alloc``."""
+        zero row of ``Planes.alloc``.  ``workspace``: fp32 scratch of at least ``conv3x3_workspace_floats(...)`` elements: lets the launcher
+        split K over idle CUs on under-filled grids (split-K with a fixed-order reduce; small frames)."""
         cin = (x.c - 32 * in_chunk0) if cin is None else cin
         if self.precision != "f16x3" or w.hi3 is None:
             raise ValueError("conv3x3_planes: needs the f16x3 engine and the conv3x3 weight planes")
@@ -728,12 +732,19 @@ class HipOps:
         meta = {"flops": 2.0 * n * h * wd * cout * cin * 9, "bytes": 4.0 * (n * h * wd * (cin + cout) + cout * cin * 9),
                 "shape": f"M{n * h * wd} N{cout} K{cin * 9}"}
         coff = in_chunk0 * x.ld_rows * 32 * 2       # bytes
-        self._run("conv3x3_planes", meta, self.lib.atmvfi_conv3x3_planes2, _ptr(x.t[0], coff), _ptr(x.t[1], coff), x.ld_rows,
+        if workspace is not None and (workspace.dtype != torch.float32 or not workspace.is_cuda or not workspace.is_contiguous()):
+            raise ValueError("conv3x3_planes: the split-K workspace must be a contiguous CUDA fp32 tensor")
+        self._run("conv3x3_planes", meta, self.lib.atmvfi_conv3x3_planes3, _ptr(x.t[0], coff), _ptr(x.t[1], coff), x.ld_rows,
                   n, h, wd, cin, _ptr(w.hi3), _ptr(w.lo3), cout, out_ptr, old, _ptr(bias), _ptr(prelu),
                   _ptr(planes.t[0]) if planes is not None else None, _ptr(planes.t[1]) if planes is not None else None,
                   planes.ld_rows if planes is not None else 0, planes_c0, _ptr(planes_prelu) if planes is not None else None,
                   _ptr(planes2.t[0]) if planes2 is not None else None, _ptr(planes2.t[1]) if planes2 is not None else None,
-                  planes2.ld_rows if planes2 is not None else 0, planes2_c0, out_cmin, wn, self._stream())
+                  planes2.ld_rows if planes2 is not None else 0, planes2_c0, out_cmin, wn, _ptr(workspace),
+                  workspace.numel() if workspace is not None else 0, self._stream())
+
+    def conv3x3_workspace_floats(self, n: int, h: int, wd: int, cin: int, cout: int) -> int:
+        """fp32 elements of split-K scratch ``conv3x3_planes`` wants for this shape on this device (0: it would not split)."""
+        return int(self.lib.atmvfi_conv3x3_planes_workspace_floats(n, h, wd, cin, cout))
 
     def head1x1_planes(self, x: Planes, n: int, h: int, wd: int, w: PackedWeight, out, bias=None):
         """nn.Conv2d(Cin, Cout <= 8, 1) on split-plane input (the 5-channel read-out of a motion MLP): one lane per pixel row, fp32 FMAs."""

@@ -213,6 +213,7 @@ class Network(_ParamWatch, BlockRunner, nn.Module):
         self.use_plane_convs = os.environ.get("ATMVFI_PLANE_CONV", "1") != "0"        # A/B switch: 3x3 convs on split-plane input
         self.use_unet_planes = os.environ.get("ATMVFI_UNET_PLANES", "1") != "0"       # A/B switch: the refiner's strided convs on split planes
         self.use_fused_stem = os.environ.get("ATMVFI_FUSED_STEM", "1") != "0"         # A/B switch: the encoder's first three layers in one launch
+        self.use_splitk = os.environ.get("ATMVFI_SPLITK", "1") != "0"                 # A/B switch: split-K of under-filled long-K 3x3 launches
         self._prepared: Dict[str, object] = {}
         self._prepared_sig = None
         # Workspaces: one dict of named buffers per (device, input shape, mode) key, least recently used first.  The reference's
@@ -470,8 +471,15 @@ class Network(_ParamWatch, BlockRunner, nn.Module):
             wk, bias, prelu = wkey or f"pk:{p}.0.weight", P[f"{p}.0.bias"], P[f"{p}.1.weight"]
         else:
             wk, bias, prelu = wkey or f"pk:{p}.weight", P[f"{p}.bias"], None
+        extra = {} if sink2 is None else {"planes2": sink2}
+        if self.use_splitk and hasattr(ops, "conv3x3_workspace_floats"):
+            # under-filled grids with long K (the motion MLPs of small frames): split K over the idle CUs; the scratch for the partial
+            # sums is workspace memory like every other buffer
+            need = ops.conv3x3_workspace_floats(n, h, w, P[wk].cin, P[wk].cout)
+            if need:
+                extra["workspace"] = self.buf("splitk_ws", need)
         ops.conv3x3_planes(xp, n, h, w, P[wk], out=out, bias=bias, prelu=prelu, planes=sink, planes_c0=sink_c0, planes_prelu=sink_prelu,
-                           out_cmin=out_cmin, **({} if sink2 is None else {"planes2": sink2}))
+                           out_cmin=out_cmin, **extra)
 
     def _conv_s2_sink(self, ops, P, p, x, sink, shape, out=None, sink_c0=0):
         """conv() 3x3 stride 2 (+PReLU) on the fp32-input GEMM engine, result to a plane sink (and ``out`` if given)."""
@@ -763,7 +771,7 @@ class Network(_ParamWatch, BlockRunner, nn.Module):
     def _mode_key(self, ops, im0, im1) -> Tuple:
         return (tuple(im0.shape), tuple(im1.shape), str(im0.device), self.global_motion, self.ensemble_global_motion,
                 self._precision, self.use_split_planes, self.use_plane_convs, self.use_unet_planes, self.use_plane_deconvs,
-                self.use_fused_stem, getattr(ops, "attention_f16x3", None), self.local_motion_args["window_size"],
+                self.use_fused_stem, self.use_splitk, getattr(ops, "attention_f16x3", None), self.local_motion_args["window_size"],
                 self.global_motion_args["window_size"], getattr(ops, "warp_tiles", None), getattr(ops, "conv3_instance", None),
                 getattr(ops, "gemm_tile_wn", None), self._workspace_key(im0))
 

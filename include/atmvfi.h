@@ -211,6 +211,18 @@ int atmvfi_conv3x3_planes2(const void* in_hi, const void* in_lo, int64_t in_rows
                            const void* w_lo, int Cout, float* out, int out_ld, const float* bias, const float* prelu, void* out_hi,
                            void* out_lo, int64_t plane_rows, int out_c0, const float* plane_prelu, void* out_hi2, void* out_lo2,
                            int64_t plane_rows2, int out_c02, int out_cmin, int wn, void* stream);
+/* The same with SPLIT-K for launches whose tiles leave most of the chip idle (small frames: the motion-MLP layers of network_lite at
+ * 256 x 256 are 22 workgroups walking 200 k-steps each): with a `workspace` of at least atmvfi_conv3x3_planes_workspace_floats() floats
+ * (16-byte aligned; NULL / too small: no split) the K range is cut into up to 8 ranges of whole 32-channel chunks, one workgroup per
+ * (tile, range) writes raw fp32 partial sums into the workspace and a second kernel adds them IN RANGE ORDER and runs the epilogue
+ * (bias, PReLU, fp32 rows, plane sinks).  Run-to-run deterministic; differs from the unsplit launch by fp32 summation order only
+ * (the reference's conv, network_base.py:20-25, fixes no order either).  atmvfi_conv3x3_planes_workspace_floats returns 0 when the
+ * launcher would not split that shape on this device. */
+int64_t atmvfi_conv3x3_planes_workspace_floats(int N, int H, int W, int Cin, int Cout);
+int atmvfi_conv3x3_planes3(const void* in_hi, const void* in_lo, int64_t in_rows, int N, int H, int W, int Cin, const void* w_hi,
+                           const void* w_lo, int Cout, float* out, int out_ld, const float* bias, const float* prelu, void* out_hi,
+                           void* out_lo, int64_t plane_rows, int out_c0, const float* plane_prelu, void* out_hi2, void* out_lo2,
+                           int64_t plane_rows2, int out_c02, int out_cmin, int wn, float* workspace, int64_t workspace_floats, void* stream);
 /* ------------------------------------------------------------------------------------
  * LayerNorm over the channel axis of token rows (eps 1e-5, affine), optional gather.
  * Replaces nn.LayerNorm at attention.py:316 (norm1 on windowed tokens), :333 (norm2) and

@@ -770,6 +770,66 @@ def test_conv3x3_planes_every_width(wn, hip, cpu, dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", [(1, 16, 16, 712, 352, 0), (1, 32, 32, 456, 224, 0), (1, 36, 60, 1352, 768, 0), (2, 21, 35, 520, 61, 0),
+                                  (1, 32, 32, 456, 224, 4), (1, 20, 28, 392, 101, 0)],
+                         ids=lambda c: f"n{c[0]}_{c[1]}x{c[2]}_cin{c[3]}_cout{c[4]}_wn{c[5]}")
+def test_conv3x3_planes_split_k(case, hip, dev):
+    """Split-K of under-filled long-K launches (atmvfi_conv3x3_planes3 with a workspace; the motion-MLP shapes of network_lite at
+    256 x 256 / 256 x 448 and of network_base at 576 x 960, ragged images, tap-packed tails, ragged Cout): K ranges by whole chunks,
+    raw fp32 partial sums, a fixed-order reduce with the whole epilogue (bias, PReLU, fp32 rows from out_cmin on, both plane sinks, the
+    first through its own PReLU).  Against the unsplit launch: equal within fp32 summation-order error (1e-5 of the value scale);
+    two split launches are bit-identical; pad channels of the planes stay zero; without a workspace nothing changes."""
+    N, H, W, cin, cout, wn = case
+    g = torch.Generator().manual_seed(7100 + cin + cout + H)
+    need = hip.conv3x3_workspace_floats(N, H, W, cin, cout)
+    assert need > 0, "the launcher does not split this shape: the case tests nothing"
+    xp = hip_ops.Planes.alloc(N * H * W, cin, dev)
+    x = rnd(g, N * H * W, (cin + 3) // 4 * 4, scale=1.5).to(dev)[:, :cin]
+    hip.split_planes(x, xp)
+    wt = rnd(g, cout, cin, 3, 3, scale=1.0 / np.sqrt(9 * cin)).to(dev)
+    bias, slope = rnd(g, cout, scale=0.2).to(dev), (torch.rand(cout, generator=g) * 0.4).to(dev)
+    pslope = torch.zeros((cout + 31) // 32 * 32, device=dev)
+    pslope[:cout] = torch.rand(cout, generator=g).to(dev)
+    pw = hip.pack_weight(GEMM_CONV, wt)
+    ws = torch.empty(need, device=dev)
+    cmin = (cout - 5) // 4 * 4
+    r4 = lambda c: (c + 3) // 4 * 4
+
+    def launch(workspace):
+        y = torch.full((N, H, W, r4(cout)), 7.0, device=dev)
+        ycmp = torch.full((N, H, W, 8), 7.0, device=dev)
+        s1 = hip_ops.Planes.alloc(N * H * W, 8 + cout, dev)
+        s2 = hip_ops.Planes.alloc(N * H * W, cout, dev)
+        hip.conv3x3_planes(xp, N, H, W, pw, out=y[..., :cout], bias=bias, prelu=slope, wn=wn, workspace=workspace)
+        hip.conv3x3_planes(xp, N, H, W, pw, out=ycmp[..., :cout - cmin], bias=bias, prelu=None, planes=s1, planes_c0=8, planes_prelu=pslope,
+                           planes2=s2, out_cmin=cmin, wn=wn, workspace=workspace)
+        torch.cuda.synchronize()
+        return y, ycmp, s1, s2
+    y0, c0_, a0, b0 = launch(None)
+    y1, c1_, a1, b1 = launch(ws)
+    y2, c2_, a2, b2 = launch(ws)
+    scale = max(1.0, float(y0[..., :cout].abs().max()))
+    assert not torch.equal(y0, y1), "the workspace launch produced the unsplit result bit for bit: no split happened"
+    assert maxdiff(y0[..., :cout], y1[..., :cout]) <= 1e-5 * scale
+    assert (y1[..., cout:] == 7.0).all()
+    assert maxdiff(c0_[..., :cout - cmin], c1_[..., :cout - cmin]) <= 1e-5 * scale and (c1_[..., cout - cmin:] == 7.0).all()
+    for p0, p1 in ((a0, a1), (b0, b1)):
+        assert maxdiff(p0.to_float(), p1.to_float()) <= 1e-5 * scale
+        assert (p1.t[:, :, N * H * W:] == 0).all()
+    assert (a1.to_rows()[:, :, :8] == 0).all() and (a1.to_rows()[:, :, 8 + cout:] == 0).all() and (b1.to_rows()[:, :, cout:] == 0).all()
+    # the second sink is the raw map: exactly the split of the fp32 result without the first sink's PReLU
+    q = hip_ops.Planes.alloc(N * H * W, cout, dev)
+    yraw = torch.full((N, H, W, r4(cout)), 7.0, device=dev)
+    hip.conv3x3_planes(xp, N, H, W, pw, out=yraw[..., :cout], bias=bias, prelu=None, wn=wn, workspace=ws)
+    hip.split_planes(yraw[..., :cout].flatten(0, 2), q)
+    torch.cuda.synchronize()
+    assert torch.equal(b1.to_rows()[:, :, :cout], q.to_rows()[:, :, :cout])
+    assert torch.equal(c1_[..., :cout - cmin], yraw[..., cmin:cout])
+    # run-to-run determinism of the split launch
+    assert torch.equal(y1, y2) and torch.equal(c1_, c2_) and torch.equal(a1.t, a2.t) and torch.equal(b1.t, b2.t)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", [(64, 64, 0), (101, 101, 0), (200, 130, 0), (72, 40, 3), (37, 200, 8), (136, 389, 0)],
                          ids=lambda c: f"cin{c[0]}_cout{c[1]}_wn{c[2]}")
 def test_conv3x3_planes_persistent_grid(case, hip, dev):

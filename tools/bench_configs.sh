@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-F="--no-cpu-baseline --no-host-io --no-profile"
+F="--no-cpu-baseline --no-host-io --no-profile --no-configs"
 python bench.py --config c1 --steps 50 --warmup 10 $F > gpurun_out/cfg_c1.json 2>/dev/null
 python bench.py --config c2 --steps 50 --warmup 10 $F > gpurun_out/cfg_c2.json 2>/dev/null
 python bench.py --config c3 --steps 20 --warmup 5 $F > gpurun_out/cfg_c3.json 2>/dev/null

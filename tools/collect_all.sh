@@ -1,6 +1,6 @@
 # Full evidence set of one build on one box (one gpurun call): bench line, rocprofv3 kernel stats, HBM traffic, SQ / LDS / cache
 # counters, all configs.   bash tools/collect_all.sh <tag>
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd $GRAFT_REPO_ROOT
 bash tools/collect_profiles.sh $TAG
 rm -f gpurun_out/sq_summary.txt
