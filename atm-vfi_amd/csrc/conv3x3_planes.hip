@@ -72,6 +72,13 @@ struct Conv3PDev {
     // kernel adds the partial sums in split order and runs the epilogue.  1 = off.
     int ksplit, cps;
     long long part_stride;
+    // fused read-out (refine_head.0 -> refine_head.1, network_base.py:257-260; WN = 2 or 4, one column block): the tile's activated
+    // output -- still in registers, in the accumulator layout, which IS the B-operand layout of the next MFMA -- is multiplied by the
+    // 27 x Cout matrix W2[(tap, o)][c] of the following 3-output 3x3 convolution; the 27 per-pixel "tap contributions" go to planar
+    // fp32 h2_out[(tap * 3 + o) * h2_plane + pixel] and atmvfi_refine_tail adds each output pixel's nine shifted contributions.
+    const _Float16* h2_w;       // [plane hi / lo][row tile 2][k-step WN/2][lane 64][8 halves], k order = this kernel's register order
+    float* h2_out;
+    long long h2_plane;
     unsigned long long* stamp;  // diagnostic builds only (ATMVFI_STAMP)
     int dbg;                    // diagnostic builds only: ATMVFI_P3_DBG bits switch pieces of the loop off (wrong results, timing only)
 };
@@ -492,6 +499,57 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
             vv[i][j] = v;
         }
     }
+    if constexpr (WN == 2 || WN == 4) {
+        if (a.h2_w) {
+            constexpr int KK = WN / 2;
+            const f16x8* wp = reinterpret_cast<const f16x8*>(a.h2_w);
+            f16x8 w2h[2][KK], w2l[2][KK];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int kk = 0; kk < KK; ++kk) {
+                    w2h[t][kk] = wp[(t * KK + kk) * 64 + lane];
+                    w2l[t][kk] = wp[((2 + t) * KK + kk) * 64 + lane];
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                f32x4 a2[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+                f32x4 c2[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int kk = 0; kk < KK; ++kk) {
+                    // the lane's eight k values of this k-step: its four channels of n-tile 2 kk and of n-tile 2 kk + 1
+                    const f32x4 u0 = vv[i][2 * kk], u1 = vv[i][2 * kk + 1];
+                    f16x2 h0, l0, h1, l1, h2, l2, h3, l3;
+                    split_pair((f32x2){u0.x, u0.y}, h0, l0);
+                    split_pair((f32x2){u0.z, u0.w}, h1, l1);
+                    split_pair((f32x2){u1.x, u1.y}, h2, l2);
+                    split_pair((f32x2){u1.z, u1.w}, h3, l3);
+                    const f16x8 bh = {h0.x, h0.y, h1.x, h1.y, h2.x, h2.y, h3.x, h3.y};
+                    const f16x8 bl = {l0.x, l0.y, l1.x, l1.y, l2.x, l2.y, l3.x, l3.y};
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        c2[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2l[t][kk], bh, c2[t], 0, 0, 0);
+                        a2[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2h[t][kk], bh, a2[t], 0, 0, 0);
+                        c2[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2h[t][kk], bl, c2[t], 0, 0, 0);
+                    }
+                }
+                // rows 4 g .. 4 g + 3 of row tile t = contributions (tap * 3 + o) = 16 t + 4 g + e of pixel r: planar, so that the 16
+                // lanes of a row group write 64 contiguous bytes and the gather pass reads coalesced
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const f32x4 tv = a2[t] + c2[t] * LO_UNSCALE;
+                    const int row = 16 * t + 4 * g;
+                    float* tp = a.h2_out + (long long)row * a.h2_plane + prow_o[i];
+                    if (live[i]) {
+                        if (row + 0 < 27) tp[0] = tv.x;
+                        if (row + 1 < 27) tp[a.h2_plane] = tv.y;
+                        if (row + 2 < 27) tp[2 * a.h2_plane] = tv.z;
+                        if (row + 3 < 27) tp[3 * a.h2_plane] = tv.w;
+                    }
+                }
+            }
+        }
+    }
     if (out_f32) {
         // fp32 NHWC rows: 16 bytes per lane, the four lanes of a pixel cover 64 contiguous bytes.  Only channels >= out_cmin are
         // wanted in fp32 (e.g. the five flow / mask channels of a decoder map whose features go on as planes).
@@ -751,12 +809,28 @@ extern "C" int64_t atmvfi_conv3x3_planes_workspace_floats(int N, int H, int W, i
     return p.ksplit > 1 ? (int64_t)p.ksplit * N * H * W * atmvfi::round_up(Cout, 16) : 0;
 }
 
+static int conv3x3_planes_impl(const void* in_hi, const void* in_lo, int64_t in_rows, int N, int H, int W, int Cin, const void* w_hi,
+                               const void* w_lo, int Cout, float* out, int out_ld, const float* bias, const float* prelu, void* out_hi,
+                               void* out_lo, int64_t plane_rows, int out_c0, const float* plane_prelu, void* out_hi2, void* out_lo2,
+                               int64_t plane_rows2, int out_c02, int out_cmin, int wn, float* workspace, int64_t workspace_floats,
+                               const void* h2_w, float* h2_out, int64_t h2_plane, void* stream);
+
 extern "C" int atmvfi_conv3x3_planes3(const void* in_hi, const void* in_lo, int64_t in_rows, int N, int H, int W, int Cin, const void* w_hi,
                                        const void* w_lo, int Cout, float* out, int out_ld, const float* bias, const float* prelu,
                                        void* out_hi, void* out_lo, int64_t plane_rows, int out_c0, const float* plane_prelu, void* out_hi2,
                                        void* out_lo2, int64_t plane_rows2, int out_c02, int out_cmin, int wn, float* workspace,
                                        int64_t workspace_floats, void* stream) {
     ATMVFI_REQUIRE(in_hi && in_lo && w_hi && w_lo && (out || out_hi), ATMVFI_EINVAL, "conv3x3_planes: null pointer");
+    return conv3x3_planes_impl(in_hi, in_lo, in_rows, N, H, W, Cin, w_hi, w_lo, Cout, out, out_ld, bias, prelu, out_hi, out_lo, plane_rows, out_c0,
+                               plane_prelu, out_hi2, out_lo2, plane_rows2, out_c02, out_cmin, wn, workspace, workspace_floats, nullptr, nullptr, 0,
+                               stream);
+}
+
+static int conv3x3_planes_impl(const void* in_hi, const void* in_lo, int64_t in_rows, int N, int H, int W, int Cin, const void* w_hi,
+                               const void* w_lo, int Cout, float* out, int out_ld, const float* bias, const float* prelu, void* out_hi,
+                               void* out_lo, int64_t plane_rows, int out_c0, const float* plane_prelu, void* out_hi2, void* out_lo2,
+                               int64_t plane_rows2, int out_c02, int out_cmin, int wn, float* workspace, int64_t workspace_floats,
+                               const void* h2_w, float* h2_out, int64_t h2_plane, void* stream) {
     ATMVFI_REQUIRE((out_hi2 == nullptr) == (out_lo2 == nullptr), ATMVFI_EINVAL, "conv3x3_planes: the second plane sink needs both planes");
     if (out_hi2)
         ATMVFI_REQUIRE(out_hi && plane_rows2 >= (int64_t)N * H * W && out_c02 >= 0 && out_c02 % 8 == 0 && atmvfi::aligned16(out_hi2) &&
@@ -795,6 +869,7 @@ extern "C" int atmvfi_conv3x3_planes3(const void* in_hi, const void* in_lo, int6
     d.out_cmin = out_cmin;
     d.tiles_x = (W + TW - 1) / TW;
     d.tiles_y = 0; d.nblocks = 0; d.tchunk = 0;
+    d.h2_w = (const _Float16*)h2_w; d.h2_out = h2_out; d.h2_plane = h2_plane;
     const int ntiles = (Cout + 15) / 16;
     ATMVFI_REQUIRE(!workspace || atmvfi::aligned16(workspace), ATMVFI_EALIGN, "conv3x3_planes: the split-K workspace must be 16-byte aligned");
     Conv3Plan plan = conv3_plan(N, H, W, Cin, Cout, wn, workspace != nullptr);
@@ -828,6 +903,17 @@ extern "C" int atmvfi_conv3x3_planes3(const void* in_hi, const void* in_lo, int6
                        full.bias, full.prelu, full.out, full.out_ld, full.out_cmin, full.out_hi, full.out_lo, (long long)full.plane_rows,
                        full.out_c0, full.plane_prelu, full.out_hi2, full.out_lo2, (long long)full.plane_rows2, full.out_c02);
     return atmvfi::check_launch("conv3x3_planes (split-K reduce)");
+}
+
+extern "C" int atmvfi_conv3x3_planes_readout(const void* in_hi, const void* in_lo, int64_t in_rows, int N, int H, int W, int Cin,
+                                              const void* w_hi, const void* w_lo, int Cout, const float* bias, const float* prelu,
+                                              const void* w2, float* contrib, int64_t contrib_plane, void* stream) {
+    ATMVFI_REQUIRE(in_hi && in_lo && w_hi && w_lo && w2 && contrib, ATMVFI_EINVAL, "conv3x3_planes_readout: null pointer");
+    ATMVFI_REQUIRE(Cout == 32 || Cout == 64, ATMVFI_EINVAL, "conv3x3_planes_readout: Cout must be 32 or 64 (one column block of 2 or 4 n-tiles), got %d", Cout);
+    ATMVFI_REQUIRE(contrib_plane >= (int64_t)N * H * W && atmvfi::aligned16(w2), ATMVFI_EINVAL,
+                   "conv3x3_planes_readout: contrib_plane must cover N*H*W pixels and w2 must be 16-byte aligned");
+    return conv3x3_planes_impl(in_hi, in_lo, in_rows, N, H, W, Cin, w_hi, w_lo, Cout, nullptr, 0, bias, prelu, nullptr, nullptr, 0, 0, nullptr,
+                               nullptr, nullptr, 0, 0, 0, Cout / 16, nullptr, 0, w2, contrib, contrib_plane, stream);
 }
 
 extern "C" int atmvfi_conv3x3_planes2(const void* in_hi, const void* in_lo, int64_t in_rows, int N, int H, int W, int Cin, const void* w_hi,

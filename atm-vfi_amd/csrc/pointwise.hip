@@ -836,6 +836,50 @@ __global__ __launch_bounds__(256) void final_residual_kernel(const float* __rest
     }
 }
 
+// refine_head.1 (nn.Conv2d(C, 3, 3, padding 1) + PReLU) -> 2 * sigmoid - 1 -> += I_t -> clamp (network_base.py:257-260, 429, 532-533) from
+// the per-pixel tap contributions T[(tap * 3 + o)][pixel] = sum_c w[o][c][tap] * r1[pixel][c] that atmvfi_conv3x3_planes_readout left
+// (planar fp32): out[o][p] = bias[o] + sum over taps of T[tap * 3 + o][p + offset(tap)], taps outside the image contributing nothing
+// (the zero padding of the convolution).  One thread per pixel; every load is coalesced.
+__global__ __launch_bounds__(256) void refine_tail_kernel(const float* __restrict__ T, long long plane, const float* __restrict__ bias,
+                                                          const float* __restrict__ slope, const float* __restrict__ it,
+                                                          float* __restrict__ it_sum, float* __restrict__ it_clamped, int B, int H, int W) {
+    fp16_saturate_on();
+    const long long hw = (long long)H * W;
+    const long long total = (long long)B * hw;
+    const float b0 = bias ? bias[0] : 0.f, b1 = bias ? bias[1] : 0.f, b2 = bias ? bias[2] : 0.f;
+    const float s0 = slope ? slope[0] : 1.f, s1 = slope ? slope[1] : 1.f, s2 = slope ? slope[2] : 1.f;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(idx / hw);
+        const long long pix = idx - (long long)b * hw;
+        const int y = (int)(pix / W), x = (int)(pix - (long long)y * W);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int yy = y + ky - 1, xx = x + kx - 1;
+                if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
+                    const float* tp = T + (long long)((ky * 3 + kx) * 3) * plane + idx + (long long)(ky - 1) * W + (kx - 1);
+                    a0 += tp[0];
+                    a1 += tp[plane];
+                    a2 += tp[2 * plane];
+                }
+            }
+        float r[3] = {a0 + b0, a1 + b1, a2 + b2};
+        r[0] = r[0] > 0.f ? r[0] : s0 * r[0];
+        r[1] = r[1] > 0.f ? r[1] : s1 * r[1];
+        r[2] = r[2] > 0.f ? r[2] : s2 * r[2];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const long long o = ((long long)b * 3 + ch) * hw + pix;
+            const float v = it[o] + (2.0f * sigmoidf_(r[ch]) - 1.0f);
+            it_sum[o] = v;
+            it_clamped[o] = fminf(fmaxf(v, 0.0f), 1.0f);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void l1_mean_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                       float* __restrict__ out, long long per_sample) {
     fp16_saturate_on();
@@ -1081,6 +1125,15 @@ extern "C" int atmvfi_final_residual(const float* it, const float* r, int r_ld, 
     hipLaunchKernelGGL(final_residual_kernel, dim3(grid_for((long long)B * H * W)), dim3(256), 0, (hipStream_t)stream, it, r,
                        r_ld, it_sum, it_clamped, B, H, W);
     return atmvfi::check_launch("final_residual");
+}
+
+extern "C" int atmvfi_refine_tail(const float* contrib, int64_t contrib_plane, const float* bias, const float* slope, const float* it,
+                                  float* it_sum, float* it_clamped, int B, int H, int W, void* stream) {
+    ATMVFI_REQUIRE(contrib && it && it_sum && it_clamped && B > 0 && H > 0 && W > 0 && contrib_plane >= (int64_t)B * H * W, ATMVFI_EINVAL,
+                   "refine_tail: bad arguments");
+    hipLaunchKernelGGL(refine_tail_kernel, dim3(grid_for((long long)B * H * W)), dim3(256), 0, (hipStream_t)stream, contrib,
+                       (long long)contrib_plane, bias, slope, it, it_sum, it_clamped, B, H, W);
+    return atmvfi::check_launch("refine_tail");
 }
 
 extern "C" int atmvfi_l1_mean(const float* a, const float* b, float* out, int B, int64_t per_sample, void* stream) {

@@ -99,6 +99,8 @@ SIGNATURES = {
     "atmvfi_conv3x3_planes2": (c_i, [c_f, c_f, c_l, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_l, c_i, c_f, c_f, c_f, c_l, c_i, c_i, c_i, c_f]),
     "atmvfi_conv3x3_planes3": (c_i, [c_f, c_f, c_l, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_l, c_i, c_f, c_f, c_f, c_l, c_i, c_i, c_i, c_f, c_l, c_f]),
     "atmvfi_conv3x3_planes_workspace_floats": (c_l, [c_i, c_i, c_i, c_i, c_i]),
+    "atmvfi_conv3x3_planes_readout": (c_i, [c_f, c_f, c_l, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_f, c_f, c_f, c_l, c_f]),
+    "atmvfi_refine_tail": (c_i, [c_f, c_l, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f]),
     "atmvfi_layernorm": (c_i, [c_f, c_i, c_l, c_i, c_f, c_f, c_i, c_f, c_f, c_l, c_i, c_f, c_f, c_i, c_f]),
     "atmvfi_dwconv3x3_gelu": (c_i, [c_f, c_i, c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f]),
     "atmvfi_pack_dw_weight": (c_i, [c_f, c_f, c_i, c_f]),
@@ -741,6 +743,52 @@ class HipOps:
                   _ptr(planes2.t[0]) if planes2 is not None else None, _ptr(planes2.t[1]) if planes2 is not None else None,
                   planes2.ld_rows if planes2 is not None else 0, planes2_c0, out_cmin, wn, _ptr(workspace),
                   workspace.numel() if workspace is not None else 0, self._stream())
+
+    def pack_readout(self, w: torch.Tensor) -> torch.Tensor:
+        """Operand of ``atmvfi_conv3x3_planes_readout``: refine_head.1's weight [3, C, 3, 3] (C = 32 or 64) as the 27 x C matrix
+        W2[(tap, o)][c], hi / lo' split, in the producing kernel's register order: fp16 [plane][row tile 2][k-step C / 32][lane][8] with
+        lane = 16 g + r -> row 16 t + r, and the lane's eight k values = its four channels of n-tile 2 kk and of n-tile 2 kk + 1
+        (channels 32 kk + cb(g) + e and 32 kk + 16 + cb(g) + e, cb = {0, 8, 4, 12}[g]).  Host-side torch ops, once per parameter version."""
+        o3, c, kh, kw = w.shape
+        if (o3, kh, kw) != (3, 3, 3) or c not in (32, 64):
+            raise ValueError(f"pack_readout: expected a [3, 32 | 64, 3, 3] weight, got {tuple(w.shape)}")
+        w2 = torch.zeros(32, c, dtype=torch.float32, device=self.device)
+        w2[:27] = w.detach().float().permute(2, 3, 0, 1).reshape(27, c)            # row = (ky * 3 + kx) * 3 + o
+        kk_n = c // 32
+        lane = torch.arange(64, device=self.device)
+        r, g = lane & 15, lane >> 4
+        cb = 8 * (g & 1) + 4 * (g >> 1)
+        e = torch.arange(8, device=self.device)
+        ch = cb[:, None] + torch.where(e < 4, e, 16 + e - 4)[None, :]            # [lane, 8] channel inside a 32-channel k-step
+        full = torch.empty(2, kk_n, 64, 8, dtype=torch.float32, device=self.device)
+        for t in range(2):
+            for kk in range(kk_n):
+                full[t, kk] = w2[(16 * t + r)[:, None].expand(64, 8), 32 * kk + ch]
+        hi = full.half()
+        lo = ((full - hi.float()) * 1024.0).half()
+        return torch.stack([hi, lo], 0).contiguous()
+
+    def conv3x3_planes_readout(self, x: Planes, n: int, h: int, wd: int, w: PackedWeight, bias, prelu, w2: torch.Tensor, contrib: torch.Tensor):
+        """refine_head.0 (3x3 conv + PReLU on split-plane input, Cout 32 or 64) with refine_head.1's 27 tap contributions per pixel
+        computed in its epilogue: contrib [27, n*h*wd] planar fp32 (include/atmvfi.h)."""
+        if self.precision != "f16x3" or w.hi3 is None or w.kh != 3 or w.cin > x.chunks * 32 or x.rows != n * h * wd or x.ld_rows <= x.rows:
+            raise ValueError("conv3x3_planes_readout: needs the f16x3 engine, conv3x3 weight planes and input planes with a spare zero row")
+        if w.cout not in (32, 64) or tuple(w2.shape) != (2, 2, w.cout // 32, 64, 8) or w2.dtype != torch.float16:
+            raise ValueError("conv3x3_planes_readout: Cout must be 32 or 64 and w2 the pack_readout() operand of that width")
+        if contrib.dtype != torch.float32 or contrib.dim() != 2 or contrib.shape[0] != 27 or contrib.shape[1] < n * h * wd or not contrib.is_contiguous():
+            raise ValueError("conv3x3_planes_readout: contrib must be contiguous fp32 [27, >= N*H*W]")
+        meta = {"flops": 2.0 * n * h * wd * w.cout * (w.cin * 9 + 27), "bytes": 4.0 * n * h * wd * (w.cin + 27), "shape": f"M{n * h * wd} N{w.cout} K{w.cin * 9} +27"}
+        self._run("conv3x3_planes", meta, self.lib.atmvfi_conv3x3_planes_readout, _ptr(x.t[0]), _ptr(x.t[1]), x.ld_rows, n, h, wd, w.cin,
+                  _ptr(w.hi3), _ptr(w.lo3), w.cout, _ptr(bias), _ptr(prelu), _ptr(w2), _ptr(contrib), contrib.shape[1], self._stream())
+
+    def refine_tail(self, contrib, bias, slope, it, it_sum, it_clamped):
+        """out = clamp(it + 2 * sigmoid(PReLU(bias + sum of the nine shifted tap contributions)) - 1): refine_head.1 + the residual."""
+        _planar(it, 3, "refine_tail.it"); _planar(it_sum, 3, "refine_tail.sum"); _planar(it_clamped, 3, "refine_tail.clamped")
+        b, _, h, w = it.shape
+        if contrib.dim() != 2 or contrib.shape[0] != 27 or contrib.shape[1] < b * h * w or not contrib.is_contiguous():
+            raise ValueError("refine_tail: contrib must be contiguous fp32 [27, >= B*H*W]")
+        self._run("refine_tail", {"bytes": 4.0 * b * h * w * (27 + 9)}, self.lib.atmvfi_refine_tail, _ptr(contrib), contrib.shape[1], _ptr(bias),
+                  _ptr(slope), _ptr(it), _ptr(it_sum), _ptr(it_clamped), b, h, w, self._stream())
 
     def conv3x3_workspace_floats(self, n: int, h: int, wd: int, cin: int, cout: int) -> int:
         """fp32 elements of split-K scratch ``conv3x3_planes`` wants for this shape on this device (0: it would not split)."""

@@ -213,6 +213,7 @@ class Network(_ParamWatch, BlockRunner, nn.Module):
         self.use_plane_convs = os.environ.get("ATMVFI_PLANE_CONV", "1") != "0"        # A/B switch: 3x3 convs on split-plane input
         self.use_unet_planes = os.environ.get("ATMVFI_UNET_PLANES", "1") != "0"       # A/B switch: the refiner's strided convs on split planes
         self.use_fused_stem = os.environ.get("ATMVFI_FUSED_STEM", "1") != "0"         # A/B switch: the encoder's first three layers in one launch
+        self.use_fused_tail = os.environ.get("ATMVFI_FUSED_TAIL", "1") != "0"         # A/B switch: refine_head.1 folded into refine_head.0's epilogue
         self.use_splitk = os.environ.get("ATMVFI_SPLITK", "1") != "0"                 # A/B switch: split-K of under-filled long-K 3x3 launches
         self._prepared: Dict[str, object] = {}
         self._prepared_sig = None
@@ -430,6 +431,8 @@ class Network(_ParamWatch, BlockRunner, nn.Module):
             wp = sd["proj.0.weight"].detach()
             wpp = torch.cat([wp[:, :w3], torch.zeros(wp.shape[0], gap, 3, 3, dtype=wp.dtype, device=wp.device), wp[:, w3:]], 1)
             P["pk:proj.0.weight:planes"] = ops.pack_weight(GEMM_CONV, wpp.contiguous())
+        if hasattr(ops, "pack_readout") and getattr(ops, "split_planes_ok", False) and self._v.refine_hidden in (32, 64):
+            P["readout"] = ops.pack_readout(sd["refine_head.1.0.weight"].detach())
         if hasattr(ops, "pack_stem") and getattr(ops, "split_planes_ok", False):
             P["stem"] = ops.pack_stem(*(sd[f"feat_extracts.{a}.{b}"].detach() for a in ("0.0", "0.1", "1.0") for b in ("0.weight", "0.bias", "1.weight")))
         # f16x3 contraction operands saturate at +-65504 (deviation 2).  Weights are known here: say so once per
@@ -771,7 +774,7 @@ class Network(_ParamWatch, BlockRunner, nn.Module):
     def _mode_key(self, ops, im0, im1) -> Tuple:
         return (tuple(im0.shape), tuple(im1.shape), str(im0.device), self.global_motion, self.ensemble_global_motion,
                 self._precision, self.use_split_planes, self.use_plane_convs, self.use_unet_planes, self.use_plane_deconvs,
-                self.use_fused_stem, self.use_splitk, getattr(ops, "attention_f16x3", None), self.local_motion_args["window_size"],
+                self.use_fused_stem, self.use_splitk, self.use_fused_tail, getattr(ops, "attention_f16x3", None), self.local_motion_args["window_size"],
                 self.global_motion_args["window_size"], getattr(ops, "warp_tiles", None), getattr(ops, "conv3_instance", None),
                 getattr(ops, "gemm_tile_wn", None), self._workspace_key(im0))
 
@@ -1105,7 +1108,7 @@ class Network(_ParamWatch, BlockRunner, nn.Module):
                     ops.warp_blend(pyr0[scale], pyr1[scale], mot, a, c, t)
                 w0_list.insert(0, a); w1_list.insert(0, c); it_list.insert(0, t)
             # residual refinement U-Net (:417-431)
-            r1 = self.buf("r1", b, H, W, rh)
+            r1 = None
             if pc:
                 h2, w2, h4, w4 = H // 2, W // 2, H // 4, W // 4
                 bufA_p = self.planes("bufA_p", b * H * W, 2 * rh)                  # [up3 out | feat0]
@@ -1147,8 +1150,20 @@ class Network(_ParamWatch, BlockRunner, nn.Module):
                 self._c3p(ops, P, "up2.1", u2a_p, b, h2, w2, sink=bufB_p, sink_c0=0)
                 ops.deconv(None, P["pk:up3.0.0.weight"], None, bias=P["up3.0.0.bias"], prelu=P["up3.0.1.weight"], planes=bufB_p, sink=bufA_p,
                            in_shape=(b, h2, w2, 2 * rh))
-                self._c3p(ops, P, "refine_head.0", bufA_p, b, H, W, out=r1)
+                fused_tail = self.use_fused_tail and "readout" in P and hasattr(ops, "conv3x3_planes_readout")
+                if fused_tail:
+                    # refine_head.0 -> refine_head.1 -> 2 sigmoid - 1 -> += -> clamp in two launches; the 64-channel full-resolution
+                    # map r1 never reaches HBM: the first launch leaves 27 "tap contributions" per pixel, the second adds the nine
+                    # shifted ones of every output pixel (include/atmvfi.h, atmvfi_conv3x3_planes_readout)
+                    contrib = self.buf("tail_contrib", 27, b * H * W)
+                    ops.conv3x3_planes_readout(bufA_p, b, H, W, P["pk:refine_head.0.0.weight"], P["refine_head.0.0.bias"],
+                                               P["refine_head.0.1.weight"], P["readout"], contrib)
+                else:
+                    r1 = self.buf("r1", b, H, W, rh)
+                    self._c3p(ops, P, "refine_head.0", bufA_p, b, H, W, out=r1)
             else:
+                fused_tail = False
+                r1 = self.buf("r1", b, H, W, rh)
                 feat0 = bufA[..., rh:2 * rh]; self._conv_act(ops, P, "proj", rin, feat0)
                 feat1 = bufB[..., rh:2 * rh]; self._conv_act(ops, P, "down1.0", feat0, feat1, 2)
                 d2a = self.buf("d2a", b, H // 4, W // 4, 2 * rh); self._conv_act(ops, P, "down2.0", bufB[..., rh:2 * rh + w2d], d2a, 2)
@@ -1162,9 +1177,12 @@ class Network(_ParamWatch, BlockRunner, nn.Module):
                 self._conv_act(ops, P, "up2.1", u2a, bufB[..., 0:rh])
                 self._deconv_act(ops, P, "up3.0", bufB[..., 0:2 * rh], bufA[..., 0:rh])
                 self._conv_act(ops, P, "refine_head.0", bufA, r1)
-            r = self.buf("r", b, H, W, 4); self._conv_act(ops, P, "refine_head.1", r1, r[..., :3])
             it_sum, it_final = ops.empty(b, 3, H, W), ops.empty(b, 3, H, W)
-            ops.final_residual(it_list[0], r[..., :3], it_sum, it_final)
+            if fused_tail:
+                ops.refine_tail(contrib, P["refine_head.1.0.bias"], P["refine_head.1.1.weight"], it_list[0], it_sum, it_final)
+            else:
+                r = self.buf("r", b, H, W, 4); self._conv_act(ops, P, "refine_head.1", r1, r[..., :3])
+                ops.final_residual(it_list[0], r[..., :3], it_sum, it_final)
             i_t_0, i_t_1 = w0_list[0], w1_list[0]
             it_list[0] = it_sum          # the reference adds the residual in place (network_base.py:532)
         return {"I_t": it_final, "im_t_list": it_list, "im0_warped_list": w0_list, "im1_warped_list": w1_list,

@@ -363,6 +363,22 @@ int atmvfi_pack_frames(const float* im0, const float* im1, float* dst /*[2B,H,W,
 int atmvfi_final_residual(const float* it /*[B,3,H,W]*/, const float* r, int r_ld,
                           float* it_sum, float* it_clamped, int B, int H, int W, void* stream);
 
+/* The tail of the refiner in two launches instead of three, without the 64-channel full-resolution map r1 ever reaching HBM
+ * (network_base.py:257-260 refine_head = conv(2c, c) + PReLU, conv(c, 3) + PReLU; :429 2 * sigmoid - 1; :532-533 += , clamp):
+ *  - atmvfi_conv3x3_planes_readout: refine_head.0 as atmvfi_conv3x3_planes (Cout = 32 or 64: one column block) whose epilogue multiplies
+ *    the activated tile -- still in registers, in the accumulator layout, which is the B-operand layout of the next MFMA -- by the
+ *    27 x Cout matrix W2[(tap, o)][c] = refine_head.1's weight [o][c][tap] (f16x3 like every contraction) and stores the 27 per-pixel
+ *    "tap contributions" as planar fp32 contrib[(tap * 3 + o) * contrib_plane + pixel].  w2: fp16 [plane hi / lo'][row tile 2]
+ *    [k-step Cout / 32][lane 64][8] in the kernel's register order (hip_ops.HipOps.pack_readout builds it);
+ *  - atmvfi_refine_tail: out[o][p] = bias[o] + sum over the nine taps of contrib[tap * 3 + o][p + offset(tap)] (taps outside the image
+ *    contribute nothing: the convolution's zero padding), PReLU(slope), 2 * sigmoid - 1, + it, and the clamped frame -- the outputs of
+ *    atmvfi_final_residual. */
+int atmvfi_conv3x3_planes_readout(const void* in_hi, const void* in_lo, int64_t in_rows, int N, int H, int W, int Cin, const void* w_hi,
+                                  const void* w_lo, int Cout, const float* bias, const float* prelu, const void* w2, float* contrib,
+                                  int64_t contrib_plane, void* stream);
+int atmvfi_refine_tail(const float* contrib, int64_t contrib_plane, const float* bias /*[3] or NULL*/, const float* slope /*[3] or NULL*/,
+                       const float* it /*[B,3,H,W]*/, float* it_sum, float* it_clamped, int B, int H, int W, void* stream);
+
 /* Host-boundary frame formats (demo_2x.py:64-85 inference_2frame + benchmark/utils.py:57-80 InputPadder), SURVEY 8f-2.
  *   u8_to_f32: uint8 [H,W,3] (BGR if `bgr`, as cv2 delivers) -> fp32 planar RGB [3,Hp,Wp] = x / 255 with replicate padding,
  *              the source frame sitting at (pad_top, pad_left) of the padded canvas;

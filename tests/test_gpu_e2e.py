@@ -294,6 +294,13 @@ def test_fallback_kernel_selections_end_to_end(variant, name, dev, weights):
     net.enable_plans(False)
     check("launch plans off")
     net.enable_plans(True)
+    # (5) the refiner's tail as three launches, (6) no split-K
+    net.use_fused_tail = False
+    check("refine_head.1 as its own launch")
+    net.use_fused_tail = True
+    net.use_splitk = False
+    check("split-K off")
+    net.use_splitk = True
     check("default again")
 
 

@@ -1211,6 +1211,55 @@ def test_atmformer_module_reference_fixture(shift, dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", [(128, 64, 1, 40, 72), (64, 32, 2, 21, 35), (128, 64, 1, 300, 520), (64, 32, 1, 16, 16), (128, 64, 2, 17, 50)],
+                         ids=lambda c: f"cin{c[0]}_c{c[1]}_n{c[2]}_{c[3]}x{c[4]}")
+def test_tail_fused(case, dev):
+    """atmvfi_conv3x3_planes_readout + atmvfi_refine_tail (refine_head.0 -> refine_head.1 -> 2 sigmoid - 1 -> += I_t -> clamp,
+    network_base.py:257-260, 429, 532-533, with the hidden map r1 kept in registers) against the chain in torch float64: both refiner
+    widths (64: network_base, 32: network_lite), ragged tiles, several images, a map of one tile, and 627 tiles on 256 persistent
+    workgroups; image borders are where the zero padding of the SECOND convolution has to be right (a tap contribution from outside
+    the image is nothing, not conv(0) + bias)."""
+    cin, c, n, h, w = case
+    g = torch.Generator().manual_seed(9100 + cin + h + w)
+    hip = hip_ops.HipOps(dev)
+    xp = hip_ops.Planes.alloc(n * h * w, cin, dev)
+    hip.split_planes(rnd(g, n * h * w, cin, scale=1.5).to(dev), xp)
+    x = xp.to_float().cpu().double().reshape(n, h, w, cin).permute(0, 3, 1, 2)       # exactly what the kernel reads
+    wa, ba, pa = rnd(g, c, cin, 3, 3, scale=1.0 / np.sqrt(9 * cin)), rnd(g, c, scale=0.2), 0.25 + rnd(g, c, scale=0.2)
+    wb, bb, pb = rnd(g, 3, c, 3, 3, scale=2.0 / np.sqrt(9 * c)), rnd(g, 3, scale=0.2), 0.25 + rnd(g, 3, scale=0.2)
+    it = torch.rand(n, 3, h, w, generator=g)
+    F = torch.nn.functional
+    r1 = F.prelu(F.conv2d(x, wa.double(), ba.double(), padding=1), pa.double())
+    r = F.prelu(F.conv2d(r1, wb.double(), bb.double(), padding=1), pb.double())
+    want = it.double() + (2.0 * torch.sigmoid(r) - 1.0)
+    pw = hip.pack_weight(GEMM_CONV, wa.to(dev))
+    w2 = hip.pack_readout(wb.to(dev))
+    contrib = torch.full((27, n * h * w), float("nan"), device=dev)
+    hip.conv3x3_planes_readout(xp, n, h, w, pw, ba.to(dev), pa.to(dev), w2, contrib)
+    s, cl = torch.full((n, 3, h, w), 7.0, device=dev), torch.full((n, 3, h, w), 7.0, device=dev)
+    hip.refine_tail(contrib, bb.to(dev), pb.to(dev), it.to(dev), s, cl)
+    torch.cuda.synchronize()
+    assert not torch.isnan(contrib).any(), "a tap contribution was never written"
+    err = (s.cpu().double() - want).abs().max().item()
+    assert err <= 3e-5, f"max|d| {err:.3e}"
+    assert torch.equal(cl, s.clamp(0, 1))
+    # against the three unfused launches (same arithmetic class, another summation order)
+    r1g = torch.empty(n, h, w, c, device=dev)
+    hip.conv3x3_planes(xp, n, h, w, pw, out=r1g, bias=ba.to(dev), prelu=pa.to(dev))
+    rg = torch.empty(n, h, w, 4, device=dev)
+    hip.conv(r1g, hip.pack_weight(GEMM_CONV, wb.to(dev)), rg[..., :3], 1, 1, 1, bb.to(dev), pb.to(dev))
+    s2, cl2 = torch.empty_like(s), torch.empty_like(s)
+    hip.final_residual(it.to(dev), rg[..., :3], s2, cl2)
+    torch.cuda.synchronize()
+    assert maxdiff(s, s2) <= 2e-5
+    # run-to-run
+    contrib2 = torch.empty_like(contrib)
+    hip.conv3x3_planes_readout(xp, n, h, w, pw, ba.to(dev), pa.to(dev), w2, contrib2)
+    torch.cuda.synchronize()
+    assert torch.equal(contrib, contrib2)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", [(24, 48, 2, 64, 96), (24, 48, 1, 36, 52), (16, 32, 2, 40, 72), (24, 48, 1, 16, 32), (16, 32, 1, 2, 2),
                                   (24, 48, 3, 70, 34), (24, 48, 2, 544, 960), (16, 32, 1, 528, 992)],
                          ids=lambda c: f"c{c[0]}_{c[1]}_f{c[2]}_{c[3]}x{c[4]}")
