@@ -58,6 +58,13 @@ struct GemmDev {
     long long out_plane_rows;
     int out_c0, out_gc;
     int force_wn;     // per-call tile-width override of gemm_f16x3 (0 = cost model)
+    // split-K of under-filled long-K launches (gemm_duo.hip, round 4): gridDim.y = ksplit workgroups per tile, each over a contiguous
+    // range of k-steps, raw fp32 partial sums to part + split * part_stride (rows of part_ld floats); gemm_splitk_reduce_kernel adds
+    // them in split order and runs the epilogue.  0 / 1 = off.
+    int ksplit;
+    float* part;
+    long long part_stride;
+    int part_ld;
     int fit32;        // gemm_pp: rows x out_ld x 4 and rows x res_ld x 4 bytes fit 32 bits (unmapped, ungrouped fp32 rows: 32-bit store offsets)
     int pfit32;       // gemm_pp: a plane of the sink (plane rows x 64 bytes) fits 32 bits: 32-bit row offsets from per-lane chunk pointers
 };

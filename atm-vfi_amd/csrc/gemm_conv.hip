@@ -352,6 +352,12 @@ extern "C" int atmvfi_gemm(const atmvfi_gemm_params* p, void* stream) {
     ATMVFI_REQUIRE(p->tile_wn >= -4 && p->tile_wn <= 8 && (p->tile_wn >= 0 || planes), ATMVFI_EINVAL,
                    "gemm: tile_wn 0 (auto), 1..8, or (split-plane input) -1 reference schedule / -2 gemm_duo (128-column tiles) / -3 gemm_pp / -4 gemm_duo (64-column tiles), got %d", p->tile_wn);
     d.force_wn = p->tile_wn;
+    ATMVFI_REQUIRE(!p->workspace || (atmvfi::aligned16(p->workspace) && p->workspace_floats > 0), ATMVFI_EALIGN,
+                   "gemm: the split-K workspace must be 16-byte aligned and non-empty");
+    d.ksplit = 0;
+    d.part = p->workspace;
+    d.part_stride = p->workspace ? p->workspace_floats : 0;      // (launch_gemm_split turns the capacity into the real stride)
+    d.part_ld = 0;
     d.fit32 = 0;
     d.pfit32 = 0;
     d.nblocks = 0;

@@ -108,6 +108,25 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(const GemmDev a) {
     const unsigned char* pw_hi = reinterpret_cast<const unsigned char*>(a.w_hi);
     const unsigned char* pw_lo = reinterpret_cast<const unsigned char*>(a.w_lo);
     const long long a_step = (long long)a.in_ld * 64, w_step = (long long)a.wrows * 64;
+    int nk = a.nchunks32;
+    if (a.ksplit > 1) {
+        // this workgroup's range of k-steps: the first (nk mod ksplit) ranges take one more
+        const int sp = blockIdx.y;
+        const int per = nk / a.ksplit, rem = nk - per * a.ksplit;
+        const int u0 = sp * per + (sp < rem ? sp : rem);
+        nk = per + (sp < rem ? 1 : 0);
+        pw_hi += (long long)u0 * w_step;
+        pw_lo += (long long)u0 * w_step;
+        if constexpr (CONVM) {
+            const int tap = u0 / a.cpt32;
+            c_chunk = u0 - tap * a.cpt32;
+            c_ky = tap / a.kw;
+            c_kx = tap - c_ky * a.kw;
+        } else {
+            pa_hi += (long long)u0 * a_step;
+            pa_lo += (long long)u0 * a_step;
+        }
+    }
     auto issue_stage = [&](int buf) {                               // 4 + 2 PIW pieces per wave
         unsigned char* dst = smem + buf * STAGE + wave * 1024;
         if constexpr (CONVM) {
@@ -169,7 +188,6 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(const GemmDev a) {
             acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
             cor[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-    const int nk = a.nchunks32;
 #ifdef ATMVFI_STAMP
     unsigned long long sub[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sub_t = 0, t_begin = 0;
     if (a.stamp) { t_begin = sub_t = __builtin_amdgcn_s_memtime(); }
@@ -272,6 +290,18 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(const GemmDev a) {
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(acc[i][q]));
+        }
+        if (a.ksplit > 1) {
+            // split-K: the raw sums of this K range as plain rows of the partial buffer; the epilogue runs in the reduce kernel
+            float* pb = a.part + blockIdx.y * a.part_stride + (n0 + 64 * wn + 4 * r);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int m = m0 + WROWS * wm + g + 16 * i + 4 * q;
+                    if (m < M) *reinterpret_cast<f32x4*>(pb + (long long)m * a.part_ld) = acc[i][q];
+                }
+            return;
         }
         const bool mapped = a.out_row_map && a.mode == ATMVFI_GEMM_LINEAR;
         const int cl = 64 * wn + 4 * r;                          // the lane's four columns inside the column block
@@ -561,6 +591,39 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(const GemmDev a) {
 #endif
 }
 
+// Split-K, second half: the epilogue of the kernels above (gemm_common.h: output row of a GEMM row incl. the window-reverse map, row
+// groups and the deconv's pixel shuffle; + bias, PReLU, + residual; fp32 rows and / or plane sink) on the sum of the partial buffers,
+// added in split order: run-to-run deterministic.  One thread per (GEMM row, 4 columns).
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GemmDev a, int ngemm4) {
+    fp16_saturate_on();
+    const long long total = a.M * (long long)ngemm4;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const long long m = idx / ngemm4;
+        const int nb = (int)(idx - m * ngemm4) * 4;
+        const atmvfi::ChanPos cp = atmvfi::gemm_chan_pos(a, nb);
+        if (cp.nvalid <= 0) continue;
+        // bias / slope of the four columns (selects, no indexed local arrays: hipcc turns those into scratch)
+        auto vec4 = [&](const float* t, float dflt) -> f32x4 {
+            if (!t) return (f32x4){dflt, dflt, dflt, dflt};
+            if (cp.nvalid >= 4) return *reinterpret_cast<const f32x4*>(t + cp.co);
+            f32x4 o = (f32x4){t[cp.co], dflt, dflt, dflt};
+            if (cp.nvalid > 1) o.y = t[cp.co + 1];
+            if (cp.nvalid > 2) o.z = t[cp.co + 2];
+            return o;
+        };
+        const float* p = a.part + m * a.part_ld + nb;
+        f32x4 v = *reinterpret_cast<const f32x4*>(p);
+        for (int sp = 1; sp < a.ksplit; ++sp) v += *reinterpret_cast<const f32x4*>(p + sp * a.part_stride);
+        float* orow;
+        const float* rrow;
+        long long prow;
+        int pc0;
+        if (!atmvfi::gemm_out_row(a, m, orow, rrow, prow, pc0)) continue;
+        const f32x4 res = rrow ? atmvfi::gemm_load_residual4(rrow, cp) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        atmvfi::gemm_finish_store4(a, orow, prow, pc0, cp, v, vec4(a.bias, 0.f), vec4(a.prelu, 1.f), res);
+    }
+}
+
 }  // namespace
 
 template <bool CONVM, int BN>
@@ -584,6 +647,15 @@ static int launch_duo(const GemmDev& d, int ngemm, hipStream_t s) {
     const long long mgroups = (atmvfi::ceil_div64(d.M, BM) + 7) / 8;
     ATMVFI_REQUIRE(mgroups * 8 * dd.nblocks < (1LL << 31), ATMVFI_EINVAL, "gemm_duo: grid too large");
     dd.vblocks = (int)(mgroups * 8 * dd.nblocks);
+    if (dd.ksplit > 1) {
+        hipLaunchKernelGGL((gemm_duo_kernel<CONVM, BN>), dim3((unsigned)dd.vblocks, (unsigned)dd.ksplit), dim3(256), lds, s, dd);
+        const int rc = atmvfi::check_launch("gemm_duo (split-K)");
+        if (rc != ATMVFI_OK) return rc;
+        const int ngemm4 = (ngemm + 3) / 4;
+        const long long groups = d.M * ngemm4;
+        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)std::min<long long>((groups + 255) / 256, 8192)), dim3(256), 0, s, dd, ngemm4);
+        return atmvfi::check_launch("gemm_duo (split-K reduce)");
+    }
     hipLaunchKernelGGL((gemm_duo_kernel<CONVM, BN>), dim3((unsigned)dd.vblocks), dim3(256), lds, s, dd);
     return atmvfi::check_launch("gemm_duo");
 }

@@ -441,6 +441,32 @@ int launch_split(const GemmDev& d, int ngemm, hipStream_t s) {
 
 }  // namespace
 
+// Split-K plan of an under-filled plane-input GEMM launch (gemm_duo.hip, 128 x 64 tiles, three workgroups per CU): as many K ranges as
+// the idle workgroup slots take, each at least 8 k-steps, at most 8 ranges; taken when the model of tools/gemm_engines_ab.py
+// (a 128 x 64 tile: 6.4 us + 0.6 us per k-step while the chip is under-filled, 0.75 with two and more per CU; the second kernel ~5 us)
+// says at least 15 % less time.  Returns the number of ranges (1: no split).
+static int gemm_splitk_plan(long long M, int ngemm, int nk) {
+    const long long cus = atmvfi::cu_count();
+    const long long tiles = atmvfi::ceil_div64(M, 128) * ((ngemm + 63) / 64);
+    if (nk < 16 || tiles * 2 > cus) return 1;                      // only grids that leave at least half of the CUs without a tile
+    const int S = (int)std::min<long long>(std::min<long long>(2 * cus / tiles, nk / 8), 8);     // at most two workgroups per CU
+    if (S < 2) return 1;
+    // 6.4 us + 0.6 us per k-step for a 128 x 64 tile on an under-filled chip (0.75 with more than one per CU); the second kernel ~5 us;
+    // the partial sums go through memory once each way (~3 TB/s for this pattern) -- measured on the launches of network_lite
+    // 256 x 256 (30 -> 16 us, 50 -> 17 us) and of network_base 576 x 960, where splitting the 68-374-tile launches LOST 8-25 us each
+    const double per_step = tiles * S > cus ? 0.75 : 0.6;
+    const double traffic_us = 2.0 * S * (double)M * atmvfi::round_up(ngemm, 64) * 4.0 / 3.0e6;
+    const double t_unsplit = 6.4 + 0.6 * nk;
+    const double t_split = 6.4 + per_step * ((nk + S - 1) / S) + 5.0 + traffic_us;
+    return t_split < 0.85 * t_unsplit ? S : 1;
+}
+
+extern "C" int64_t atmvfi_gemm_workspace_floats(int64_t M, int ngemm, int ksteps) {
+    if (M <= 0 || ngemm <= 0 || ksteps <= 0) return 0;
+    const int S = gemm_splitk_plan(M, ngemm, ksteps);
+    return S > 1 ? (int64_t)S * M * atmvfi::round_up(ngemm, 64) : 0;
+}
+
 int atmvfi::launch_gemm_split(const GemmDev& d, int ngemm, hipStream_t s) {
     // force_wn: -1 this file (the reference schedule: tools / A-B only), -2 / -4 gemm_duo.hip with 128- / 64-column tiles, -3 gemm_pp.hip;
     // 0 = choose.  The three give
@@ -455,6 +481,18 @@ int atmvfi::launch_gemm_split(const GemmDev& d, int ngemm, hipStream_t s) {
     // End to end: network_lite 256 x 256 +11 %, 256 x 448 +10 %, network_base 540p +3 %, 1080p +1 % (tools/small_gemm_ab.py).
     if (d.force_wn == -2 || d.force_wn == -4) return launch_gemm_duo(d, ngemm, s);
     if (d.force_wn == -3) return launch_gemm_pp(d, ngemm, s);
+    if (d.force_wn == 0 && d.part) {
+        const int S = gemm_splitk_plan(d.M, ngemm, d.nchunks32);
+        const int ld = round_up(ngemm, 64);
+        if (S > 1 && (long long)S * d.M * ld <= d.part_stride) {
+            GemmDev ds = d;
+            ds.ksplit = S;
+            ds.part_ld = ld;
+            ds.part_stride = d.M * ld;
+            ds.force_wn = -4;
+            return launch_gemm_duo(ds, ngemm, s);
+        }
+    }
     if (d.force_wn == 0) {
         if (ngemm <= 64) return launch_gemm_duo(d, ngemm, s);
         // Under-filled grids (round 4, tools/gemm_engines_ab.py -> profiles/r04_gemm_engines_ab.txt: all three schedules timed on every

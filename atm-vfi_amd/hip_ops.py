@@ -54,6 +54,7 @@ class GemmParams(ctypes.Structure):
         ("out_hi", c_f), ("out_lo", c_f), ("out_plane_rows", ctypes.c_int64), ("out_plane_c0", ctypes.c_int32),
         ("out_plane_gc", ctypes.c_int32), ("tile_wn", ctypes.c_int32),
         ("in_hi2", c_f), ("in_lo2", c_f), ("in_ld2", ctypes.c_int32), ("in_split_chunks", ctypes.c_int32),
+        ("workspace", c_f), ("workspace_floats", ctypes.c_int64),
     ]
 
 
@@ -79,6 +80,7 @@ SIGNATURES = {
     "atmvfi_last_error": (ctypes.c_char_p, []),
     "atmvfi_source_digest": (ctypes.c_char_p, []),
     "atmvfi_gemm": (c_i, [ctypes.POINTER(GemmParams), c_f]),
+    "atmvfi_gemm_workspace_floats": (c_l, [c_l, c_i, c_i]),
     "atmvfi_split_planes": (c_i, [c_f, c_i, c_l, c_i, c_f, c_f, c_f, c_i, c_f]),
     "atmvfi_split_planes_at": (c_i, [c_f, c_i, c_l, c_i, c_f, c_f, c_f, c_i, c_i, c_i, c_f]),
     "atmvfi_conv2d": (c_i, [ctypes.POINTER(GemmParams), c_f]),
@@ -495,6 +497,8 @@ class HipOps:
         self.gemm_tile_wn = 0
         self.warp_tiles = os.environ.get("ATMVFI_WARP_TILES", "1") != "0"     # A/B switch: planar warps with LDS-staged source tiles
         self.recording: Optional[LaunchPlan] = None     # when set: every launch is also appended to this plan
+        # split-K scratch for the plane-input GEMM: a callable floats -> fp32 tensor (Network hands out workspace memory); None: never split
+        self.gemm_workspace = None
 
     # ------------------------------------------------------------------ launch plans
     def begin_plan(self, inputs) -> LaunchPlan:
@@ -644,6 +648,20 @@ class HipOps:
         self._gemm_sink(p, planes, n * oh * ow, cout, planes_c0, 0, 1, "conv")
         p._srcs = (x, out, bias, prelu, in_prelu)
         self._run("conv2d_f16x3" if p.precision else "conv2d", meta, self.lib.atmvfi_conv2d, ctypes.byref(p), self._stream())
+
+    def _gemm_splitk(self, p: "GemmParams", m: int, ngemm: int, ksteps: int):
+        """Give the launch split-K scratch when the launcher would use it (under-filled grid, long K); returns the tensor (kept alive by
+        the caller's workspace) or None."""
+        if self.gemm_workspace is None or p.precision != 1 or not p.in_hi or p.tile_wn != 0:
+            return None
+        need = int(self.lib.atmvfi_gemm_workspace_floats(m, ngemm, ksteps))
+        if not need:
+            return None
+        ws = self.gemm_workspace(need)
+        if ws is None:
+            return None
+        p.workspace, p.workspace_floats = ws.data_ptr(), ws.numel()
+        return ws
 
     def pack_stem(self, w1, b1, p1, w2, b2, p2, w3, b3, p3) -> "StemWeights":
         """The operand layouts of ``atmvfi_stem_fused`` (include/atmvfi.h) from the nine parameters of feat_extracts.0.0 / 0.1 / 1.0
@@ -846,7 +864,8 @@ class HipOps:
         self._gemm_sink(p, sink, n * oh * ow, cout, sink_c0, 0, 1, "conv_planes")
         meta = {"flops": 2.0 * n * oh * ow * cout * cin * w.kh * w.kw, "bytes": 4.0 * (n * h * wd * cin + n * oh * ow * cout + cout * cin * w.kh * w.kw),
                 "shape": f"M{n * oh * ow} N{cout} K{cin * w.kh * w.kw}"}
-        p._srcs = (out, bias, prelu)
+        ws = self._gemm_splitk(p, n * oh * ow, cout, w.kh * w.kw * ((cin + 31) // 32))
+        p._srcs = (out, bias, prelu, ws)
         self._run("conv2d_split", meta, self.lib.atmvfi_conv2d, ctypes.byref(p), self._stream())
 
     def deconv(self, x, w: PackedWeight, out, bias=None, prelu=None, in_prelu=None, planes: Optional[Planes] = None,
@@ -888,7 +907,8 @@ class HipOps:
             p.in_hi, p.in_lo = planes.t[0].data_ptr(), planes.t[1].data_ptr()
         meta = {"flops": 2.0 * n * h * wd * 4 * cout * cin, "bytes": 4.0 * (n * h * wd * cin + n * oh * ow * cout + 4 * cout * cin),
                 "shape": f"M{n * h * wd} N{4 * cout} K{cin}"}
-        p._srcs = (x, out, bias, prelu, in_prelu)
+        ws = self._gemm_splitk(p, n * h * wd, 4 * ((cout + 3) // 4 * 4), (cin + 31) // 32) if use_planes else None
+        p._srcs = (x, out, bias, prelu, in_prelu, ws)
         self._run("deconv2x2_split" if use_planes else "deconv2x2_f16x3" if p.precision else "deconv2x2", meta, self.lib.atmvfi_deconv2x2,
                   ctypes.byref(p), self._stream())
 
@@ -944,7 +964,8 @@ class HipOps:
         if sink is not None:
             self._gemm_sink(p, sink, orpg if orpg else mo, cout, sink_c0, sink_gc, (mo // orpg) if orpg else 1, "linear")
         meta = {"flops": 2.0 * m * cout * cin, "bytes": 4.0 * (m * cin + m * cout + cout * cin), "shape": f"M{m} N{cout} K{cin}"}
-        p._srcs = (None if planes is not None else x, out, bias, residual, out_row_map)
+        ws = self._gemm_splitk(p, m, cout, (cin + 31) // 32) if planes is not None else None
+        p._srcs = (None if planes is not None else x, out, bias, residual, out_row_map, ws)
         self._run("linear_split" if planes is not None else "linear_f16x3" if p.precision else "linear", meta, self.lib.atmvfi_linear, ctypes.byref(p), self._stream())
 
     # ------------------------------------------------------------- transformer

@@ -327,7 +327,12 @@ class Network(_ParamWatch, BlockRunner, nn.Module):
                                    "'cuda' (HIP). There is no CPU implementation in the product; the CPU oracle lives in oracle/.")
             self._ops_obj = HipOps(device)
             self._ops_obj.precision = self._precision
+            self._ops_obj.gemm_workspace = self._gemm_scratch
         return self._ops_obj
+
+    def _gemm_scratch(self, floats: int) -> Optional[torch.Tensor]:
+        """Split-K scratch of the plane-input GEMM (hip_ops.HipOps.gemm_workspace): workspace memory like every other buffer."""
+        return self.buf("gemm_splitk_ws", floats) if self.use_splitk else None
 
     def release_workspace(self):
         self._plans.clear()           # recorded plans and

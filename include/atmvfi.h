@@ -119,12 +119,22 @@ typedef struct atmvfi_gemm_params {
     const void* in_hi2;
     const void* in_lo2;
     int32_t in_ld2, in_split_chunks;
+    /* Split-K scratch (F16X3, split-plane input; optional): with `workspace` (fp32, 16-byte aligned) of at least
+       atmvfi_gemm_workspace_floats(M, ngemm, k-steps) floats the launcher may cut a long K of an under-filled grid (small frames:
+       a few tiles walking 40-150 k-steps on a mostly idle chip) into up to 8 ranges of k-steps, one workgroup per (tile, range)
+       writing raw fp32 partial sums, and a second kernel that adds them IN RANGE ORDER and runs the epilogue.  Run-to-run
+       deterministic; differs from the unsplit launch by fp32 summation order only.  NULL: never split. */
+    float* workspace;
+    int64_t workspace_floats;
 } atmvfi_gemm_params;
 
 #define ATMVFI_PREC_F32   0
 #define ATMVFI_PREC_F16X3 1
 
 int atmvfi_gemm(const atmvfi_gemm_params* p, void* stream);
+/* fp32 elements of split-K scratch the plane-input GEMM wants for M rows, ngemm GEMM columns (Cout; 4 * round_up(Cout, 4) for DECONV)
+ * and ksteps = taps * ceil(Cin / 32) k-steps on this device; 0: it would not split that shape. */
+int64_t atmvfi_gemm_workspace_floats(int64_t M, int ngemm, int ksteps);
 
 /* 1x1 convolution with 1 <= Cout <= 8 output channels on split-plane input: the read-out nn.Conv2d(hidden, 5, 1) of the motion MLPs
  * (network_base.py:158,195 local_motion_mlp[2] / global_motion_mlp[2]).  in_hi / in_lo: chunk-major planes of `rows` pixel rows

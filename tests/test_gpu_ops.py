@@ -983,6 +983,88 @@ def test_conv_from_two_plane_sources(hip, dev):
 
 
 @pytest.mark.gpu
+def test_gemm_split_k(dev):
+    """Split-K of under-filled long-K plane-input GEMM launches (atmvfi_gemm_params.workspace; gemm_duo.hip + gemm_splitk_reduce_kernel):
+    a linear with bias, residual and the window-reverse row map into a grouped view + plane sink, a stride-2 convolution from two
+    plane sources into a plane sink (the refiner's down3.0 at 256 x 256), a deconv into a plane sink.  Against the unsplit launch:
+    equal within fp32 summation-order error; bit-identical between two split launches; nothing changes without a workspace."""
+    g = torch.Generator().manual_seed(8400)
+    hip = hip_ops.HipOps(dev)
+    used = []
+
+    def scratch(n):
+        used.append(n)
+        return torch.empty(n, device=dev)
+
+    def both(fn):
+        hip.gemm_workspace = None
+        a = fn()
+        hip.gemm_workspace = scratch
+        n0 = len(used)
+        b = fn()
+        c = fn()
+        hip.gemm_workspace = None
+        torch.cuda.synchronize()
+        assert len(used) == n0 + 2, "the launcher did not ask for split-K scratch: the case tests nothing"
+        return a, b, c
+
+    # ---- linear: M 512, N 256, K 2048, residual + scatter map (a permutation with dropped rows) ----
+    m, n, k = 512, 256, 2048
+    x = rnd(g, m, k, scale=1.5).to(dev)
+    xp = hip_ops.Planes.alloc(m, k, dev)
+    hip.split_planes(x, xp)
+    w = hip.pack_weight(GEMM_LINEAR, rnd(g, n, k, scale=1.0 / np.sqrt(k)).to(dev))
+    bias, res = rnd(g, n, scale=0.2).to(dev), rnd(g, m, n).to(dev)
+    perm = torch.randperm(m, generator=g).to(torch.int32)
+    perm[::37] = -1
+    rmap = perm.to(dev)
+
+    def lin():
+        out = torch.full((2, m // 2, n), 7.0, device=dev)
+        sink = hip_ops.Planes.alloc(m // 2, 8 + 2 * n, dev)
+        hip.linear(xp, w, out, bias=bias, residual=res, out_row_map=rmap, sink=sink, sink_c0=8, sink_gc=n)
+        return out, sink
+    (o0, s0), (o1, s1), (o2, s2) = both(lin)
+    scale = max(1.0, float(o0[o0 != 7.0].abs().max()))
+    assert not torch.equal(o0, o1) and maxdiff(o0, o1) <= 1e-5 * scale and torch.equal(o1, o2) and torch.equal(s1.t, s2.t)
+    assert maxdiff(s0.to_float(), s1.to_float()) <= 1e-5 * scale
+    assert (o1 == 7.0).sum() == (o0 == 7.0).sum()           # dropped rows stay untouched
+
+    # ---- stride-2 3x3 convolution from two plane sources, plane sink (down3.0 of network_lite at 256 x 256: M 1024, N 128, K 2592) ----
+    N, H, W = 1, 64, 64
+    pa, pb = hip_ops.Planes.alloc(N * H * W, 64, dev), hip_ops.Planes.alloc(N * H * W, 229, dev)
+    hip.split_planes(rnd(g, N * H * W, 64, scale=1.2).to(dev), pa)
+    hip.split_planes(rnd(g, N * H * W, 232, scale=1.2).to(dev)[:, :229], pb)
+    wc = hip.pack_weight(GEMM_CONV, rnd(g, 128, 64 + 224, 3, 3, scale=1.0 / np.sqrt(9 * 288)).to(dev))
+    cb, cs = rnd(g, 128, scale=0.2).to(dev), (torch.rand(128, generator=g) * 0.4).to(dev)
+
+    def conv():
+        out = torch.full((N, H // 2, W // 2, 128), 7.0, device=dev)
+        sink = hip_ops.Planes.alloc(N * (H // 2) * (W // 2), 128, dev)
+        hip.conv_planes(pa, N, H, W, wc, out=out, stride=2, pad=1, dil=1, bias=cb, prelu=cs, sink=sink, x2=pb, split_chunks=2)
+        return out, sink
+    (o0, s0), (o1, s1), (o2, s2) = both(conv)
+    scale = max(1.0, float(o0.abs().max()))
+    assert not torch.equal(o0, o1) and maxdiff(o0, o1) <= 1e-5 * scale and torch.equal(o1, o2) and torch.equal(s1.t, s2.t)
+    assert maxdiff(s0.to_float(), s1.to_float()) <= 1e-5 * scale
+
+    # ---- deconv 2x2 / stride 2 into a plane sink: M 1024, N 4 x 61 -> 256, K 1024 ----
+    n_, h_, w_, cin, cout = 1, 32, 32, 1024, 61
+    xd = hip_ops.Planes.alloc(n_ * h_ * w_, cin, dev)
+    hip.split_planes(rnd(g, n_ * h_ * w_, cin, scale=1.2).to(dev), xd)
+    wd = hip.pack_weight(GEMM_DECONV, rnd(g, cin, cout, 2, 2, scale=1.0 / np.sqrt(cin)).to(dev))
+    db, dsl = rnd(g, cout, scale=0.2).to(dev), (torch.rand(cout, generator=g) * 0.4).to(dev)
+
+    def dec():
+        sink = hip_ops.Planes.alloc(n_ * 2 * h_ * 2 * w_, cout, dev)
+        hip.deconv(None, wd, None, bias=db, prelu=dsl, planes=xd, sink=sink, in_shape=(n_, h_, w_, cin))
+        return sink
+    s0, s1, s2 = both(dec)
+    assert not torch.equal(s0.t, s1.t) and maxdiff(s0.to_float(), s1.to_float()) <= 1e-5 * max(1.0, float(s0.to_float().abs().max()))
+    assert torch.equal(s1.t, s2.t) and (s1.t[:, :, s1.rows:] == 0).all() and (s1.to_rows()[:, :, cout:] == 0).all()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(2, 3, 17, 29), (2, 3, 17, 28), (1, 3, 68, 120), (1, 5, 34, 60)], ids=lambda s: "x".join(map(str, s)))
 def test_flow_warp_up2_equals_two_launches(shape, hip, dev):
     """flow_warp + x2 flow up-sampling in one launch == the two kernels, bit for bit (incl. flows that leave the image); with W a
