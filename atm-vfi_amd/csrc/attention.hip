@@ -562,7 +562,8 @@ __global__ void motion_head_kernel(const float* __restrict__ motion, const int* 
                                    const float* __restrict__ w0, const float* __restrict__ b0,
                                    const float* __restrict__ w1, const float* __restrict__ b1,
                                    float* __restrict__ out, int out_ld, long long out_gstride, int out_rpg,
-                                   long long rows, int heads) {
+                                   long long rows, int heads, _Float16* __restrict__ phi, _Float16* __restrict__ plo,
+                                   long long plane_rows, int pc0, int pgc) {
     fp16_saturate_on();
     const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= rows) return;
@@ -585,6 +586,17 @@ __global__ void motion_head_kernel(const float* __restrict__ motion, const int* 
                                         : ro * (long long)out_ld;
     out[off] = ox;
     out[off + 1] = oy;
+    if (phi) {
+        // the same two values again as split planes (the motion channels of the motion MLP's plane input: no separate split pass)
+        const long long grp = out_rpg > 0 ? ro / out_rpg : 0;
+        const long long prow = out_rpg > 0 ? ro - grp * out_rpg : ro;
+        const int c = pc0 + (int)grp * pgc;
+        f16x2 h, l;
+        split_pair((f32x2){ox, oy}, h, l);
+        const long long poff = ((long long)(c >> 5) * plane_rows + prow) * 32 + (c & 31);
+        *reinterpret_cast<f16x2*>(phi + poff) = h;
+        *reinterpret_cast<f16x2*>(plo + poff) = l;
+    }
 }
 
 template <int NT>
@@ -716,13 +728,26 @@ extern "C" int atmvfi_window_attn_self(const float* qkv, float* out, const int32
     return atmvfi_window_attention(qkv, out, nullptr, labels, Bw, nW, ws, heads, hd, 0, nullptr, nullptr, 0, stream);
 }
 
-extern "C" int atmvfi_motion_head(const float* motion, const int32_t* row_map, const float* w0, const float* b0,
-                                   const float* w1, const float* b1, float* out, int out_ld, int64_t out_gstride,
-                                   int out_rpg, int64_t rows, int heads, void* stream) {
+extern "C" int atmvfi_motion_head_planes(const float* motion, const int32_t* row_map, const float* w0, const float* b0,
+                                         const float* w1, const float* b1, float* out, int out_ld, int64_t out_gstride, int out_rpg,
+                                         int64_t rows, int heads, void* out_hi, void* out_lo, int64_t plane_rows, int plane_c0, int plane_gc,
+                                         void* stream) {
     ATMVFI_REQUIRE(motion && w0 && b0 && w1 && b1 && out, ATMVFI_EINVAL, "motion_head: null pointer");
     ATMVFI_REQUIRE(rows > 0 && heads >= 2 && heads % 2 == 0, ATMVFI_EINVAL, "motion_head: bad rows/heads");
+    ATMVFI_REQUIRE((out_hi == nullptr) == (out_lo == nullptr), ATMVFI_EINVAL, "motion_head: the plane sink needs both planes");
+    if (out_hi)
+        ATMVFI_REQUIRE(plane_rows > 0 && plane_c0 >= 0 && plane_c0 % 2 == 0 && plane_gc % 2 == 0 && atmvfi::aligned16(out_hi) && atmvfi::aligned16(out_lo),
+                       ATMVFI_EINVAL, "motion_head: plane sink needs plane_rows > 0, even channel offsets and 16-byte aligned planes");
     const unsigned blocks = (unsigned)((rows + 255) / 256);
     hipLaunchKernelGGL(motion_head_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, motion, row_map, w0, b0, w1,
-                       b1, out, out_ld, (long long)out_gstride, out_rpg, (long long)rows, heads);
+                       b1, out, out_ld, (long long)out_gstride, out_rpg, (long long)rows, heads, (_Float16*)out_hi, (_Float16*)out_lo,
+                       (long long)plane_rows, plane_c0, plane_gc);
     return atmvfi::check_launch("motion_head");
+}
+
+extern "C" int atmvfi_motion_head(const float* motion, const int32_t* row_map, const float* w0, const float* b0, const float* w1,
+                                  const float* b1, float* out, int out_ld, int64_t out_gstride, int out_rpg, int64_t rows, int heads,
+                                  void* stream) {
+    return atmvfi_motion_head_planes(motion, row_map, w0, b0, w1, b1, out, out_ld, out_gstride, out_rpg, rows, heads, nullptr, nullptr, 0, 0,
+                                     0, stream);
 }

@@ -111,6 +111,7 @@ SIGNATURES = {
     "atmvfi_window_attn_cross_motion": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
     "atmvfi_window_attn_self": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
     "atmvfi_motion_head": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_l, c_i, c_l, c_i, c_f]),
+    "atmvfi_motion_head_planes": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_l, c_i, c_l, c_i, c_f, c_f, c_l, c_i, c_i, c_f]),
     "atmvfi_flow_warp": (c_i, [c_f, c_f, c_l, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_f]),
     "atmvfi_flow_warp_tiled": (c_i, [c_f, c_f, c_l, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_f]),
     "atmvfi_flow_warp_nhwc": (c_i, [c_f, c_i, c_l, c_f, c_l, c_i, c_i, c_f, c_i, c_l, c_i, c_i, c_i, c_i, c_f]),
@@ -913,6 +914,7 @@ class HipOps:
                   ctypes.byref(p), self._stream())
 
     split_planes_ok = True        # this backend has the split-plane sinks and the LDS-DMA GEMM
+    motion_head_sink = True       # ... and the motion head's plane sink (no split pass for the motion MLP's eight motion channels)
 
     def split_planes(self, x, out: Planes, prelu=None, c0: Optional[int] = None):
         """fp32 rows -> split planes, optionally through a per-channel PReLU first.  ``c0``: write the channels at this offset
@@ -1033,13 +1035,21 @@ class HipOps:
         self._run("window_attention", meta, fn, _ptr(qkv), _ptr(out), _ptr(motion), _ptr(labels),
                   bw, nw, ws, heads, hd, kv_shift, hi, lo, pld, self._stream())
 
-    def motion_head(self, motion, row_map, w0, b0, w1, b1, out):
+    def motion_head(self, motion, row_map, w0, b0, w1, b1, out, planes: Optional[Planes] = None, planes_c0: int = 0, planes_gc: int = 0):
+        """``planes``: also write the two values as split planes -- channel ``planes_c0`` (+ ``planes_gc`` per row group of ``out``),
+        plane row = the row inside its group."""
         old, mo, co, ogs, orpg = rows_view(out, "motion_head.out")
         rows = motion.shape[0]
         if co != 2:
             raise ValueError("motion_head: output view must have 2 channels")
-        self._run("motion_head", {"bytes": 4.0 * rows * 18}, self.lib.atmvfi_motion_head, _ptr(motion), _ptr(row_map), _ptr(w0),
-                  _ptr(b0), _ptr(w1), _ptr(b1), _ptr(out), old, ogs, orpg, rows, motion.shape[1], self._stream())
+        if planes is not None:
+            groups = (mo // orpg) if orpg else 1
+            if planes.rows != (orpg if orpg else mo) or planes_c0 % 2 or planes_gc % 2 or planes_c0 + (groups - 1) * planes_gc + 2 > planes.chunks * 32:
+                raise ValueError("motion_head: the plane sink must hold one row per row of a group and even channel offsets inside its chunks")
+        self._run("motion_head", {"bytes": 4.0 * rows * 18}, self.lib.atmvfi_motion_head_planes, _ptr(motion), _ptr(row_map), _ptr(w0),
+                  _ptr(b0), _ptr(w1), _ptr(b1), _ptr(out), old, ogs, orpg, rows, motion.shape[1],
+                  _ptr(planes.t[0]) if planes is not None else None, _ptr(planes.t[1]) if planes is not None else None,
+                  planes.ld_rows if planes is not None else 0, planes_c0, planes_gc, self._stream())
 
     # ------------------------------------------------------------------ warps
     def _tiled_warp_ok(self, w, *planes) -> bool:

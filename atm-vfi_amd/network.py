@@ -121,7 +121,7 @@ class BlockRunner:
         return g
 
 
-    def _block(self, ops, P, p, x, frames, h, w, ws, shift, cross, out, motion_dst, tag, out_sink=None):
+    def _block(self, ops, P, p, x, frames, h, w, ws, shift, cross, out, motion_dst, tag, out_sink=None, motion_sink=None):
         """One shifted-window transformer block (ATMFormer attention.py:265-334 when ``cross``,
         RefineBottleneck :433-495 otherwise).  x/out: token-matrix views in image order."""
         c = x.shape[-1]
@@ -147,8 +147,9 @@ class BlockRunner:
         xb = self.buf(f"{tag}xb", frames * h * w, c)
         ops.linear(ao_p if pl else ao, P[f"pk:{p}.attn.proj.weight"], xb, bias=P[f"{p}.attn.proj.bias"], residual=xn, out_row_map=row_map)
         if cross:
+            mk = {} if motion_sink is None else {"planes": motion_sink[0], "planes_c0": motion_sink[1], "planes_gc": motion_sink[2]}
             ops.motion_head(mo, row_map, P[f"{p}.attn.mlp.0.weight"], P[f"{p}.attn.mlp.0.bias"],
-                            P[f"{p}.attn.mlp.2.weight"], P[f"{p}.attn.mlp.2.bias"], motion_dst)
+                            P[f"{p}.attn.mlp.2.weight"], P[f"{p}.attn.mlp.2.bias"], motion_dst, **mk)
         hid = P[f"{p}.mlp.fc1.bias"].shape[0]
         f1 = self.buf(f"{tag}fc1", frames, h, w, hid)
         if pl:
@@ -622,14 +623,18 @@ class Network(_ParamWatch, BlockRunner, nn.Module):
         for blk in range(2):
             mdst = flat[:, 4 * blk:4 * blk + 4].unflatten(1, (2, 2)).permute(1, 0, 2)       # '(N B) L K -> B L (N K)'
             out = self._stacked(mlp_in, 8, c) if blk == 1 else self.buf(f"{tag}blk0", 2 * b * h * w, c)
+            # the block's four motion channels (frame 0 dx dy, frame 1 dx dy at 4 blk ..) go into the plane input of the motion MLP
+            # straight from the motion head (no separate split pass)
+            msink = (mlp_in_p, 4 * blk, 2) if (pc and getattr(ops, "motion_head_sink", False)) else None
             self._block(ops, P, f"{branch}.{blk}", x, 2 * b, h, w, ws, 0 if blk == 0 else ws // 2, True, out, mdst, tag,
-                        out_sink=(mlp_in_p, 8, c) if (pc and blk == 1) else None)
+                        out_sink=(mlp_in_p, 8, c) if (pc and blk == 1) else None, motion_sink=msink)
             x = out
         hid = P[f"{mlp}.0.0.bias"].shape[0]
         if pc:
             # [motion 8 | frame0 C | frame1 C] as split planes: the features come from fc2's plane sink, the eight motion
             # channels (written by the two motion heads) from one small split pass
-            ops.split_planes(flat[:, 0:8], mlp_in_p, c0=0)
+            if not getattr(ops, "motion_head_sink", False):
+                ops.split_planes(flat[:, 0:8], mlp_in_p, c0=0)
             t1p = self.planes(f"{tag}mm1_p", b * h * w, hid)
             self._c3p(ops, P, f"{mlp}.0", mlp_in_p, b, h, w, sink=t1p)
             t2p = self.planes(f"{tag}mm2_p", b * h * w, hid)

@@ -295,6 +295,12 @@ int atmvfi_motion_head(const float* motion /*[rows, heads, 2]*/, const int32_t* 
                        const float* w0 /*[heads/2, heads]*/, const float* b0, const float* w1 /*[1, heads/2]*/,
                        const float* b1, float* out, int out_ld, int64_t out_gstride, int out_rpg,
                        int64_t rows, int heads, void* stream);
+/* The same, and the two values again as split planes (hi / lo', chunk major, plane_rows rows per chunk): row r = row_map[m] goes to plane
+ * row r % out_rpg, channels plane_c0 + (r / out_rpg) * plane_gc + {0, 1} -- the eight motion channels of the motion MLP's plane input
+ * (network_base.py:377-382, 410) without a separate split pass.  Channel offsets must be even. */
+int atmvfi_motion_head_planes(const float* motion, const int32_t* row_map, const float* w0, const float* b0, const float* w1,
+                              const float* b1, float* out, int out_ld, int64_t out_gstride, int out_rpg, int64_t rows, int heads,
+                              void* out_hi, void* out_lo, int64_t plane_rows, int plane_c0, int plane_gc, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Backward bilinear warp, zero padding (flow_warp.py:50-60 -> grid_sample(bilinear, zeros,

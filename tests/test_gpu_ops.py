@@ -314,6 +314,19 @@ def test_motion_head(hip, cpu, dev):
     hip.motion_head(mo.to(dev), geo.row_map.to(dev), w0.to(dev), b0.to(dev), w1.to(dev), b1.to(dev), view(dg))
     torch.cuda.synchronize()
     assert maxdiff(dg, dc) <= 2e-5
+    # the plane sink (the motion channels of the motion MLP's plane input without a split pass): exactly the split of the fp32 values,
+    # at channels c0 + 2 * frame + {0, 1}; everything else in the planes untouched
+    sink = hip_ops.Planes.alloc(B * h * w, 40, dev)
+    dg2 = torch.full((B * h * w, 24), 7.0, device=dev)
+    hip.motion_head(mo.to(dev), geo.row_map.to(dev), w0.to(dev), b0.to(dev), w1.to(dev), b1.to(dev), view(dg2), planes=sink, planes_c0=4, planes_gc=2)
+    want = hip_ops.Planes.alloc(B * h * w, 40, dev)
+    hip.split_planes(dg2[:, 4:8].contiguous(), want, c0=8)          # (split_planes_at needs an offset that is a multiple of 8)
+    torch.cuda.synchronize()
+    assert torch.equal(dg2, dg)
+    assert torch.equal(sink.to_rows()[:, :, 4:8], want.to_rows()[:, :, 8:12])
+    rest = sink.to_rows().clone()
+    rest[:, :, 4:8] = 0
+    assert (rest == 0).all() and (sink.t[:, :, sink.rows:] == 0).all()
 
 
 # ------------------------------------------------------------------ warps / resampling
