@@ -738,12 +738,22 @@ __device__ __forceinline__ float pyramid_value(const float* __restrict__ plane, 
 }
 
 __global__ __launch_bounds__(256) void image_pyramid_kernel(const float* __restrict__ im0, const float* __restrict__ im1, float* __restrict__ l1,
-                                                            float* __restrict__ l2, float* __restrict__ l3, int B, int H, int W) {
+                                                            float* __restrict__ l2, float* __restrict__ l3, float* __restrict__ pack, int B, int H, int W) {
     fp16_saturate_on();
     const long long n1 = (long long)(H >> 1) * (W >> 1), n2 = (long long)(H >> 2) * (W >> 2), n3 = (long long)(H >> 3) * (W >> 3);
     const long long planes = 2ll * B * 3;
     const long long t1 = planes * n1, t2 = planes * n2, t3 = planes * n3;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < t1 + t2 + t3; idx += (long long)gridDim.x * blockDim.x) {
+    const long long hw = (long long)H * W, tp = pack ? 2ll * B * hw : 0;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < t1 + t2 + t3 + tp; idx += (long long)gridDim.x * blockDim.x) {
+        if (idx >= t1 + t2 + t3) {
+            // torch.cat([im0, im1], 0) as NHWC4 (the encoder's input; pack_frames_kernel's work in the same launch)
+            const long long e = idx - (t1 + t2 + t3);
+            const int f = (int)(e / hw);
+            const long long pix = e - (long long)f * hw;
+            const float* s = (f < B ? im0 + (long long)f * 3 * hw : im1 + (long long)(f - B) * 3 * hw) + pix;
+            *reinterpret_cast<f32x4*>(pack + e * 4) = (f32x4){s[0], s[hw], s[2 * hw], 0.f};
+            continue;
+        }
         const int lvl = idx < t1 ? 1 : (idx < t1 + t2 ? 2 : 3);
         const long long e = idx - (lvl == 1 ? 0 : (lvl == 2 ? t1 : t1 + t2));
         const long long n = lvl == 1 ? n1 : (lvl == 2 ? n2 : n3);
@@ -1082,12 +1092,19 @@ extern "C" int atmvfi_resize_bilinear_ac(const float* src, int64_t src_bstride, 
     return atmvfi::check_launch("resize_bilinear_ac");
 }
 
-extern "C" int atmvfi_image_pyramid(const float* im0, const float* im1, float* l1, float* l2, float* l3, int B, int H, int W, void* stream) {
+extern "C" int atmvfi_image_pyramid_pack(const float* im0, const float* im1, float* l1, float* l2, float* l3, float* pack, int B, int H, int W,
+                                         void* stream) {
     ATMVFI_REQUIRE(im0 && im1 && l1 && l2 && l3, ATMVFI_EINVAL, "image_pyramid: null pointer");
     ATMVFI_REQUIRE(B > 0 && H >= 8 && W >= 8 && H % 8 == 0 && W % 8 == 0, ATMVFI_EINVAL, "image_pyramid: H, W must be multiples of 8 (got %dx%d)", H, W);
-    const long long total = 2ll * B * 3 * ((long long)(H >> 1) * (W >> 1) + (long long)(H >> 2) * (W >> 2) + (long long)(H >> 3) * (W >> 3));
-    hipLaunchKernelGGL(image_pyramid_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, im0, im1, l1, l2, l3, B, H, W);
+    ATMVFI_REQUIRE(!pack || atmvfi::aligned16(pack), ATMVFI_EALIGN, "image_pyramid: pack must be 16-byte aligned");
+    const long long total = 2ll * B * 3 * ((long long)(H >> 1) * (W >> 1) + (long long)(H >> 2) * (W >> 2) + (long long)(H >> 3) * (W >> 3)) +
+                            (pack ? 2ll * B * H * W : 0);
+    hipLaunchKernelGGL(image_pyramid_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, im0, im1, l1, l2, l3, pack, B, H, W);
     return atmvfi::check_launch("image_pyramid");
+}
+
+extern "C" int atmvfi_image_pyramid(const float* im0, const float* im1, float* l1, float* l2, float* l3, int B, int H, int W, void* stream) {
+    return atmvfi_image_pyramid_pack(im0, im1, l1, l2, l3, nullptr, B, H, W, stream);
 }
 
 extern "C" int atmvfi_pack_frames(const float* im0, const float* im1, float* dst, int B, int H, int W, void* stream) {

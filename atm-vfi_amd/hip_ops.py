@@ -97,6 +97,7 @@ SIGNATURES = {
     "atmvfi_flow_warp_up2": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     "atmvfi_flow_warp_up2_tiled": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     "atmvfi_image_pyramid": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f]),
+    "atmvfi_image_pyramid_pack": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f]),
     "atmvfi_head1x1_planes": (c_i, [c_f, c_f, c_l, c_l, c_i, c_f, c_f, c_i, c_f, c_i, c_f]),
     "atmvfi_conv3x3_planes2": (c_i, [c_f, c_f, c_l, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_l, c_i, c_f, c_f, c_f, c_l, c_i, c_i, c_i, c_f]),
     "atmvfi_conv3x3_planes3": (c_i, [c_f, c_f, c_l, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_l, c_i, c_f, c_f, c_f, c_l, c_i, c_i, c_i, c_f, c_l, c_f]),
@@ -914,6 +915,7 @@ class HipOps:
                   ctypes.byref(p), self._stream())
 
     split_planes_ok = True        # this backend has the split-plane sinks and the LDS-DMA GEMM
+    pyramid_packs = True          # image_pyramid(pack=...) does pack_frames' work in the same launch
     motion_head_sink = True       # ... and the motion head's plane sink (no split pass for the motion MLP's eight motion channels)
 
     def split_planes(self, x, out: Planes, prelu=None, c0: Optional[int] = None):
@@ -1128,16 +1130,20 @@ class HipOps:
         self._run("resize_bilinear_ac", meta, self.lib.atmvfi_resize_bilinear_ac, _ptr(src), src.stride(0), src.stride(1),
                   src.stride(2), src.stride(3), _ptr(dst), b, c, hi, wi, dst.shape[2], dst.shape[3], float(value_scale), self._stream())
 
-    def image_pyramid(self, im0, im1, l1, l2, l3):
-        """The x0.5 pyramid levels 1..3 of both frames in one launch: im0 / im1 contiguous [B,3,H,W]; l1..l3 contiguous [2B,3,H>>l,W>>l]."""
+    def image_pyramid(self, im0, im1, l1, l2, l3, pack=None):
+        """The x0.5 pyramid levels 1..3 of both frames in one launch: im0 / im1 contiguous [B,3,H,W]; l1..l3 contiguous [2B,3,H>>l,W>>l].
+        ``pack``: also write torch.cat([im0, im1], 0) as NHWC4 [2B,H,W,4] (``pack_frames``' output) in the same launch."""
         b, c, h, w = im0.shape
+        if pack is not None and (tuple(pack.shape) != (2 * b, h, w, 4) or not pack.is_contiguous()):
+            raise ValueError("image_pyramid: pack must be contiguous [2B,H,W,4]")
         for t, l in ((l1, 1), (l2, 2), (l3, 3)):
             if not t.is_contiguous() or tuple(t.shape) != (2 * b, 3, h >> l, w >> l):
                 raise ValueError(f"image_pyramid: level {l} must be contiguous [{2 * b},3,{h >> l},{w >> l}], got {tuple(t.shape)}")
         if c != 3 or im1.shape != im0.shape or not im0.is_contiguous() or not im1.is_contiguous():
             raise ValueError("image_pyramid: frames must be contiguous [B,3,H,W]")
-        meta = {"bytes": 4.0 * 2 * b * 3 * h * w * (1 + 0.25 + 0.0625 + 0.015625)}
-        self._run("image_pyramid", meta, self.lib.atmvfi_image_pyramid, _ptr(im0), _ptr(im1), _ptr(l1), _ptr(l2), _ptr(l3), b, h, w, self._stream())
+        meta = {"bytes": 4.0 * 2 * b * 3 * h * w * (1 + 0.25 + 0.0625 + 0.015625) + (4.0 * 2 * b * h * w * 7 if pack is not None else 0.0)}
+        self._run("image_pyramid", meta, self.lib.atmvfi_image_pyramid_pack, _ptr(im0), _ptr(im1), _ptr(l1), _ptr(l2), _ptr(l3), _ptr(pack),
+                  b, h, w, self._stream())
 
     def frame_u8_to_f32(self, src_u8, dst, pad_top: int, pad_left: int, bgr: bool):
         """uint8 [H,W,3] device tensor -> fp32 planar [3,Hp,Wp] (x / 255, replicate padding, optional BGR -> RGB)."""

@@ -936,9 +936,13 @@ class Network(_ParamWatch, BlockRunner, nn.Module):
                 t = self.buf(f"pyr_{l}", 2 * b, 3, H >> l, W >> l)
                 pyr_st.append(t)
                 pyr0.append(t[:b]); pyr1.append(t[b:])
-            ops.image_pyramid(im0, im1, pyr_st[1], pyr_st[2], pyr_st[3])      # one launch for the three levels of both frames
             # encoder + local fusion (:451-455)
-            x0 = self.buf("x0", 2 * b, H, W, 4); ops.pack_frames(im0, im1, x0)
+            x0 = self.buf("x0", 2 * b, H, W, 4)
+            if getattr(ops, "pyramid_packs", False):
+                ops.image_pyramid(im0, im1, pyr_st[1], pyr_st[2], pyr_st[3], pack=x0)   # one launch: three levels of both frames + torch.cat as NHWC4
+            else:
+                ops.image_pyramid(im0, im1, pyr_st[1], pyr_st[2], pyr_st[3])
+                ops.pack_frames(im0, im1, x0)
             cache_ok = self._frame_cache_on and not (self.global_motion and self.ensemble_global_motion)
             glob = self.global_motion and not self.ensemble_global_motion
             cg = v.global_dim
@@ -992,7 +996,11 @@ class Network(_ParamWatch, BlockRunner, nn.Module):
                     g1 = gout[..., 2:4].permute(0, 3, 1, 2)
                 # the two global flows stacked like the frames: every warp / x2 up-sampling below is one launch for both
                 gf = self.buf("gf_3", 2 * b, 2, h, w)
-                ops.resize(g0, gf[:b], 2.0); ops.resize(g1, gf[b:], 2.0)
+                if b == 1 and not self.ensemble_global_motion:
+                    # one pair: [flow0 | flow1] of the motion map's first four channels IS the stacked layout [2, 2, h, w]: one launch
+                    ops.resize(gout[..., 0:4].permute(0, 3, 1, 2), gf.view(1, 4, h, w), 2.0)
+                else:
+                    ops.resize(g0, gf[:b], 2.0); ops.resize(g1, gf[b:], 2.0)
                 featw = self.buf("featw", 2 * b, h, w, C)
                 ops.flow_warp_nhwc(feat.reshape(2 * b, h, w, C), gf, featw)
                 x_tokens = featw.reshape(2 * b * h * w, C)

@@ -362,6 +362,9 @@ int atmvfi_resize_bilinear_ac(const float* src, int64_t src_bstride, int64_t src
  * (H, W multiples of 8); l1 / l2 / l3 planar [2B,3,H>>l,W>>l], frame 0's images first.  Bit-identical to atmvfi_resize_bilinear_ac
  * applied level by level. */
 int atmvfi_image_pyramid(const float* im0, const float* im1, float* l1, float* l2, float* l3, int B, int H, int W, void* stream);
+/* The same and, with `pack` non-NULL, atmvfi_pack_frames' output [2B,H,W,4] in the same launch (both read only the two frames). */
+int atmvfi_image_pyramid_pack(const float* im0, const float* im1, float* l1, float* l2, float* l3, float* pack, int B, int H, int W,
+                              void* stream);
 
 /* flow_warp (flow_warp.py:50-60) of a planar image [B,C,H,W] by a contiguous planar flow [B,2,H,W] into dst, AND that flow up-sampled
  * to [B,2,2H,2W] with its values doubled (upsample_flow, network_base.py:11-18) into flow_up, in one launch: one step of the global

@@ -1157,6 +1157,13 @@ def test_image_pyramid_equals_sequential_resizes(shape, hip, dev):
         assert torch.equal(a, r), maxdiff(a, r)
     want = torch.nn.functional.interpolate(torch.cat([im0, im1], 0), scale_factor=0.5, mode="bilinear", align_corners=True)
     assert maxdiff(lv[0], want) <= 1e-6
+    # with `pack`: pack_frames' NHWC4 stack of the two frames in the same launch, the levels unchanged
+    lv2 = [torch.full_like(t, 5.0) for t in lv]
+    x0, x1 = torch.full((2 * b, h, w, 4), 5.0, device=dev), torch.full((2 * b, h, w, 4), 6.0, device=dev)
+    hip.image_pyramid(im0, im1, *lv2, pack=x0)
+    hip.pack_frames(im0, im1, x1)
+    torch.cuda.synchronize()
+    assert torch.equal(x0, x1) and all(torch.equal(a, r) for a, r in zip(lv2, lv))
 
 
 @pytest.mark.gpu
