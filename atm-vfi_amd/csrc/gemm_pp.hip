@@ -32,11 +32,16 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #ifdef ATMVFI_STAMP
 static unsigned long long* g_pp_stamp = nullptr;
 extern "C" void atmvfi_debug_set_pp_stamp_buffer(void* p) { g_pp_stamp = (unsigned long long*)p; }
+// per-k-step cycle sums (k-step index inside its tile, 0..15): 16 more values per wave behind the 8 of the phase stamps of every wave
+#define PP_KSTAMP_BEGIN() unsigned long long kt0_ = 0; do { if (a.stamp) { __builtin_amdgcn_sched_barrier(0); kt0_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#define PP_KSTAMP_END(idx) do { if (a.stamp) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) atomicAdd(&kst[wave * 16 + ((idx) < 15 ? (idx) : 15)], t_ - kt0_); __builtin_amdgcn_sched_barrier(0); } } while (0)
 #define PP_STAMP(i) do { if (a.stamp) { tstamp[i] = __builtin_amdgcn_s_memtime(); rstamp[i] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #define PP_SUB(k) do { if (a.stamp) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); sub[k] += t_ - sub_t; sub_t = t_; __builtin_amdgcn_sched_barrier(0); } } while (0)
 #else
 #define PP_STAMP(i) do { } while (0)
 #define PP_SUB(k) do { } while (0)
+#define PP_KSTAMP_BEGIN() do { } while (0)
+#define PP_KSTAMP_END(idx) do { } while (0)
 #endif
 
 namespace {
@@ -212,6 +217,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmDev a) {
     f32x4 acc[4][4], cor[4][4];
 
 #ifdef ATMVFI_STAMP
+    unsigned long long* kst = reinterpret_cast<unsigned long long*>(smem + 3 * STAGE + 2 * CST_FLOATS * sizeof(float));
+    if (tid < 128) kst[tid] = 0;
+    __syncthreads();
     unsigned long long tstamp[4], rstamp[4];
     unsigned long long t_loop = 0, t_epi = 0, r_loop = 0, r_epi = 0, t_pro = 0, r_pro = 0;
     int ntile = 0;
@@ -332,14 +340,22 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmDev a) {
         {
             bool g1wait = seq == 0;
             for (int kc = 0; kc + 2 < nk; ++kc) {
+                PP_KSTAMP_BEGIN();
                 kstep(std::integral_constant<int, 0>{}, g1wait);
+                PP_KSTAMP_END(kc);
                 g1wait = true;
             }
             if (nk >= 2) {
+                PP_KSTAMP_BEGIN();
                 kstep(std::integral_constant<int, 1>{}, g1wait);
+                PP_KSTAMP_END(nk - 2);
                 g1wait = true;
             }
-            kstep(std::integral_constant<int, 2>{}, g1wait);
+            {
+                PP_KSTAMP_BEGIN();
+                kstep(std::integral_constant<int, 2>{}, g1wait);
+                PP_KSTAMP_END(nk - 1);
+            }
         }
         PP_STAMP(2);
 #ifdef ATMVFI_STAMP
@@ -710,6 +726,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmDev a) {
         o[4] = r_loop / ntile; o[5] = sub[0] / ntile; o[6] = sub[1] / ntile;
         o[7] = sub[2] / ntile;
     }
+    __syncthreads();
+    if (a.stamp && tid < 128) a.stamp[(long long)gridDim.x * 64 + (long long)blockIdx.x * 128 + tid] = kst[tid] / (ntile ? ntile : 1);
 #endif
 }
 
@@ -717,7 +735,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmDev a) {
 
 template <bool CONVM>
 static int launch_pp(const GemmDev& d, int ngemm, hipStream_t s) {
+#ifdef ATMVFI_STAMP
+    const size_t lds = (size_t)3 * STAGE + 2 * CST_FLOATS * sizeof(float) + 1024;      // + the per-k-step stamp sums
+#else
     const size_t lds = (size_t)3 * STAGE + 2 * CST_FLOATS * sizeof(float);
+#endif
     const hipError_t attr_err = atmvfi::allow_dynamic_lds<gemm_pp_kernel<CONVM>>(lds);
     ATMVFI_REQUIRE(attr_err == hipSuccess, ATMVFI_ELAUNCH, "gemm_pp: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
     ATMVFI_REQUIRE((long long)d.in_ld * 64 < (1ll << 32) && (long long)d.wrows * 64 < (1ll << 32) &&
