@@ -907,6 +907,26 @@ __global__ __launch_bounds__(256) void l1_mean_kernel(const float* __restrict__ 
     if (threadIdx.x == 0) atomicAdd(out + s, (red[0] + red[1] + red[2] + red[3]) / (float)per_sample);
 }
 
+// multiscale_global_motion_ensemble's per-sample pick (network_base.py:591-603): the candidate whose alignment loss is the minimum, the
+// FIRST one on ties (the reference's if / elif chain over levels 0, 1, 2), copied into the output flows.  Candidates are already at the
+// level-0 flow resolution (the x2 / x4 up-sampling of levels 1 / 2 is the candidates' resize).
+__global__ __launch_bounds__(256) void ensemble_select_kernel(const float* __restrict__ l0, const float* __restrict__ l1, const float* __restrict__ l2,
+                                                              const float* __restrict__ a0, const float* __restrict__ b0,
+                                                              const float* __restrict__ a1, const float* __restrict__ b1,
+                                                              const float* __restrict__ a2, const float* __restrict__ b2,
+                                                              float* __restrict__ out0, float* __restrict__ out1, int B, long long per_sample) {
+    fp16_saturate_on();
+    const long long total = (long long)B * per_sample;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int s = (int)(idx / per_sample);
+        const float x0 = l0[s], x1 = l1[s], x2 = l2[s];
+        const float mn = fminf(fminf(x0, x1), x2);
+        const int pick = x0 == mn ? 0 : (x1 == mn ? 1 : 2);
+        out0[idx] = pick == 0 ? a0[idx] : (pick == 1 ? a1[idx] : a2[idx]);
+        out1[idx] = pick == 0 ? b0[idx] : (pick == 1 ? b1[idx] : b2[idx]);
+    }
+}
+
 inline unsigned grid_for(long long total) {
     long long b = (total + 255) / 256;
     if (b > 8192) b = 8192;   // 256 CUs x 32 blocks, grid-stride the rest
@@ -1153,8 +1173,21 @@ extern "C" int atmvfi_refine_tail(const float* contrib, int64_t contrib_plane, c
     return atmvfi::check_launch("refine_tail");
 }
 
+extern "C" int atmvfi_ensemble_select(const float* loss0, const float* loss1, const float* loss2, const float* c0_l0, const float* c1_l0,
+                                      const float* c0_l1, const float* c1_l1, const float* c0_l2, const float* c1_l2, float* out0, float* out1, int B,
+                                      int64_t per_sample, void* stream) {
+    ATMVFI_REQUIRE(loss0 && loss1 && loss2 && c0_l0 && c1_l0 && c0_l1 && c1_l1 && c0_l2 && c1_l2 && out0 && out1 && B > 0 && per_sample > 0,
+                   ATMVFI_EINVAL, "ensemble_select: bad arguments");
+    hipLaunchKernelGGL(ensemble_select_kernel, dim3(grid_for((long long)B * per_sample)), dim3(256), 0, (hipStream_t)stream, loss0, loss1, loss2,
+                       c0_l0, c1_l0, c0_l1, c1_l1, c0_l2, c1_l2, out0, out1, B, (long long)per_sample);
+    return atmvfi::check_launch("ensemble_select");
+}
+
 extern "C" int atmvfi_l1_mean(const float* a, const float* b, float* out, int B, int64_t per_sample, void* stream) {
     ATMVFI_REQUIRE(a && b && out && B > 0 && per_sample > 0, ATMVFI_EINVAL, "l1_mean: bad arguments");
+    // the accumulator is cleared here, on the caller's stream (the launch is self-contained: recordable into a launch plan)
+    const hipError_t me = hipMemsetAsync(out, 0, (size_t)B * sizeof(float), (hipStream_t)stream);
+    ATMVFI_REQUIRE(me == hipSuccess, ATMVFI_ELAUNCH, "l1_mean: hipMemsetAsync: %s", hipGetErrorString(me));
     long long bx = (per_sample + 256 * 16 - 1) / (256 * 16);
     if (bx > 1024) bx = 1024;
     hipLaunchKernelGGL(l1_mean_kernel, dim3((unsigned)bx, (unsigned)B), dim3(256), 0, (hipStream_t)stream, a, b, out,

@@ -128,6 +128,7 @@ SIGNATURES = {
     "atmvfi_pack_frames": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_f]),
     "atmvfi_final_residual": (c_i, [c_f, c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_f]),
     "atmvfi_l1_mean": (c_i, [c_f, c_f, c_f, c_i, c_l, c_f]),
+    "atmvfi_ensemble_select": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_l, c_f]),
     "atmvfi_stem_fused": (c_i, [c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_l, c_f]),
     "atmvfi_plan_fn_id": (c_i, [ctypes.c_char_p]),
     "atmvfi_plan_run": (c_i, [ctypes.POINTER(PlanOp), c_i, ctypes.POINTER(PlanPatch), c_i, ctypes.POINTER(ctypes.c_uint64), c_i,
@@ -1186,8 +1187,19 @@ class HipOps:
         _chk(a, "l1_mean.a"); _chk(b, "l1_mean.b")
         if not a.is_contiguous() or not b.is_contiguous() or a.shape != b.shape:
             raise ValueError("l1_mean: inputs must be contiguous and of equal shape")
-        if self.recording is not None:
-            raise PlanUnsupported("l1_mean clears its accumulator with a torch op")
-        out.zero_()
         n = a.shape[0]
         self._run("l1_mean", {"bytes": 8.0 * a.numel()}, self.lib.atmvfi_l1_mean, _ptr(a), _ptr(b), _ptr(out), n, a.numel() // n, self._stream())
+
+    def ensemble_select(self, losses, cands, out0, out1):
+        """Per sample the candidate flow pair of the level with the smallest loss (first on ties): losses = three [B] tensors,
+        cands = three (flow0, flow1) pairs of contiguous [B,2,h,w] tensors, out0 / out1 contiguous [B,2,h,w]."""
+        b = out0.shape[0]
+        per = out0.numel() // b
+        ts = [t for pair in cands for t in pair] + [out0, out1]
+        if len(losses) != 3 or len(cands) != 3 or any(t.shape != out0.shape or not t.is_contiguous() for t in ts) or any(l.numel() != b for l in losses):
+            raise ValueError("ensemble_select: three [B] losses, three pairs of contiguous [B,2,h,w] candidates and two outputs of that shape expected")
+        for t in ts + list(losses):
+            _chk(t, "ensemble_select")
+        self._run("ensemble_select", {"bytes": 4.0 * out0.numel() * 4}, self.lib.atmvfi_ensemble_select, _ptr(losses[0]), _ptr(losses[1]),
+                  _ptr(losses[2]), _ptr(cands[0][0]), _ptr(cands[0][1]), _ptr(cands[1][0]), _ptr(cands[1][1]), _ptr(cands[2][0]),
+                  _ptr(cands[2][1]), _ptr(out0), _ptr(out1), b, per, self._stream())

@@ -732,6 +732,10 @@ class Network(_ParamWatch, BlockRunner, nn.Module):
                 k0 = self.buf(f"ens_c0_{lvl}", b, 2, h // 16, w // 16); ops.resize(f0, k0, float(1 << lvl))
                 k1 = self.buf(f"ens_c1_{lvl}", b, 2, h // 16, w // 16); ops.resize(f1, k1, float(1 << lvl))
             cands.append((k0, k1)); losses.append(loss)
+        if hasattr(ops, "ensemble_select"):                # the pick inside the C ABI: no device arithmetic outside it, plannable
+            s0, s1 = self.buf("ens_sel0", b, 2, h // 16, w // 16), self.buf("ens_sel1", b, 2, h // 16, w // 16)
+            ops.ensemble_select(losses, cands, s0, s1)
+            return s0, s1
         ls = torch.stack(losses, 0)                        # [3,B]; first minimum wins like the reference's if/elif chain
         pick = ls.argmin(dim=0)
         sel0 = torch.stack([c[0] for c in cands], 0)       # [3,B,2,h_,w_]
@@ -775,8 +779,9 @@ class Network(_ParamWatch, BlockRunner, nn.Module):
     def enable_plans(self, flag: bool = True):
         """Launch plans (default on): once a (shape, mode, weights) combination has run twice, its forward is recorded
         (``hip_ops.LaunchPlan``) and every later one is a single ``atmvfi_plan_run`` call -- same launches, same arguments, fresh
-        output tensors -- instead of ~120 Python-side op calls.  Not used with ensemble mode, the frame cache, graphs or per-launch
-        profiling (those forwards contain work outside the C ABI or need the individual launches)."""
+        output tensors -- instead of ~120 Python-side op calls.  Not used with the frame cache, graphs or per-launch profiling (those
+        forwards contain copies outside the C ABI or need the individual launches).  Ensemble mode is planned too since round 4 (its
+        per-sample pick is `atmvfi_ensemble_select`)."""
         self.use_plans = bool(flag)
         if not flag:
             self._plans.clear()
@@ -796,7 +801,7 @@ class Network(_ParamWatch, BlockRunner, nn.Module):
             return self._forward_graph(im0, im1)
         ops = self._ops_obj
         pl = self._plist
-        if (not self.use_plans or self.ensemble_global_motion or not isinstance(ops, HipOps) or ops.profile is not None
+        if (not self.use_plans or not isinstance(ops, HipOps) or ops.profile is not None
                 or pl is None or pl[0].device != im0.device or torch.cuda.is_current_stream_capturing()):
             return self._forward_eager(im0, im1)         # (also every case that must raise: it validates devices and shapes)
         self._prepare(ops)

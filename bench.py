@@ -130,7 +130,7 @@ def parse():
     return args
 
 
-def time_config(pkg, host_io, pairs, dev, cname, steps, warmup, precision, shared=None):
+def time_config(pkg, host_io, pairs, dev, cname, steps, warmup, precision, shared=None, ensemble=False):
     """One BASELINE.json configuration on one GPU, timed like the headline: resident synthetic pairs, ``warmup`` untimed forwards (they
     also record the launch plan), ``steps`` timed ones between synchronisations.  -> the entry of the bench line's ``configs`` block."""
     variant, height, width, g_on, desc = CONFIGS[cname]
@@ -143,6 +143,7 @@ def time_config(pkg, host_io, pairs, dev, cname, steps, warmup, precision, share
         net.to(dev).eval()
         net.set_precision(precision)
     net.global_motion = g_on
+    net.ensemble_global_motion = bool(ensemble)          # multiscale_global_motion_ensemble (network_base.py:564-605): three input scales
     padder = host_io.InputPadder((1, 3, height, width), divisor=64)
     frames = []
     for i in range(2):
@@ -159,9 +160,10 @@ def time_config(pkg, host_io, pairs, dev, cname, steps, warmup, precision, share
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     fps = steps / el
-    out = {"workload": desc + f" (padded {H}x{W})", "value": round(fps, 3), "unit": "frames/s", "ms_per_step": round(1e3 * el / steps, 4),
+    net.ensemble_global_motion = False
+    out = {"workload": desc + f" (padded {H}x{W})" + (", ensemble_global_motion on" if ensemble else ""), "value": round(fps, 3), "unit": "frames/s", "ms_per_step": round(1e3 * el / steps, 4),
            "steps": steps, "warmup": warmup}
-    fl = FLOPS_PER_PAIR.get((variant, H, W, g_on))
+    fl = None if ensemble else FLOPS_PER_PAIR.get((variant, H, W, g_on))
     if fl:
         out["forward_tflops"] = round(fl * fps / 1e12, 2)
         out["forward_frac_of_f16x3_peak"] = round(fl * fps / 1e12 / (PEAK_F16_MFMA_TFLOPS / 3.0), 4)
@@ -484,6 +486,9 @@ def main():
             for cname, csteps, cwarm in (("c1", 200, 20), ("c2", 200, 20), ("c3", 60, 6), ("c5", 4, 3)):
                 result["configs"][cname] = time_config(pkg, host_io, pairs, dev, cname, csteps, cwarm, args.precision,
                                                        shared=(net, sd) if CONFIGS[cname][0] == variant else None)
+            # the large-motion mode of the API on the c3 frame size: planned like every other mode since its pick moved
+            # into the C ABI (atmvfi_ensemble_select)
+            result["configs"]["c3_ensemble"] = time_config(pkg, host_io, pairs, dev, "c3", 40, 6, args.precision, shared=(net, sd), ensemble=True)
             net.global_motion = not args.global_off
         # ---- CPU baseline: the oracle on this node's host cores, bounded sample ----
         if world == 1 and not args.no_cpu_baseline:

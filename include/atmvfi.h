@@ -405,8 +405,14 @@ int atmvfi_refine_tail(const float* contrib, int64_t contrib_plane, const float*
 int atmvfi_frame_u8_to_f32(const void* src, int H, int W, int bgr, float* dst, int Hp, int Wp, int pad_top, int pad_left, void* stream);
 int atmvfi_frame_f32_to_u8(const float* src, int Hp, int Wp, int pad_top, int pad_left, void* dst, int H, int W, int bgr, void* stream);
 
-/* mean |a - b| per sample: global_alignmentness (network_base.py:560-561).  out[B] must be zeroed by the caller. */
+/* mean |a - b| per sample: global_alignmentness (network_base.py:560-561).  out[B] is cleared by the call (on `stream`). */
 int atmvfi_l1_mean(const float* a, const float* b, float* out, int B, int64_t per_sample, void* stream);
+/* multiscale_global_motion_ensemble's per-sample pick (network_base.py:591-603): out0 / out1 [B, per_sample] = the candidate flow pair
+ * (c0_lL, c1_lL, already at the level-0 flow resolution) of the level whose loss[b] is the minimum, the first one on ties (the
+ * reference's if / elif chain).  Keeps the ensemble forward free of device arithmetic outside this ABI. */
+int atmvfi_ensemble_select(const float* loss0, const float* loss1, const float* loss2, const float* c0_l0, const float* c1_l0,
+                           const float* c0_l1, const float* c1_l1, const float* c0_l2, const float* c1_l2, float* out0, float* out1, int B,
+                           int64_t per_sample, void* stream);
 
 /* The encoder's full-resolution stem in one launch: feat_extracts.0.0 (3 -> C0, 3x3 + PReLU), feat_extracts.0.1 (C0 -> C0, 3x3 + PReLU) and
  * feat_extracts.1.0 (C0 -> C1, 3x3 stride 2 + PReLU) of shared_feat_extraction (network_base.py:99-110, 342-352), (C0, C1) = (24, 48) or

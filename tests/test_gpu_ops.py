@@ -424,6 +424,19 @@ def test_pack_final_l1(hip, cpu, dev):
     cpu.l1_mean(im0, im1, lc)
     hip.l1_mean(im0.to(dev), im1.to(dev), lg)
     assert maxdiff(lg, lc) <= 1e-6
+    hip.l1_mean(im0.to(dev), im1.to(dev), lg)                 # the call clears its accumulator itself: a second call does not add up
+    assert maxdiff(lg, lc) <= 1e-6
+    # ensemble pick (network_base.py:591-603): per sample the candidate pair of the smallest loss, the FIRST on ties
+    g2 = torch.Generator().manual_seed(77)
+    B = 5
+    cands = [(torch.rand(B, 2, 6, 9, generator=g2).to(dev), torch.rand(B, 2, 6, 9, generator=g2).to(dev)) for _ in range(3)]
+    losses = [torch.tensor(v, device=dev) for v in ([0.3, 0.2, 0.5, 0.1, 0.4], [0.2, 0.2, 0.4, 0.1, 0.3], [0.9, 0.1, 0.4, 0.1, 0.3])]
+    picks = [1, 2, 1, 0, 1]
+    o0, o1 = torch.full((B, 2, 6, 9), 7.0, device=dev), torch.full((B, 2, 6, 9), 7.0, device=dev)
+    hip.ensemble_select(losses, cands, o0, o1)
+    torch.cuda.synchronize()
+    for i, pk in enumerate(picks):
+        assert torch.equal(o0[i], cands[pk][0][i]) and torch.equal(o1[i], cands[pk][1][i]), (i, pk)
 
 
 # ------------------------------------------------------------------ a whole ATMFormer block (reference fixture)
