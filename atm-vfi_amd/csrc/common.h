@@ -70,14 +70,22 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void fp16_saturate_on() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1"); }
 
 // The hi/lo split of the f16x3 engines on two values at once: hi = fp16(x), lo' = fp16((x - hi) * 1024), both conversions
-// saturating at +-65504 through MODE.FP16_OVFL (fp16_saturate_on() at the kernel's top): v_cvt_pk_f16_f32, two v_cvt_f32_f16,
-// v_pk_add_f32, v_pk_mul_f32, v_cvt_pk_f16_f32 -- 3 VALU instructions per value.  Until round 2 the saturation was four
-// v_med3_f32 (5 per value, and the epilogues / operand stagings that split are VALU-bound); bit-identical for every finite
-// input.  An infinite input now stays infinite in hi and makes lo' NaN (it was +-65504 / +-65504): the fp32 reference has inf or
-// NaN downstream of such a value as well.
+// saturating at +-65504 through MODE.FP16_OVFL (fp16_saturate_on() at the kernel's top).  Four VALU instructions per two values:
+// v_cvt_pk_f16_f32, v_pk_mul_f32 (x * 1024), and v_fma_mixlo_f16 / v_fma_mixhi_f16 computing fp16(fma(hi, -1024, x * 1024)) with hi
+// read as the fp16 half it is -- x - hi and both products are exact in fp32, so the one rounding to fp16 sees the same real number as
+// the six-instruction form (v_cvt_pk, two v_cvt_f32_f16, v_pk_add_f32, v_pk_mul_f32, v_cvt_pk) it replaces: bit-identical for all 2^32
+// fp32 bit patterns under FP16_OVFL = 1 (tools/probes/split_mix_probe.hip, profiles/r04_split_mix_probe.txt).  The epilogues and
+// operand stagings that split are VALU-bound.  (Until round 2 the saturation was four v_med3_f32: 5 per value.)  An infinite input
+// stays infinite in hi and makes lo' NaN: the fp32 reference has inf or NaN downstream of such a value as well.
 __device__ __forceinline__ void split_pair(const f32x2 x, f16x2& hi, f16x2& lo) {
     hi = __builtin_convertvector(x, f16x2);
-    lo = __builtin_convertvector((x - __builtin_convertvector(hi, f32x2)) * 1024.0f, f16x2);
+    const f32x2 xs = x * 1024.0f;
+    const unsigned hb = __builtin_bit_cast(unsigned, hi);
+    const float k = 1024.0f;
+    unsigned lb;
+    asm("v_fma_mixlo_f16 %0, %1, -%2, %3 op_sel_hi:[1,0,0]" : "=v"(lb) : "v"(hb), "v"(k), "v"(xs.x));
+    asm("v_fma_mixhi_f16 %0, %1, -%2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lb) : "v"(hb), "v"(k), "v"(xs.y));
+    lo = __builtin_bit_cast(f16x2, lb);
 }
 
 // Output of a row-producing kernel: fp32 rows, and/or the split-plane pair (hi = fp16(x), lo = fp16((x - hi) * 1024), both

@@ -31,13 +31,25 @@
 // Diagnostic build only (`make stamp`, tools/stamp_conv3p.py): per-wave s_memtime sums of the phases of a k-step.
 static unsigned long long* g_planes_stamp = nullptr;
 extern "C" void atmvfi_debug_set_planes_stamp_buffer(void* p) { g_planes_stamp = (unsigned long long*)p; }
+#ifdef ATMVFI_STAMP_KSTEP
 #define PDBG(bit) ((a.dbg & (bit)) != 0)
+#else
+#define PDBG(bit) false
+#endif
 #define PSTAMP_DECL unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_epi = 0; unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
-#define PSTAMP(k) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); st_[k] += t1_ - st_t0; st_t0 = t1_; __builtin_amdgcn_sched_barrier(0); }
+#define TSTAMP(k) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); st_[k] += t1_ - st_t0; st_t0 = t1_; __builtin_amdgcn_sched_barrier(0); }
+#ifdef ATMVFI_STAMP_KSTEP
+// (per-phase stamps inside the k-step: eight s_memtime per k-step and 16 more live scalars -- since the persistent grid this build spills
+// and its phase numbers are not the product's; the default stamp build only times whole tiles: TSTAMP below)
+#define PSTAMP(k) TSTAMP(k)
+#else
+#define PSTAMP(k)
+#endif
 #else
 #define PDBG(bit) false
 #define PSTAMP_DECL
 #define PSTAMP(k)
+#define TSTAMP(k)
 #endif
 
 namespace {
@@ -89,8 +101,10 @@ constexpr int HALO_LO = HALO_PLANE_PIECES * 1024;            // byte offset of t
 constexpr int HALO_BYTES = 2 * HALO_LO;
 
 // weight ring depth: as many k-steps as fit beside the two halo buffers and the epilogue constants in 160 KiB, at most 5
+// epilogue constants of a tile in LDS: bias, PReLU slope and the plane sink's own slope for its BN columns (three rows of BN floats)
+constexpr int planes_const_floats(int BN) { return (3 * BN + 63) / 64 * 64; }
 constexpr int ring_slots(int wn) {
-    const int free_bytes = 160 * 1024 - 2 * HALO_BYTES - 2 * 1024 - 1024;     // two halo buffers, two buffers of epilogue constants (<= 1 KiB each), 1 KiB slack
+    const int free_bytes = 160 * 1024 - 2 * HALO_BYTES - 2 * planes_const_floats(16 * wn) * 4;     // two halo buffers, two buffers of epilogue constants
     const int n = free_bytes / (2 * 16 * wn * 64);
     return n > 5 ? 5 : n;            // the static vmcnt counts of the k-loop assume a lookahead of at most 4 k-steps
 }
@@ -101,6 +115,25 @@ __device__ __forceinline__ void dma16(const unsigned char* src, unsigned char* l
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// One LDS-DMA instruction per wave (4 bytes per lane): cst[c] = bias[n0 + c], cst[BN + c] = slope[n0 + c], cst[2 BN + c] = plane_slope[n0 + c]
+// for the tile's BN columns, 0 / 1 / 1 where an array is absent or the column is past Cout.  (The plane sink's slopes used to be global loads
+// inside the store loop: every one of them made hipcc wait for vmcnt(0), i.e. for the previous n-tile pair's STORES to be acknowledged --
+// the sink epilogue of a 112-column tile took 9.4 k cycles against 5.1 k for fp32 rows, tools/stamp_conv3p.py.)
+template <int BN>
+__device__ __forceinline__ void dma_planes_consts(const float* bias, const float* slope, const float* plane_slope, int Cout, int n0, float* cst,
+                                                  int wave, int lane) {
+    constexpr int NPIECE = (3 * BN + 63) / 64;
+    static_assert(NPIECE <= 8, "one piece per wave");
+    const int piece = wave % NPIECE;
+    const int t = piece * 64 + lane;
+    const int row = t / BN;
+    const int col = n0 + t - row * BN;
+    const float* src = row == 0 ? bias : row == 1 ? slope : plane_slope;
+    const float* p = (src && row < 3 && col < Cout) ? src + col : &kEpilogueDefaults[row == 0 ? 0 : 1];
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                     (__attribute__((address_space(3))) void*)(cst + piece * 64), 4, 0, 0);
+}
+
 template <int WN>
 __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev a) {
     fp16_saturate_on();
@@ -109,7 +142,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
     constexpr int SW = (2 * WN + 7) / 8;                // weight pieces per wave and k-step (some waves one fewer)
     constexpr int NB = ring_slots(WN);                  // weight ring slots (k-steps)
     constexpr int LA = NB - 1;                          // k-steps between a slot's DMA issue and its first read
-    constexpr int CSTF = epilogue_const_floats(BN);
+    constexpr int CSTF = planes_const_floats(BN);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned halo0 = lds_offset(smem);                        // two halo buffers
     const unsigned ring0 = halo0 + 2 * HALO_BYTES;                  // NB weight slots
@@ -311,7 +344,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
     PSTAMP_DECL
     // ---- prologue of the first tile: epilogue constants, halo of chunk 0, weights of k-steps 0 .. LA-1; everything lands before
     // the first read (later tiles: the wait at the tile boundary), so the first LA - 1 k-steps of a tile wait for nothing ----
-    dma_epilogue_consts<BN>(a.bias, a.prelu, n0, cst_base, wave, lane, [&](int col) { return col < a.Cout ? col : -1; });
+    dma_planes_consts<BN>(a.bias, a.prelu, a.plane_prelu, a.Cout, n0, cst_base, wave, lane);
     static_for<0, 6>([&](auto sc) { issue_halo(sc); });
     halo_advance();
 #pragma unroll
@@ -319,7 +352,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
     wait_vm<0>();
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();          // the second group runs one phase behind
-    PSTAMP(0)
+    TSTAMP(0)
 
     f16x8 xh[2], xl[2], wh[WN], wl[WN];
     const unsigned wfrag = ring0 + (unsigned)(r * 64 + ((g ^ swz64(r)) << 4));       // swz64(16 j + r) == swz64(r)
@@ -459,13 +492,19 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
         // ---- tile boundary.  The first group waits for the second one's last MFMA phase; the next tile's epilogue constants go
         // out; everything else in flight -- the next tile's first LA k-steps of weights and its first halo -- has to be complete
         // before that tile's first read, and is waited for HERE, before this tile's stores join the queue (vmcnt counts them).
+#if !defined(ATMVFI_STAMP_KSTEP)
+        TSTAMP(1)             // the tile's k-loop
+#endif
         if (grp == 0) __builtin_amdgcn_s_barrier();
         if (has_next) {
-            dma_epilogue_consts<BN>(a.bias, a.prelu, nn0, cst_base + ((seq + 1) & 1) * CSTF, wave, lane, [&](int col) { return col < a.Cout ? col : -1; });
+            dma_planes_consts<BN>(a.bias, a.prelu, a.plane_prelu, a.Cout, nn0, cst_base + ((seq + 1) & 1) * CSTF, wave, lane);
             wait_vm<1>();             // all but the constants: the next tile's first LA k-steps of weights and its first halo
         } else {
             wait_vm<0>();
         }
+#if !defined(ATMVFI_STAMP_KSTEP)
+        TSTAMP(2)             // the first group's wait for the second one's last MFMA phase + the wait for the next tile's first DMA
+#endif
 
     // ---- epilogue.  Lane (r, g) holds rows 4g..4g+3 of every 16-row n-tile = channels cb(g)..cb(g)+3 with cb = {0, 8, 4, 12}:
     // the weight rows were permuted that way on their way into LDS (wlane), so that lanes g and g + 2 -- the two halves of the
@@ -576,17 +615,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
     // 16j + 8g .. of n-tile j and the upper half-wave those of n-tile j+1 (T21 of the programming guide), so ONE 16-byte
     // store per lane and plane writes 16 pixels x 32 channels x 2 bytes = one contiguous KiB of the chunk-major plane.
     // Channels past Cout inside the last group of 8 are zero (zero weight rows, zero bias); groups beyond are not stored.
-    auto plane_sink = [&](_Float16* phi, _Float16* plo, long long prows, int pc0, const float* pslope) {
+    auto plane_sink = [&](_Float16* phi, _Float16* plo, long long prows, int pc0, const bool pslope) {
         const int climit = (a.Cout + 7) & ~7;
         constexpr int NP = (WN + 1) / 2;
 #pragma unroll
         for (int jp = 0; jp < NP; ++jp) {
             const int j0 = 2 * jp, j1 = (2 * jp + 1 < WN) ? 2 * jp + 1 : 2 * jp;
             f32x4 s0 = (f32x4){1.f, 1.f, 1.f, 1.f}, s1 = s0;
-            if (pslope) {               // padded to a multiple of 32 floats by the host
-                const int c0 = n0 + 16 * j0 + cb, c1 = n0 + 16 * j1 + cb;
-                s0 = *reinterpret_cast<const f32x4*>(pslope + (c0 < a.Cout ? c0 : 0));
-                s1 = *reinterpret_cast<const f32x4*>(pslope + (c1 < a.Cout ? c1 : 0));
+            if (pslope) {               // the sink's own slopes: third row of the tile's constants (no global load between the stores)
+                s0 = *reinterpret_cast<const f32x4*>(cst + 2 * BN + 16 * j0 + cb);
+                s1 = *reinterpret_cast<const f32x4*>(cst + 2 * BN + 16 * j1 + cb);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -623,8 +661,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
             }
         }
     };
-    if (a.out_hi) plane_sink(a.out_hi, a.out_lo, a.plane_rows, a.out_c0, a.plane_prelu);
-    if (a.out_hi2) plane_sink(a.out_hi2, a.out_lo2, a.plane_rows2, a.out_c02, nullptr);
+    if (a.out_hi) plane_sink(a.out_hi, a.out_lo, a.plane_rows, a.out_c0, a.plane_prelu != nullptr);
+    if (a.out_hi2) plane_sink(a.out_hi2, a.out_lo2, a.plane_rows2, a.out_c02, false);
 #ifdef ATMVFI_STAMP
         if (a.stamp) {
             __builtin_amdgcn_sched_barrier(0);
@@ -643,6 +681,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
 #pragma unroll
         for (int s = 0; s < SW; ++s) wnext[s] = weight_base(s, nn0);
         if (grp == 1) __builtin_amdgcn_s_barrier();          // the second group drops one phase behind again
+#if !defined(ATMVFI_STAMP_KSTEP)
+        TSTAMP(3)             // the next-but-one tile's decode + the second group's extra barrier
+#endif
     }
 #ifdef ATMVFI_STAMP
     if (a.stamp && lane == 0) {
@@ -659,7 +700,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
 template <int WN>
 int launch_planes(const Conv3PDev& d, int ntiles, hipStream_t s) {
     constexpr int BN = 16 * WN;
-    const size_t lds = (size_t)2 * HALO_BYTES + (size_t)ring_slots(WN) * 2 * BN * 64 + 2 * epilogue_const_floats(BN) * sizeof(float);
+    const size_t lds = (size_t)2 * HALO_BYTES + (size_t)ring_slots(WN) * 2 * BN * 64 + 2 * planes_const_floats(BN) * sizeof(float);
+    static_assert(2 * HALO_BYTES + ring_slots(WN) * 2 * BN * 64 + 2 * planes_const_floats(BN) * 4 <= 160 * 1024, "LDS budget");
     auto kern = conv3x3_planes_kernel<WN>;
     const hipError_t attr_err = atmvfi::allow_dynamic_lds<conv3x3_planes_kernel<WN>>(lds);
     ATMVFI_REQUIRE(attr_err == hipSuccess, ATMVFI_ELAUNCH, "conv3x3_planes: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));

@@ -23,18 +23,29 @@ nblk = (((H + 15) // 16) * ((W + 15) // 16) + 7) // 8 * 8 * 8
 buf = torch.zeros(nblk * 8 * 10, dtype=torch.int64, device=dev)
 ops.lib.atmvfi_debug_set_planes_stamp_buffer.argtypes = [ctypes.c_void_p]
 ops.lib.atmvfi_debug_set_planes_stamp_buffer(ctypes.c_void_p(buf.data_ptr()))
+mode = os.environ.get("ATMVFI_STAMP_OUT", "f32")       # f32: fp32 rows; sink: a plane sink; sink+prelu: through its own PReLU; both: rows + sink
+yp = hip_ops.Planes.alloc(H * W, cout, dev)
+slope = torch.full(((cout + 31) // 32 * 32,), 0.25, device=dev)
+kw = {"f32": dict(out=y[..., :cout]), "sink": dict(planes=yp), "sink+prelu": dict(planes=yp, planes_prelu=slope),
+      "both": dict(out=y[..., :cout], planes=yp, planes_prelu=slope)}[mode]
+print("outputs:", mode)
 for _ in range(3):
-    ops.conv3x3_planes(xp, 1, H, W, pw, out=y[..., :cout], bias=b, prelu=b, wn=wn)
+    ops.conv3x3_planes(xp, 1, H, W, pw, bias=b, prelu=b, wn=wn, **kw)
 torch.cuda.synchronize()
 t = buf.reshape(-1, 8, 10).double()
 t = t[t[:, 0, 9] > 0]
-names = ["prologue", "fragment address + ds_read issue", "DMA issue", "vmcnt wait", "lgkmcnt(0) wait", "barrier after read phase",
-         "MFMA phase", "barrier after MFMA phase", "epilogue"]
+if os.environ.get("ATMVFI_STAMP_KSTEP"):      # a library built with -DATMVFI_STAMP -DATMVFI_STAMP_KSTEP (spills since the persistent grid)
+    names = ["prologue", "fragment address + ds_read issue", "DMA issue", "vmcnt wait", "lgkmcnt(0) wait", "barrier after read phase",
+             "MFMA phase", "barrier after MFMA phase", "epilogue"]
+else:                                         # the default stamp build: whole tiles only (four s_memtime per tile)
+    names = ["prologue (first tile only)", "k-loop", "boundary: partner's last MFMA + DMA wait", "next decode + re-stagger barrier",
+             "-", "-", "-", "-", "epilogue (VALU + stores)"]
 nk = t[0, 0, 9].item()
 for grp in (0, 1):
     tg = t[:, 4 * grp:4 * grp + 4, :9].reshape(-1, 9)
     tot = tg.sum(1).mean().item()
     print(f"{H}x{W} {cin}->{cout} wn {wn} group {grp}: {tg.shape[0]} waves, {nk:.0f} k-steps, mean ticks per wave {tot:.0f} (per k-step {tot / nk:.0f})")
     for k in range(9):
+        if names[k] == "-": continue
         m = tg[:, k].mean().item()
         print(f"  {names[k]:34s} {m:10.0f}  {100 * m / tot:5.1f} %   per k-step {m / nk:7.0f}")
