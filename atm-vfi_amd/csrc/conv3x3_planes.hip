@@ -506,6 +506,48 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
         TSTAMP(2)             // the first group's wait for the second one's last MFMA phase + the wait for the next tile's first DMA
 #endif
 
+    // ---- PReLU as max(v, s v).  For 0 <= s <= 1 that IS v > 0 ? v : s v, bit for bit (s v lies between v and 0, signed zeros included),
+    // in 1.5 VALU instructions per value (v_pk_mul_f32 + v_max_f32) instead of 2.5 and two wait states (v_cmp -> vcc -> v_cndmask);
+    // a tile whose constants hold a slope outside [0, 1] (or a NaN) takes the select form.  Both activations of a decoder tile are
+    // ~45 % of its epilogue's VALU work, and the epilogue is VALU-bound (tools/stamp_conv3p.py).  The check reads the tile's two slope
+    // rows from LDS (absent arrays and columns past Cout hold 1).
+    constexpr bool MAXFORM = WN < 8;
+    bool slopes_in_range = true;
+#pragma unroll
+    for (int k = 0; MAXFORM && k < (2 * BN + 63) / 64; ++k) {
+        const int idx = BN + 64 * k + lane;
+        const float sv = cst[idx < 3 * BN ? idx : 3 * BN - 1];
+        slopes_in_range = slopes_in_range && sv >= 0.f && sv <= 1.f;
+    }
+    const bool pmax = __builtin_amdgcn_ballot_w64(!slopes_in_range) == 0ull;
+    // (one uniform branch per STAGE -- the fold / bias / activation loop, each plane sink -- chooses the form: a branch around every
+    // activation costs more scalar time than the form saves, two copies of the whole epilogue cost 16-60 registers)
+    auto prelu4 = [](auto mode, const f32x4 v, const f32x4 sl, const bool on) -> f32x4 {
+        constexpr int MODE = decltype(mode)::value;          // 0: no activation, 1: select form, 2: max form, 3: select form if `on`
+        if constexpr (MODE == 3) {
+            f32x4 o = v;
+            if (on) o = (f32x4){v.x > 0.f ? v.x : sl.x * v.x, v.y > 0.f ? v.y : sl.y * v.y, v.z > 0.f ? v.z : sl.z * v.z, v.w > 0.f ? v.w : sl.w * v.w};
+            return o;
+        } else
+        if constexpr (MODE == 2) {
+            const f32x4 t = sl * v;
+            f32x4 o;
+            // (v_max_f32 by hand: fmaxf() makes hipcc canonicalize each operand first -- a second v_max_f32 per value)
+            asm("v_max_f32 %0, %1, %2" : "=v"(o.x) : "v"(v.x), "v"(t.x));
+            asm("v_max_f32 %0, %1, %2" : "=v"(o.y) : "v"(v.y), "v"(t.y));
+            asm("v_max_f32 %0, %1, %2" : "=v"(o.z) : "v"(v.z), "v"(t.z));
+            asm("v_max_f32 %0, %1, %2" : "=v"(o.w) : "v"(v.w), "v"(t.w));
+            return o;
+        } else if constexpr (MODE == 1) {
+            return (f32x4){v.x > 0.f ? v.x : sl.x * v.x, v.y > 0.f ? v.y : sl.y * v.y, v.z > 0.f ? v.z : sl.z * v.z, v.w > 0.f ? v.w : sl.w * v.w};
+        } else {
+            return v;
+        }
+    };
+    typedef std::integral_constant<int, 0> ActNone;
+    typedef std::integral_constant<int, 1> ActSelect;
+    typedef std::integral_constant<int, 2> ActMax;
+    typedef std::integral_constant<int, 3> ActRuntime;
     // ---- epilogue.  Lane (r, g) holds rows 4g..4g+3 of every 16-row n-tile = channels cb(g)..cb(g)+3 with cb = {0, 8, 4, 12}:
     // the weight rows were permuted that way on their way into LDS (wlane), so that lanes g and g + 2 -- the two halves of the
     // wave, which v_permlane32_swap exchanges -- hold the two halves of one 8-channel group.
@@ -521,23 +563,22 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
         orow[i] = out_f32 ? out_f32 + prow_o[i] * a.out_ld : nullptr;
     }
     f32x4 vv[2][WN];
+    auto fold = [&](auto mode) {
 #pragma unroll
-    for (int j = 0; j < WN; ++j) {
-        const int cl = 16 * j + cb;
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(cst + cl);
-        const f32x4 pv = *reinterpret_cast<const f32x4*>(cst + BN + cl);
+        for (int j = 0; j < WN; ++j) {
+            const int cl = 16 * j + cb;
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(cst + cl);
+            const f32x4 pv = *reinterpret_cast<const f32x4*>(cst + BN + cl);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            f32x4 v = acc[i][j] + cor[i][j] * LO_UNSCALE + bv;
-            if (a.prelu) {                 // (uniform: the epilogue is VALU-bound, ~45 instructions per 4 values with both activations)
-                v.x = v.x > 0.f ? v.x : pv.x * v.x;
-                v.y = v.y > 0.f ? v.y : pv.y * v.y;
-                v.z = v.z > 0.f ? v.z : pv.z * v.z;
-                v.w = v.w > 0.f ? v.w : pv.w * v.w;
-            }
-            vv[i][j] = v;
+            for (int i = 0; i < 2; ++i) vv[i][j] = prelu4(mode, acc[i][j] + cor[i][j] * LO_UNSCALE + bv, pv, a.prelu != nullptr);
         }
-    }
+    };
+    // (the 8-n-tile instance has no register to spare for copies of a stage -- it spills 32-37 -- and its layers have the longest K: it
+    // keeps one copy with the select form under a uniform flag)
+    if constexpr (!MAXFORM) fold(ActRuntime{});
+    else if (!a.prelu) fold(ActNone{});
+    else if (pmax) fold(ActMax{});
+    else fold(ActSelect{});
     if constexpr (WN == 2 || WN == 4) {
         if (a.h2_w) {
             constexpr int KK = WN / 2;
@@ -615,25 +656,25 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
     // 16j + 8g .. of n-tile j and the upper half-wave those of n-tile j+1 (T21 of the programming guide), so ONE 16-byte
     // store per lane and plane writes 16 pixels x 32 channels x 2 bytes = one contiguous KiB of the chunk-major plane.
     // Channels past Cout inside the last group of 8 are zero (zero weight rows, zero bias); groups beyond are not stored.
-    auto plane_sink = [&](_Float16* phi, _Float16* plo, long long prows, int pc0, const bool pslope) {
+    auto plane_sink = [&](_Float16* phi, _Float16* plo, long long prows, int pc0, auto mode) {
+        constexpr bool pslope = decltype(mode)::value != 0;
+        const bool slope_on = a.plane_prelu != nullptr;
         const int climit = (a.Cout + 7) & ~7;
         constexpr int NP = (WN + 1) / 2;
 #pragma unroll
         for (int jp = 0; jp < NP; ++jp) {
             const int j0 = 2 * jp, j1 = (2 * jp + 1 < WN) ? 2 * jp + 1 : 2 * jp;
             f32x4 s0 = (f32x4){1.f, 1.f, 1.f, 1.f}, s1 = s0;
-            if (pslope) {               // the sink's own slopes: third row of the tile's constants (no global load between the stores)
+            if constexpr (pslope) {     // the sink's own slopes: third row of the tile's constants (no global load between the stores)
                 s0 = *reinterpret_cast<const f32x4*>(cst + 2 * BN + 16 * j0 + cb);
                 s1 = *reinterpret_cast<const f32x4*>(cst + 2 * BN + 16 * j1 + cb);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 f32x4 u0 = vv[i][j0], u1 = vv[i][j1];
-                if (pslope) {
-                    u0.x = u0.x > 0.f ? u0.x : s0.x * u0.x;  u0.y = u0.y > 0.f ? u0.y : s0.y * u0.y;
-                    u0.z = u0.z > 0.f ? u0.z : s0.z * u0.z;  u0.w = u0.w > 0.f ? u0.w : s0.w * u0.w;
-                    u1.x = u1.x > 0.f ? u1.x : s1.x * u1.x;  u1.y = u1.y > 0.f ? u1.y : s1.y * u1.y;
-                    u1.z = u1.z > 0.f ? u1.z : s1.z * u1.z;  u1.w = u1.w > 0.f ? u1.w : s1.w * u1.w;
+                if constexpr (pslope) {
+                    u0 = prelu4(mode, u0, s0, slope_on);
+                    u1 = prelu4(mode, u1, s1, slope_on);
                 }
                 f16x2 h00, l00, h01, l01, h10, l10, h11, l11;
                 split_pair((f32x2){u0.x, u0.y}, h00, l00);
@@ -661,8 +702,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
             }
         }
     };
-    if (a.out_hi) plane_sink(a.out_hi, a.out_lo, a.plane_rows, a.out_c0, a.plane_prelu != nullptr);
-    if (a.out_hi2) plane_sink(a.out_hi2, a.out_lo2, a.plane_rows2, a.out_c02, false);
+    if (a.out_hi) {
+        if constexpr (!MAXFORM) plane_sink(a.out_hi, a.out_lo, a.plane_rows, a.out_c0, ActRuntime{});
+        else if (!a.plane_prelu) plane_sink(a.out_hi, a.out_lo, a.plane_rows, a.out_c0, ActNone{});
+        else if (pmax) plane_sink(a.out_hi, a.out_lo, a.plane_rows, a.out_c0, ActMax{});
+        else plane_sink(a.out_hi, a.out_lo, a.plane_rows, a.out_c0, ActSelect{});
+    }
+    if (a.out_hi2) plane_sink(a.out_hi2, a.out_lo2, a.plane_rows2, a.out_c02, ActNone{});
 #ifdef ATMVFI_STAMP
         if (a.stamp) {
             __builtin_amdgcn_sched_barrier(0);
