@@ -169,46 +169,65 @@ __global__ __launch_bounds__(256) void dwconv_gelu_rows_kernel(const float* __re
     const bool xm_ok = x > 0, xp_ok = x + 1 < W;
     const float* base = in + ((long long)n * H * W + x) * in_ld + c;
     const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 win[3][3];        // [row slot][x-1, x, x+1]
-    auto load_row = [&](int y, f32x4 (&dst)[3]) {
-        const bool ok = (unsigned)y < (unsigned)H;
-        const float* p = base + (long long)(ok ? y : 0) * W * in_ld;       // clamped: always a valid address
-        const f32x4 a = *reinterpret_cast<const f32x4*>(p - (xm_ok ? in_ld : 0));
-        const f32x4 b = *reinterpret_cast<const f32x4*>(p);
-        const f32x4 d = *reinterpret_cast<const f32x4*>(p + (xp_ok ? in_ld : 0));
-        dst[0] = (ok && xm_ok) ? a : zero;
-        dst[1] = ok ? b : zero;
-        dst[2] = (ok && xp_ok) ? d : zero;
-    };
-    load_row(y0 - 1, win[0]);
-    load_row(y0, win[1]);
+    // Borders: a column outside the image gets ZERO WEIGHTS (its loads are clamped to a valid address, and finite x * 0 adds exactly
+    // nothing), a row outside the image is a block-uniform case and becomes zeros without a load -- so a loaded value is first touched by
+    // the FMAs, and row y + 2 can be requested one iteration ahead: the wait for it then sits behind a whole row of arithmetic and behind
+    // this row's stores in program order (vmcnt retires in order: waiting for a load issued AFTER the previous row's stores also waited
+    // for those stores to be acknowledged -- once per row, with the load latency on top).
 #pragma unroll
-    for (int r = 0; r < RS; ++r) {
-        const int y = y0 + r;
-        load_row(y + 1, win[(r + 2) % 3]);
-        if (y < H) {
-            // explicit packed fused multiply-adds (v_pk_fma_f32: 18 instructions per 4-channel output instead of 36 mul + 36 add
-            // under -ffp-contract=off; always fused, so the result does not depend on how the loop is peeled)
-            f32x2 a01 = bv.xy, a23 = bv.zw;
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const f32x4* row = win[(r + ky) % 3];
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const f32x4 v = row[kx], wt = wv[ky * 3 + kx];
-                    a01 = __builtin_elementwise_fma(v.xy, wt.xy, a01);
-                    a23 = __builtin_elementwise_fma(v.zw, wt.zw, a23);
-                }
-            }
-            const f32x4 acc = {a01.x, a01.y, a23.x, a23.y};
-            f32x4 o;
-            o.x = gelu_erf2(acc.x);
-            o.y = gelu_erf2(acc.y);
-            o.z = gelu_erf2(acc.z);
-            o.w = gelu_erf2(acc.w);
-            sink_store4(out, ((long long)n * H + y) * W + x, c, o);
-        }
+    for (int ky = 0; ky < 3; ++ky) {
+        if (!xm_ok) wv[ky * 3 + 0] = zero;
+        if (!xp_ok) wv[ky * 3 + 2] = zero;
     }
+    // A strip whose RS + 2 input rows all lie inside the image (all but the first and the last strip of a map) runs without any row test:
+    // straight-line code, so that hipcc's waits are counted ones (at a control-flow join it waits for vmcnt(0)).
+    auto run = [&](auto interior_tag) {
+        constexpr bool INTERIOR = decltype(interior_tag)::value;
+        f32x4 win[4][3];        // [row slot][x-1, x, x+1]
+        const long long xm = xm_ok ? in_ld : 0, xp = xp_ok ? in_ld : 0;
+        auto load_row = [&](int y, f32x4 (&dst)[3]) {
+            if (INTERIOR || (unsigned)y < (unsigned)H) {                        // (uniform over the block)
+                const float* p = base + (long long)y * W * in_ld;
+                dst[0] = *reinterpret_cast<const f32x4*>(p - xm);
+                dst[1] = *reinterpret_cast<const f32x4*>(p);
+                dst[2] = *reinterpret_cast<const f32x4*>(p + xp);
+            } else {
+                dst[0] = zero; dst[1] = zero; dst[2] = zero;
+            }
+        };
+        load_row(y0 - 1, win[0]);
+        load_row(y0, win[1]);
+        load_row(y0 + 1, win[2]);
+#pragma unroll
+        for (int r = 0; r < RS; ++r) {
+            const int y = y0 + r;
+            if (r + 1 < RS) load_row(y + 2, win[(r + 3) % 4]);
+            if (INTERIOR || y < H) {
+                // explicit packed fused multiply-adds (v_pk_fma_f32: 18 instructions per 4-channel output instead of 36 mul + 36 add
+                // under -ffp-contract=off; always fused, so the result does not depend on how the loop is peeled)
+                f32x2 a01 = bv.xy, a23 = bv.zw;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const f32x4* row = win[(r + ky) % 4];
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const f32x4 v = row[kx], wt = wv[ky * 3 + kx];
+                        a01 = __builtin_elementwise_fma(v.xy, wt.xy, a01);
+                        a23 = __builtin_elementwise_fma(v.zw, wt.zw, a23);
+                    }
+                }
+                const f32x4 acc = {a01.x, a01.y, a23.x, a23.y};
+                f32x4 o;
+                o.x = gelu_erf2(acc.x);
+                o.y = gelu_erf2(acc.y);
+                o.z = gelu_erf2(acc.z);
+                o.w = gelu_erf2(acc.w);
+                sink_store4(out, ((long long)n * H + y) * W + x, c, o);
+            }
+        }
+    };
+    if (y0 >= 1 && y0 + RS + 1 <= H) run(std::true_type{});
+    else run(std::false_type{});
 }
 
 __global__ void pack_dw_kernel(const float* __restrict__ src, float* __restrict__ dst, int C) {
