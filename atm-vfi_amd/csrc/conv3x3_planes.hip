@@ -465,6 +465,22 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
         halo_advance();
     };
 
+    // fused read-out: the lane's fragments of W2 stay in registers for all of the workgroup's tiles (loaded in every tile's epilogue they
+    // cost a round trip to L2 per tile with nothing to hide it; the 2- and 4-n-tile instances have 80+ registers to spare)
+    constexpr int KK2 = (WN == 2 || WN == 4) ? WN / 2 : 1;
+    f16x8 w2h[2][KK2], w2l[2][KK2];
+    if constexpr (WN == 2 || WN == 4) {
+        if (a.h2_w) {
+            const f16x8* wp = reinterpret_cast<const f16x8*>(a.h2_w);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int kk = 0; kk < KK2; ++kk) {
+                    w2h[t][kk] = wp[(t * KK2 + kk) * 64 + lane];
+                    w2l[t][kk] = wp[((2 + t) * KK2 + kk) * 64 + lane];
+                }
+        }
+    }
     for (;;) {
         const float* cst = cst_base + (seq & 1) * CSTF;
 #pragma unroll
@@ -582,15 +598,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
     if constexpr (WN == 2 || WN == 4) {
         if (a.h2_w) {
             constexpr int KK = WN / 2;
-            const f16x8* wp = reinterpret_cast<const f16x8*>(a.h2_w);
-            f16x8 w2h[2][KK], w2l[2][KK];
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int kk = 0; kk < KK; ++kk) {
-                    w2h[t][kk] = wp[(t * KK + kk) * 64 + lane];
-                    w2l[t][kk] = wp[((2 + t) * KK + kk) * 64 + lane];
-                }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 f32x4 a2[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
