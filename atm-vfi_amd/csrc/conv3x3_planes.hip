@@ -79,6 +79,10 @@ struct Conv3PDev {
     int out_cmin;               // fp32 output: only channels >= out_cmin (multiple of 4) are stored
     int tiles_x, tiles_y, nblocks, tchunk;
     int vblocks;                // virtual blocks (tiles incl. XCD padding) walked by the persistent grid
+    // the tile decode's divisors as multiply-shift pairs (launch_planes: q = (mul_hi(n, m) + n) >> s, exact for n < 2^31): dividing by a
+    // kernel argument costs ~18 scalar instructions, and the decode of a workgroup's next-but-one tile -- five divisions -- sits on the
+    // critical path of every tile boundary (1.3-1.5 k cycles per tile, tools/stamp_conv3p.py)
+    unsigned dm_nblocks, ds_nblocks, dm_perimg, ds_perimg, dm_grp, ds_grp, dm_rows, ds_rows;
     // split-K (under-filled grids with long K, round 4): gridDim.y = ksplit workgroups per tile; split s takes the cps full chunks from
     // chunk s * cps on (the last one the rest and the tap-packed tail) and stores its raw fp32 sums at out + s * part_stride; a second
     // kernel adds the partial sums in split order and runs the epilogue.  1 = off.
@@ -187,27 +191,29 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
     // tile's last k-steps.
     const int grid = gridDim.x;
     const int per_img = a.tiles_x * a.tiles_y;
+    auto fdiv = [](int n, unsigned m, unsigned sh) -> int { return (int)((__umulhi((unsigned)n, m) + (unsigned)n) >> sh); };
     auto decode = [&](int v, int& t_img, int& t_ox0, int& t_oy0, int& t_n0) -> bool {
         int sgrp, nblk, L;
         if (a.ksplit > 1) {
             // split-K launches have fewer tiles than CUs: plain order (tile = v / nblocks), so that the workgroups -- dealt round-robin
             // over the XCDs -- spread over the whole chip instead of filling the first eighths of the XCD-aware order
-            sgrp = v / a.nblocks;
+            sgrp = fdiv(v, a.dm_nblocks, a.ds_nblocks);
             nblk = v - sgrp * a.nblocks;
             L = sgrp;
         } else {
             const int slot = v >> 3;
-            sgrp = slot / a.nblocks;
+            sgrp = fdiv(slot, a.dm_nblocks, a.ds_nblocks);
             nblk = slot - sgrp * a.nblocks;
             L = (v & 7) * a.tchunk + sgrp;
         }
         if (v >= a.vblocks || L >= a.N * per_img) return false;
-        t_img = L / per_img;
+        t_img = fdiv(L, a.dm_perimg, a.ds_perimg);
         L -= t_img * per_img;
-        const int tgrp = L / (8 * a.tiles_x);
+        const int tgrp = fdiv(L, a.dm_grp, a.ds_grp);              // groups of 8 tile rows
         const int rem = L - tgrp * 8 * a.tiles_x;
-        const int rows_here = (a.tiles_y - 8 * tgrp) < 8 ? a.tiles_y - 8 * tgrp : 8;
-        const int txb = rem / rows_here;
+        const bool full = a.tiles_y - 8 * tgrp >= 8;
+        const int rows_here = full ? 8 : a.tiles_y - 8 * tgrp;     // (the last group of a map may be shorter: tiles_y mod 8 rows)
+        const int txb = full ? rem >> 3 : fdiv(rem, a.dm_rows, a.ds_rows);
         const int tyb = 8 * tgrp + (rem - txb * rows_here);
         t_ox0 = txb * TW;
         t_oy0 = tyb * 16;
@@ -772,6 +778,16 @@ int launch_planes(const Conv3PDev& d, int ntiles, hipStream_t s) {
     ds.dbg = 0;
 #endif
     ATMVFI_REQUIRE(sgroups * 8 * ds.nblocks < (1LL << 31), ATMVFI_EINVAL, "conv3x3_planes: grid too large");
+    // q = (mul_hi(n, m) + n) >> s with s = ceil(log2 d), m = ceil(2^(32 + s) / d) - 2^32: exact for every n < 2^31 and d >= 1
+    auto magic = [](int d, unsigned& m, unsigned& sh) {
+        sh = 0;
+        while ((1ll << sh) < d) ++sh;
+        m = (unsigned)((((unsigned long long)1 << (32 + sh)) + (unsigned)d - 1) / (unsigned)d - ((unsigned long long)1 << 32));
+    };
+    magic(ds.nblocks, ds.dm_nblocks, ds.ds_nblocks);
+    magic(d.tiles_x * ds.tiles_y, ds.dm_perimg, ds.ds_perimg);
+    magic(8 * d.tiles_x, ds.dm_grp, ds.ds_grp);
+    magic((ds.tiles_y & 7) ? (ds.tiles_y & 7) : 8, ds.dm_rows, ds.ds_rows);
     ds.vblocks = d.ksplit > 1 ? (int)((long long)d.N * d.tiles_x * ds.tiles_y * ds.nblocks) : (int)(sgroups * 8 * ds.nblocks);
     // persistent (one workgroup per CU walking its XCD's tiles, DMA streams flowing across tiles) whenever a tile has at least two
     // 32-channel chunks -- the halo stream moves on to the next tile while the last chunk is consumed; else one workgroup per tile

@@ -796,6 +796,46 @@ def test_conv3x3_planes_every_width(wn, hip, cpu, dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("wn", [2, 4, 7, 8])
+def test_conv3x3_planes_prelu_forms(wn, hip, dev):
+    """The plane kernel applies PReLU as max(v, s v) when every slope of a tile's columns lies in [0, 1] and as the select otherwise,
+    decided per tile from the tile's constants in LDS (the 8-n-tile instance always selects).  Slopes in range, slopes with negative /
+    > 1 entries in ONE of two column blocks only (the two blocks of a pixel tile then take different forms), the same for the plane
+    sink's own slopes, and signed zeros / huge values in the data: always bit-identical to the fp32-input kernel (select form) and to
+    split_planes(prelu) of its result."""
+    g = torch.Generator().manual_seed(7300 + wn)
+    r4 = lambda c: (c + 3) // 4 * 4
+    N, H, W, cin = 1, 40, 52, 40
+    cout = 2 * 16 * wn - 3
+    x = rnd(g, N, H, W, r4(cin), scale=1.5).to(dev)
+    x[0, 3, 5, :cin] = 0.0
+    x[0, 7, 9, :cin] = 3.0e4
+    wt = rnd(g, cout, cin, 3, 3, scale=1.0 / np.sqrt(9 * cin)).to(dev)
+    bias = rnd(g, cout, scale=0.2).to(dev)
+    bias[::5] = 0.0                                            # exact zeros (and -0 * slope) at the all-zero pixel
+    pw = hip.pack_weight(GEMM_CONV, wt)
+    xp = hip_ops.Planes.alloc(N * H * W, cin, dev)
+    hip.split_planes(x[..., :cin].flatten(0, 2), xp)
+    base = torch.rand(cout, generator=g)
+    for name, edit in (("in range", lambda t: t), ("edges 0 and 1", lambda t: torch.where(torch.arange(cout) % 2 == 0, torch.zeros(()), torch.ones(()))),
+                       ("second block out of range", lambda t: torch.cat([t[:16 * wn], t[16 * wn:] * 3.0 - 1.0])),
+                       ("first block out of range", lambda t: torch.cat([-t[:16 * wn], t[16 * wn:]]))):
+        slope = edit(base.clone()).to(dev).contiguous()
+        pslope = torch.zeros((cout + 31) // 32 * 32, device=dev)
+        pslope[:cout] = edit(torch.rand(cout, generator=g)).to(dev)
+        y0 = torch.full((N, H, W, r4(cout)), 7.0, device=dev)
+        hip.conv(x[..., :cin], pw, y0[..., :cout], 1, 1, 1, bias, slope)
+        y1 = torch.full((N, H, W, r4(cout)), 7.0, device=dev)
+        s1 = hip_ops.Planes.alloc(N * H * W, cout, dev)
+        hip.conv3x3_planes(xp, N, H, W, pw, out=y1[..., :cout], bias=bias, prelu=slope, planes=s1, planes_prelu=pslope, wn=wn)
+        qp = hip_ops.Planes.alloc(N * H * W, cout, dev)
+        hip.split_planes(y0[..., :cout].flatten(0, 2), qp, prelu=pslope[:cout].contiguous())
+        torch.cuda.synchronize()
+        assert torch.equal(y0.view(torch.int32), y1.view(torch.int32)), (wn, name, maxdiff(y0, y1))
+        assert torch.equal(s1.t.view(torch.int16), qp.t.view(torch.int16)), (wn, name)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", [(1, 16, 16, 712, 352, 0), (1, 32, 32, 456, 224, 0), (1, 36, 60, 1352, 768, 0), (2, 21, 35, 520, 61, 0),
                                   (1, 32, 32, 456, 224, 4), (1, 20, 28, 392, 101, 0)],
                          ids=lambda c: f"n{c[0]}_{c[1]}x{c[2]}_cin{c[3]}_cout{c[4]}_wn{c[5]}")
