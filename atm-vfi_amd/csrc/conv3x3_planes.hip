@@ -95,6 +95,7 @@ struct Conv3PDev {
     const _Float16* h2_w;       // [plane hi / lo][row tile 2][k-step WN/2][lane 64][8 halves], k order = this kernel's register order
     float* h2_out;
     long long h2_plane;
+    int defer;                  // 1: multi-tile launches may take conv3x3_planes_de_kernel (wn without bit 4, include/atmvfi.h)
     unsigned long long* stamp;  // diagnostic builds only (ATMVFI_STAMP)
     int dbg;                    // diagnostic builds only: ATMVFI_P3_DBG bits switch pieces of the loop off (wrong results, timing only)
 };
@@ -432,7 +433,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
             constexpr int lo = T + 1 - LA > 0 ? T + 1 - LA : 0;
             constexpr int hi = T < 5 ? T : 5;
             constexpr int halos = !TAIL ? (hi >= lo ? hi - lo + 1 : 0) : (lo <= 0 ? 3 : 0) + ((lo <= 1 && T >= 1) ? 3 : 0);
-            if (!PDBG(4)) wait_vm<(LA - 1) * SW + halos>();
+            // (tap 8: the next chunk's halo has to be complete -- its tap-5 piece, which the window formula still counts as "behind" with
+            // a lookahead of 4 k-steps, must not stay in flight over the chunk boundary: three k-steps old by then, it never showed)
+            if (!PDBG(4)) wait_vm<(!TAIL && T == 8) ? (LA - 1) * SW : (LA - 1) * SW + halos>();
         }
         PSTAMP(3)
         asm volatile("s_waitcnt lgkmcnt(0)"
@@ -756,6 +759,549 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// DEFERRED-EPILOGUE variant (round 4).  conv3x3_planes_kernel stops the matrix pipes at every tile boundary: both wave groups run their
+// epilogues -- VALU-bound, 4.7 k + 7.3 k cycles of a 55 k-cycle 112-column tile with a plane sink (tools/stamp_conv3p.py) -- and nothing
+// else can run, because all 256 registers of a wave hold the two accumulator sets of the f16x3 arithmetic (acc: hi x hi, cor: the two
+// cross products, folded as acc + cor / 1024).  Here the three products of a k-step go into ONE fp32 accumulator: the activation
+// fragments of the cross products are scaled by 2^-10 in registers first (hi for the weights' lo' x hi product, lo' for hi x lo':
+// 16 v_pk_mul_f16 per k-step; the results are fp16 subnormals for |x| < 2^-4, which gfx950's matrix cores keep:
+// tools/probes/mfma_denorm_probe.hip; tools/sim_single_acc.py: as exact as the two-accumulator fold for activations of ordinary size,
+// 5e-8 absolute for |x| ~ 1e-3).  The freed registers hold the PREVIOUS tile's sums, and that tile's epilogue runs unit by unit
+// (n-tile pair x pixel row: ~130 VALU instructions, 10 stores) inside the MFMA phases of the current tile's first eight k-steps,
+// interleaved with the MFMAs by sched_group_barrier -- the matrix pipe accepts an instruction every 16 cycles, the VALU is idle during
+// an MFMA phase (the SIMD partner is in its read phase).  The k-loop then runs from tile to tile without a boundary: no extra barrier,
+// no wait; every store instruction is issued unconditionally (absent outputs and dead lanes through EXEC = 0), so the counted vmcnt
+// waits stay immediates.  Not bit-identical to conv3x3_planes_kernel (fp32 summation of the three products), same tolerance class.
+// Launcher: 1-7 n-tiles, at least one full chunk, no split-K, no fused read-out (those stay on conv3x3_planes_kernel).
+template <int WN>
+__global__ __launch_bounds__(512, 1) void conv3x3_planes_de_kernel(const Conv3PDev a) {
+    fp16_saturate_on();
+    constexpr int BN = 16 * WN;
+    constexpr int WSLOT = 2 * BN * 64;                  // bytes of one ring slot: [hi BN rows][lo BN rows] x 64 B
+    constexpr int SW = (2 * WN + 7) / 8;                // weight pieces per wave and k-step (some waves one fewer)
+    constexpr int NB = ring_slots(WN);                  // weight ring slots (k-steps)
+    constexpr int LA = NB - 1;                          // k-steps between a slot's DMA issue and its first read
+    constexpr int CSTF = planes_const_floats(BN);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned halo0 = lds_offset(smem);                        // two halo buffers
+    const unsigned ring0 = halo0 + 2 * HALO_BYTES;                  // NB weight slots
+    float* cst_base = reinterpret_cast<float*>(smem + 2 * HALO_BYTES + NB * WSLOT);     // two buffers of epilogue constants
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
+    const int r = lane & 15;
+    const int g = lane >> 4;
+
+    // (no split-K in this variant: the launcher keeps split launches on conv3x3_planes_kernel)
+    const _Float16* in_hi = a.in_hi;
+    const _Float16* in_lo = a.in_lo;
+    const _Float16* w_hi = a.w_hi;
+    const _Float16* w_lo = a.w_lo;
+    float* out_f32 = a.out;
+    const int nfull = a.cf >> 5;          // >= 1 (launcher)
+    const int ktail = a.tail;
+    // PERSISTENT GRID over the XCD-aware tile order (conv3x3_f16x3_row.hip): virtual block v -> column blocks of one tile back to
+    // back on one XCD, each XCD walking a contiguous eighth of the tiles in groups of 8 tile rows, column by column.  Workgroup b
+    // walks v = b, b + grid, ... (grid a multiple of 8: it stays on its XCD; the tile index only grows along the walk, so the first
+    // empty block ends it).  The DMA streams keep flowing across tiles: the slots that re-sent the last weights / the current halo
+    // "into buffers nobody reads" at the end of a tile now carry the NEXT tile's first k-steps and its first halo, so a tile's
+    // prologue (first DMA round trip + address arithmetic, 6.5 % of a 101-wide full-resolution tile) runs under the previous
+    // tile's last k-steps.
+    const int grid = gridDim.x;
+    const int per_img = a.tiles_x * a.tiles_y;
+    auto fdiv = [](int n, unsigned m, unsigned sh) -> int { return (int)((__umulhi((unsigned)n, m) + (unsigned)n) >> sh); };
+    auto decode = [&](int v, int& t_img, int& t_ox0, int& t_oy0, int& t_n0) -> bool {
+        int sgrp, nblk, L;
+        if (a.ksplit > 1) {
+            // split-K launches have fewer tiles than CUs: plain order (tile = v / nblocks), so that the workgroups -- dealt round-robin
+            // over the XCDs -- spread over the whole chip instead of filling the first eighths of the XCD-aware order
+            sgrp = fdiv(v, a.dm_nblocks, a.ds_nblocks);
+            nblk = v - sgrp * a.nblocks;
+            L = sgrp;
+        } else {
+            const int slot = v >> 3;
+            sgrp = fdiv(slot, a.dm_nblocks, a.ds_nblocks);
+            nblk = slot - sgrp * a.nblocks;
+            L = (v & 7) * a.tchunk + sgrp;
+        }
+        if (v >= a.vblocks || L >= a.N * per_img) return false;
+        t_img = fdiv(L, a.dm_perimg, a.ds_perimg);
+        L -= t_img * per_img;
+        const int tgrp = fdiv(L, a.dm_grp, a.ds_grp);              // groups of 8 tile rows
+        const int rem = L - tgrp * 8 * a.tiles_x;
+        const bool full = a.tiles_y - 8 * tgrp >= 8;
+        const int rows_here = full ? 8 : a.tiles_y - 8 * tgrp;     // (the last group of a map may be shorter: tiles_y mod 8 rows)
+        const int txb = full ? rem >> 3 : fdiv(rem, a.dm_rows, a.ds_rows);
+        const int tyb = 8 * tgrp + (rem - txb * rows_here);
+        t_ox0 = txb * TW;
+        t_oy0 = tyb * 16;
+        t_n0 = nblk * BN;
+        return true;
+    };
+    int vb = blockIdx.x;
+    int img, ox0, oy0, n0;                       // the tile of the MFMAs / of the epilogue
+    if (!decode(vb, img, ox0, oy0, n0)) return;
+    int nimg = 0, nox0 = 0, noy0 = 0, nn0 = 0;   // this workgroup's next tile
+    bool has_next = decode(vb + grid, nimg, nox0, noy0, nn0);
+
+    // ---- halo pieces of this wave: k = wave + 8 s, s = 0..5 (k < 42): pieces 0..20 = hi plane, 21..41 = lo plane, each plane
+    // a linear image of 336 pixel rows x 64 B (324 used).  Lane -> pixel row hp = 16 (k % 21) + lane / 4, physical 16-byte slot
+    // lane & 3; the slot swizzle goes on the SOURCE (the DMA destination is lane-linear).  hoff = byte offset from the plane base
+    // of the chunk; pixels outside the image (and the 12 pad rows) read the planes' zero row N*H*W.  hoff belongs to the tile
+    // whose halo is being put in flight: the tile of the MFMAs or, towards its end, the next one.
+    unsigned hoff[6];
+    const long long zero_row = (long long)a.N * a.H * a.W;
+    auto setup_halo = [&](int t_img, int t_ox0, int t_oy0) {
+        // (the lane index laundered through an empty asm: the per-lane halo coordinates of the six pieces are tile-invariant, and
+        // hipcc otherwise hoists them out of the tile loop -- 30 more live registers across the k-loop, spills at 8 n-tiles)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            int k = wave + 8 * s;
+            if (k >= 2 * HALO_PLANE_PIECES) k -= 8;      // waves 2..7 have no sixth piece: they send their fifth twice (see below)
+            const int kp = k >= HALO_PLANE_PIECES ? k - HALO_PLANE_PIECES : k;
+            const int hp = 16 * kp + (ln >> 2);
+            const int hy = hp / HW_, hx = hp - hy * HW_;
+            const int iy = t_oy0 - 1 + hy, ix = t_ox0 - 1 + hx;
+            const bool ok = hp < HALO_PIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const int ls = (ln & 3) ^ swz64(hp);
+            const long long row = ok ? ((long long)t_img * a.H + iy) * a.W + ix : zero_row;
+            hoff[s] = (unsigned)(row * 64 + ls * 16);
+        }
+    };
+    setup_halo(img, ox0, oy0);
+    const long long chunk_bytes = a.in_rows * 64;
+    // ---- DMA schedule.  Everything in the k-loop is branch-free and the same for every wave, so that the vmcnt waits are plain
+    // immediates: a taken scalar branch costs 20-40 cycles and the first version of this loop had ten per read phase (validity
+    // of a piece, end of the k-steps, a decision tree around s_waitcnt: 230 ticks of a 900-tick phase, tools/stamp_conv3p.py).
+    //   * weights: SW pieces per wave and k-step; piece idx = wave + 8 s -> plane idx / WN, row group idx % WN (16 rows x 64 B =
+    //     one contiguous KiB of the k-step-major planes).  A wave without a piece s (idx >= 2 WN) sends its piece s - 1 again:
+    //     same bytes to the same place.  Behind a tile's last k-step come the first k-steps of the workgroup's next tile (or,
+    //     after the last tile, the last k-step again into ring slots nobody reads any more).
+    //   * halo of the next chunk: piece wave + 8 t in k-step t = 0..5 (tail k-steps 0 and 1: three pieces each); behind a tile's
+    //     last chunk comes chunk 0 of the next tile (after the last tile: the current chunk again into the idle buffer).
+    // LDS row i of a 16-row group <- weight row 8 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3): rows 4g..4g+3 of the MFMA result are
+    // then channels {0, 8, 4, 12}[g] .. + 3 (see the epilogue)
+    const int wrow = 8 * ((lane >> 4) & 1) + 4 * (lane >> 5) + ((lane >> 2) & 3);
+    const unsigned wlane = (unsigned)(wrow * 64 + (((lane & 3) ^ swz64(lane >> 2)) << 4));
+    const long long step_bytes = (long long)a.wrows * 64;
+    const unsigned char* wsrc[SW];          // wave-uniform source of piece s at the next k-step to issue
+    const unsigned char* wnext[SW];         // the same at k-step 0 of the workgroup's next tile
+    int wdst[SW];                           // its byte offset inside a ring slot
+    auto weight_base = [&](int s, int t_n0) -> const unsigned char* {
+        int idx = wave + 8 * s;
+        if (idx >= 2 * WN) idx -= 8;
+        const int ic = idx >= 0 ? idx : 0;                       // (WN < 4: waves >= 2 WN have no piece at all and send piece 0)
+        const int icc = ic < 2 * WN ? ic : 0;
+        const int plane = icc >= WN ? 1 : 0;
+        const int j = icc - plane * WN;
+        int rg = t_n0 + 16 * j;
+        if (rg >= a.wrows) rg = a.wrows - 16;                    // row groups past the packed rows: columns never stored
+        return reinterpret_cast<const unsigned char*>(plane ? w_lo : w_hi) + (long long)rg * 64;
+    };
+#pragma unroll
+    for (int s = 0; s < SW; ++s) {
+        int idx = wave + 8 * s;
+        if (idx >= 2 * WN) idx -= 8;
+        const int ic = idx >= 0 ? idx : 0;
+        const int icc = ic < 2 * WN ? ic : 0;
+        const int plane = icc >= WN ? 1 : 0;
+        const int j = icc - plane * WN;
+        wsrc[s] = weight_base(s, n0);
+        wnext[s] = weight_base(s, nn0);
+        wdst[s] = (plane * BN + 16 * j) * 64;
+    }
+
+    const int nchunks = nfull + (ktail ? 1 : 0);
+    const int nk = 9 * nfull + (ktail ? 3 : 0);
+
+    int wr_off = 0;                       // ring slot (byte offset) the next weight issue goes to
+    int kleft = nk - 1;                   // k-steps of the issuer's tile after the one whose weights are issued next
+    auto issue_weights = [&]() {          // weights of the next k-step -> next ring slot
+        unsigned char* dst = smem + 2 * HALO_BYTES + wr_off;
+        const bool more = kleft > 0;
+#pragma unroll
+        for (int s = 0; s < SW; ++s) {
+            dma16(wsrc[s] + wlane, dst + wdst[s]);
+            wsrc[s] = more ? wsrc[s] + step_bytes : (has_next ? wnext[s] : wsrc[s]);       // (scalar selects: no branch)
+        }
+        kleft = more ? kleft - 1 : (has_next ? nk - 1 : 0);
+        wr_off = wr_off + WSLOT == NB * WSLOT ? 0 : wr_off + WSLOT;
+    };
+    const unsigned char* hsrc_hi = reinterpret_cast<const unsigned char*>(in_hi);      // plane bases of the chunk whose halo is issued next
+    const unsigned char* hsrc_lo = reinterpret_cast<const unsigned char*>(in_lo);
+    int hbuf = 0;                         // halo buffer (byte offset) that chunk goes to
+    auto issue_halo = [&](auto sc) {      // halo piece wave + 8 S (waves 2..7, S = 5: piece wave + 32 again)
+        constexpr int S = decltype(sc)::value;
+        int k = wave + 8 * S;
+        if (S == 5 && k >= 2 * HALO_PLANE_PIECES) k -= 8;
+        dma16((k >= HALO_PLANE_PIECES ? hsrc_lo : hsrc_hi) + hoff[S], smem + hbuf + k * 1024);
+    };
+    int chunks_left = nchunks - 1;        // chunks of the issuer's tile after the one whose halo is issued next
+    // all six pieces of a chunk are out: on to the tile's next chunk, to chunk 0 of the next tile, or (after the last tile) nowhere
+    auto halo_advance = [&]() {
+        if (chunks_left > 0) {
+            hsrc_hi += chunk_bytes;
+            hsrc_lo += chunk_bytes;
+            --chunks_left;
+        } else if (has_next) {
+            hsrc_hi = reinterpret_cast<const unsigned char*>(in_hi);
+            hsrc_lo = reinterpret_cast<const unsigned char*>(in_lo);
+            setup_halo(nimg, nox0, noy0);
+            chunks_left = nchunks - 1;
+        }
+        hbuf = HALO_BYTES - hbuf;
+    };
+
+    f32x4 acc[2][WN], pend[2][WN];
+
+    // tail k-steps: lane group g reads slot 0 of the halo pixel of tap 4t + g (taps 9..11 meet zero weights: tap 8 again)
+    int dtail = 0;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int tap = (4 * t + g) < 9 ? 4 * t + g : 8;
+        const int ty = tap / 3;
+        dtail |= (ty * HW_ + (tap - 3 * ty)) << (8 * t);
+    }
+
+    // ---- prologue: halo of chunk 0, weights of k-steps 0 .. LA-1 (the first tile's epilogue constants go out at the top of the tile loop,
+    // like every tile's: the counted waits of a tile's first k-steps count that piece) ----
+    static_for<0, 6>([&](auto sc) { issue_halo(sc); });
+    halo_advance();
+#pragma unroll
+    for (int u = 0; u < LA; ++u) issue_weights();
+    wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();          // the second group runs one phase behind
+
+    f16x8 xh[2], xl[2], wh[WN], wl[WN];
+    const unsigned wfrag = ring0 + (unsigned)(r * 64 + ((g ^ swz64(r)) << 4));
+    const int prow = 2 * wave * HW_ + r;
+    unsigned xa[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) xa[k] = halo0 + (unsigned)(prow * 64 + ((g ^ swz64(prow + k)) << 4));
+    int rd_off = 0;
+    int hcur = 0;
+    int seq = 0;
+
+    // ---- the PENDING tile: its sums (pend), which constants buffer holds its bias / slopes, and per lane where its outputs go.  Its
+    // epilogue runs one unit (n-tile pair jp, pixel row i) per k-step of the current tile's first chunk, inside the MFMA phase.
+    const float* pcst = cst_base;
+    int pn0 = 0;
+    const int cb = 8 * (g & 1) + 4 * (g >> 1);
+    const int climit = (a.Cout + 7) & ~7;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    // per lane and pixel row i: is the pixel inside the image (and is there a pending tile at all); byte offsets of (pixel, first channel
+    // of the lane) in the fp32 rows and in the two sinks' planes -- n-tile pair jp then adds 128 bytes / jp chunks (32-bit offsets from
+    // scalar bases: the launcher guarantees every output stays under 4 GiB)
+    bool plive[2] = {false, false};
+    unsigned poff_f32[2] = {0u, 0u}, poff_s1[2] = {0u, 0u}, poff_s2[2] = {0u, 0u};
+    auto place_pending = [&](int simg, int sox0, int soy0, int sn0, bool valid) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int oy = soy0 + 2 * wave + i, ox = sox0 + r;
+            plive[i] = valid && oy < a.H && ox < a.W;
+            const unsigned prow_o = plive[i] ? (unsigned)((simg * a.H + oy) * a.W + ox) : 0u;
+            poff_f32[i] = (prow_o * (unsigned)a.out_ld + (unsigned)(sn0 + cb)) * 4u;
+            const int cs = sn0 + (g < 2 ? 0 : 16) + 8 * (g & 1);          // first of the 8 channels this lane stores for n-tile pair 0
+            const int c1 = a.out_c0 + cs, c2 = a.out_c02 + cs;
+            poff_s1[i] = (((unsigned)(c1 >> 5) * (unsigned)a.plane_rows + prow_o) * 32u + (unsigned)(c1 & 31)) * 2u;
+            poff_s2[i] = (((unsigned)(c2 >> 5) * (unsigned)a.plane_rows2 + prow_o) * 32u + (unsigned)(c2 & 31)) * 2u;
+        }
+        pn0 = sn0;
+    };
+    auto select_prelu = [](const f32x4 v, const f32x4 sl) -> f32x4 {
+        return (f32x4){v.x > 0.f ? v.x : sl.x * v.x, v.y > 0.f ? v.y : sl.y * v.y, v.z > 0.f ? v.z : sl.z * v.z, v.w > 0.f ? v.w : sl.w * v.w};
+    };
+    // the six-instruction split (plain C++: the MFMA phase's instruction interleaving schedules it; split_pair()'s inline asm it cannot)
+    auto split4 = [](const f32x4 v, unsigned& h01, unsigned& h23, unsigned& l01, unsigned& l23) {
+        const f16x2 ha = __builtin_convertvector((f32x2){v.x, v.y}, f16x2), hb = __builtin_convertvector((f32x2){v.z, v.w}, f16x2);
+        const f16x2 la = __builtin_convertvector(((f32x2){v.x, v.y} - __builtin_convertvector(ha, f32x2)) * 1024.0f, f16x2);
+        const f16x2 lb = __builtin_convertvector(((f32x2){v.z, v.w} - __builtin_convertvector(hb, f32x2)) * 1024.0f, f16x2);
+        h01 = __builtin_bit_cast(unsigned, ha); h23 = __builtin_bit_cast(unsigned, hb);
+        l01 = __builtin_bit_cast(unsigned, la); l23 = __builtin_bit_cast(unsigned, lb);
+    };
+    // the two n-tiles' dwords swapped across the wave halves (conv3x3_planes_kernel's plane_sink): one 16-byte store per lane and plane
+    auto sink_pack = [&](const f32x4 u0, const f32x4 u1, u32x4& hv, u32x4& lv) {
+        unsigned h00, h01, l00, l01, h10, h11, l10, l11;
+        split4(u0, h00, h01, l00, l01);
+        split4(u1, h10, h11, l10, l11);
+        const auto sh0 = __builtin_amdgcn_permlane32_swap(h00, h10, false, false);
+        const auto sh1 = __builtin_amdgcn_permlane32_swap(h01, h11, false, false);
+        const auto sl0 = __builtin_amdgcn_permlane32_swap(l00, l10, false, false);
+        const auto sl1 = __builtin_amdgcn_permlane32_swap(l01, l11, false, false);
+        hv = (u32x4){sh0[0], sh1[0], sh0[1], sh1[1]};
+        lv = (u32x4){sl0[0], sl1[0], sl0[1], sl1[1]};
+    };
+    // A unit's results, between its arithmetic (inside the MFMA phase) and its stores (behind the phase's last MFMA)
+    struct UnitOut {
+        f32x4 v[2];                   // the two n-tiles' four channels after bias + PReLU
+        u32x4 hv, lv, hv2, lv2;       // plane sinks (the first one through its own PReLU)
+    };
+    constexpr int NUNIT = 2 * ((WN + 1) / 2);
+    static_assert(NUNIT <= 8, "one epilogue unit per k-step of a 9-k-step chunk");
+    // Stores of unit U (plain conditional stores: they are NOT counted by the k-loop's vmcnt immediates -- loads and stores do not retire
+    // in one order on gfx950, a counted wait over a mix returns early: found with this kernel, 1e-4 errors in a few pixels -- so a wait
+    // for DMA pieces also sees the unit's stores of the last phases as outstanding and waits for them too: they are a k-step old by then)
+    auto unit_store = [&](auto uc, const f32x4 (&src)[2][WN], const UnitOut& o, const bool (&live)[2], const unsigned (&of32)[2], const unsigned (&os1)[2],
+                          const unsigned (&os2)[2], int sn0) {
+        constexpr int U = decltype(uc)::value;
+        constexpr int jp = U >> 1, i = U & 1;
+        constexpr int j0 = 2 * jp;
+        constexpr bool has_j1 = 2 * jp + 1 < WN;
+        if (out_f32) {
+#pragma unroll
+            for (int e = 0; e < (has_j1 ? 2 : 1); ++e) {
+                const int co = sn0 + 16 * (j0 + e) + cb;
+                const int nvalid = a.Cout - co;
+                float* p = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(out_f32) + of32[i]) + 16 * (j0 + e);
+                if (live[i] && co + 4 > a.out_cmin) {
+                    if (nvalid >= 4) {
+                        *reinterpret_cast<f32x4*>(p) = o.v[e];
+                    } else if (nvalid > 0) {
+                        p[0] = o.v[e].x;
+                        if (nvalid > 1) p[1] = o.v[e].y;
+                        if (nvalid > 2) p[2] = o.v[e].z;
+                    }
+                }
+            }
+        }
+        const int jt = g < 2 ? j0 : 2 * jp + 1;
+        const bool sink_ok_ = live[i] && jt < WN && sn0 + 16 * jt + 8 * (g & 1) < climit;
+        if (a.out_hi && sink_ok_) {
+            const unsigned off = os1[i] + (unsigned)jp * (unsigned)a.plane_rows * 64u;
+            *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(a.out_hi) + off) = o.hv;
+            *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(a.out_lo) + off) = o.lv;
+        }
+        if (a.out_hi2 && sink_ok_) {
+            const unsigned off = os2[i] + (unsigned)jp * (unsigned)a.plane_rows2 * 64u;
+            *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(a.out_hi2) + off) = o.hv2;
+            *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(a.out_lo2) + off) = o.lv2;
+        }
+    };
+    // unit arithmetic, stage by stage (each stage shares a scheduling region with a third of the k-step's MFMAs)
+    auto unit_fold = [&](auto uc, const f32x4 (&src)[2][WN], const float* scst, UnitOut& o) {
+        constexpr int U = decltype(uc)::value;
+        constexpr int jp = U >> 1, i = U & 1;
+        constexpr int j0 = 2 * jp, j1 = (2 * jp + 1 < WN) ? 2 * jp + 1 : 2 * jp;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int cl = 16 * (e ? j1 : j0) + cb;
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(scst + cl);
+            const f32x4 pv = *reinterpret_cast<const f32x4*>(scst + BN + cl);
+            o.v[e] = select_prelu(src[i][e ? j1 : j0] + bv, pv);       // (an absent slope array reads 1.0: x > 0 ? x : 1.0 * x is x)
+        }
+    };
+    auto unit_sink1 = [&](auto uc, const float* scst, UnitOut& o) {
+        constexpr int U = decltype(uc)::value;
+        constexpr int jp = U >> 1;
+        constexpr int j0 = 2 * jp, j1 = (2 * jp + 1 < WN) ? 2 * jp + 1 : 2 * jp;
+        const f32x4 q0 = *reinterpret_cast<const f32x4*>(scst + 2 * BN + 16 * j0 + cb);
+        const f32x4 q1 = *reinterpret_cast<const f32x4*>(scst + 2 * BN + 16 * j1 + cb);
+        sink_pack(select_prelu(o.v[0], q0), select_prelu(o.v[1], q1), o.hv, o.lv);
+    };
+    auto unit_sink2 = [&](UnitOut& o) { sink_pack(o.v[0], o.v[1], o.hv2, o.lv2); };
+    // one MFMA, then a few vector instructions, and so on: the matrix pipe takes an instruction every 16 cycles, the wave issues the VALU
+    // work in between (its SIMD partner is in its read phase: LDS and DMA, hardly any VALU)
+    auto interleave = [](auto nc, auto perc) {
+        constexpr int NM = decltype(nc)::value, PER = decltype(perc)::value;
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);          // the unit's six LDS reads of constants first
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, PER, 0);
+        }
+    };
+
+    // One k-step of one wave.  T = tap (regular chunk) or tail step; FIRST: the tile's first chunk, whose k-steps 0 .. NUNIT-1 carry the
+    // pending tile's epilogue units.
+    const f16x8 k2m10 = {(_Float16)0.0009765625f, (_Float16)0.0009765625f, (_Float16)0.0009765625f, (_Float16)0.0009765625f,
+                         (_Float16)0.0009765625f, (_Float16)0.0009765625f, (_Float16)0.0009765625f, (_Float16)0.0009765625f};
+    auto kstep = [&](auto tc, auto tailc, auto firstc) {
+        constexpr int T = decltype(tc)::value;
+        constexpr bool TAIL = decltype(tailc)::value;
+        constexpr bool FIRST = decltype(firstc)::value;
+#ifdef ATMVFI_DE_EXP_NOUNITS
+        constexpr bool UNIT = false;             // experiment build: no deferred units at all (wrong results; times the bare k-loop)
+#else
+        constexpr bool UNIT = FIRST && T < NUNIT;
+#endif
+        // ---------------- read phase ----------------
+        if constexpr (!TAIL) {
+            constexpr int C0 = (T / 3) * HW_ + T % 3, C1 = C0 + HW_;
+            lds_read16<64 * C0>(xh[0], xa[C0 & 7]);
+            lds_read16<64 * C0 + HALO_LO>(xl[0], xa[C0 & 7]);
+            lds_read16<64 * C1>(xh[1], xa[C1 & 7]);
+            lds_read16<64 * C1 + HALO_LO>(xl[1], xa[C1 & 7]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int p = prow + i * HW_ + ((dtail >> (8 * T)) & 0xff);
+                const unsigned addr = halo0 + (unsigned)hcur + (unsigned)(p * 64 + (swz64(p) << 4));
+                lds_read16<0>(xh[i], addr);
+                lds_read16<HALO_LO>(xl[i], addr);
+            }
+        }
+        const unsigned wa = wfrag + (unsigned)rd_off;
+        static_for<0, WN>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            lds_read16<j * 1024>(wh[j], wa);
+            lds_read16<j * 1024 + BN * 64>(wl[j], wa);
+        });
+        rd_off = rd_off + WSLOT == NB * WSLOT ? 0 : rd_off + WSLOT;
+        issue_weights();
+        if constexpr (!TAIL && T < 6) issue_halo(std::integral_constant<int, T>{});
+        if constexpr (TAIL && T < 2) {
+            issue_halo(std::integral_constant<int, 3 * T>{});
+            issue_halo(std::integral_constant<int, 3 * T + 1>{});
+            issue_halo(std::integral_constant<int, 3 * T + 2>{});
+        }
+        // Own pieces of the next k-step landed.  Behind its weights (issued LA - 1 read phases ago) went SW weight pieces per phase, the
+        // halo pieces of the phases T + 1 - LA .. T of this chunk and -- first LA - 1 k-steps of a tile -- the tile's constants piece.
+        // What the previous tile's last phases issued besides their weights (the three-piece halo issues of tail steps) is not counted,
+        // nor are the epilogue units' stores: counting fewer operations than are behind only waits longer.
+        {
+            constexpr int lo = T + 1 - LA > 0 ? T + 1 - LA : 0;
+            constexpr int hi = T < 5 ? T : 5;
+            constexpr int halos = !TAIL ? (hi >= lo ? hi - lo + 1 : 0) : (lo <= 0 ? 3 : 0) + ((lo <= 1 && T >= 1) ? 3 : 0);
+            constexpr int consts = (FIRST && T < LA - 1) ? 1 : 0;
+            // The LAST k-step of a chunk is also where the next chunk's halo has to be complete (the next read phase starts with it): only
+            // what was issued after its last piece may stay in flight -- the weights of taps 6, 7, 8 behind a regular chunk's tap-5 piece
+            // (at least LA - 1 phases of them), the weights of tail step 2 behind the three pieces of tail step 1.  (With a lookahead of
+            // 4 k-steps the window formula alone lets the tap-5 piece stay in flight over the chunk boundary, and all six pieces of the
+            // tail steps over a tile boundary -- there conv3x3_planes_kernel has its wait_vm<1>, this kernel has no boundary.)
+            constexpr int N = (!TAIL && T == 8) ? (LA - 1) * SW : (TAIL && T == 2) ? SW : (LA - 1) * SW + halos + consts;
+            wait_vm<N>();
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(xh[0]), "+v"(xh[1]), "+v"(xl[0]), "+v"(xl[1]));
+#pragma unroll
+        for (int j = 0; j < WN; ++j) asm volatile("" : "+v"(wh[j]), "+v"(wl[j]));
+        // lo' planes carry (x - hi) * 1024: scaled back here, in fp16 (subnormals are kept by the matrix cores:
+        // tools/probes/mfma_denorm_probe.hip), so that all three products of a k-step go into ONE accumulator
+        xl[0] = xl[0] * k2m10;
+        xl[1] = xl[1] * k2m10;
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---------------- MFMA phase ----------------
+        // three passes of 2 WN MFMAs (hi x hi, hi x lo, lo' x hi * 2^-10), each one scheduling region; a k-step that carries an epilogue
+        // unit puts a stage of it into each (present outputs only: uniform branches between the regions)
+        __builtin_amdgcn_s_setprio(1);
+        auto pass1 = [&]() {
+            static_for<0, WN>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xh[0], acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xh[1], acc[1][j], 0, 0, 0);
+            });
+        };
+        auto pass2 = [&]() {
+            static_for<0, WN>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xl[0], acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xl[1], acc[1][j], 0, 0, 0);
+            });
+        };
+        auto pass3 = [&]() {
+            xh[0] = xh[0] * k2m10;      // hi * 2^-10 for the lo'(weights) x hi(activations) product (the weights' lo' stays scaled)
+            xh[1] = xh[1] * k2m10;
+            static_for<0, WN>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j], xh[0], acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j], xh[1], acc[1][j], 0, 0, 0);
+            });
+        };
+        if constexpr (UNIT) {
+            // one scheduling region: the k-step's 6 WN MFMAs and the unit's arithmetic for EVERY output kind (a launch without the
+            // second sink, say, wastes its ~30 vector instructions: free, the VALU is idle in an MFMA phase; a branch on the output
+            // kinds would cut the region -- and with MFMAs on both of its sides costs ~50 registers)
+            typedef std::integral_constant<int, T> UC;
+            UnitOut uo;
+            __builtin_amdgcn_sched_barrier(0);
+            pass1();
+            pass2();
+            pass3();
+            unit_fold(UC{}, pend, pcst, uo);
+            unit_sink1(UC{}, pcst, uo);
+            unit_sink2(uo);
+            interleave(std::integral_constant<int, 6 * WN>{}, std::integral_constant<int, (150 + 6 * WN - 1) / (6 * WN)>{});
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            unit_store(UC{}, pend, uo, plive, poff_f32, poff_s1, poff_s2, pn0);
+        } else {
+            pass1();
+            pass2();
+            pass3();
+            __builtin_amdgcn_s_setprio(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto next_chunk = [&]() {
+        const int d = hcur ? -HALO_BYTES : HALO_BYTES;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) xa[k] += d;
+        hcur += d;
+        halo_advance();
+    };
+
+    for (;;) {
+        float* cst = cst_base + (seq & 1) * CSTF;
+        // (all of this sits in the wave's read-phase slot of the tile's first k-step: the SIMD partner is in its last MFMA phase of the
+        // previous tile.)  This tile's constants: needed a whole tile from now, by its deferred epilogue.
+        dma_planes_consts<BN>(a.bias, a.prelu, a.plane_prelu, a.Cout, n0, cst, wave, lane);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                pend[i][j] = acc[i][j];
+                acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                asm volatile("" : "+v"(acc[i][j]), "+v"(pend[i][j]));
+            }
+        static_for<0, 9>([&](auto tc) { kstep(tc, std::false_type{}, std::true_type{}); });
+        next_chunk();
+        for (int c = 1; c < nfull; ++c) {
+            static_for<0, 9>([&](auto tc) { kstep(tc, std::false_type{}, std::false_type{}); });
+            next_chunk();
+        }
+        if (ktail) {
+            static_for<0, 3>([&](auto tc) { kstep(tc, std::true_type{}, std::false_type{}); });
+            next_chunk();
+        }
+        if (!has_next) break;
+        // on to the next tile without a pause: its first halo and its first LA k-steps of weights are in LDS or on their way
+        place_pending(img, ox0, oy0, n0, true);
+        pcst = cst;
+        vb += grid;
+        img = nimg; ox0 = nox0; oy0 = noy0; n0 = nn0;
+        ++seq;
+        has_next = decode(vb + grid, nimg, nox0, noy0, nn0);
+#pragma unroll
+        for (int s = 0; s < SW; ++s) wnext[s] = weight_base(s, nn0);
+    }
+    // ---- the last tile's epilogue, in the open: the first group waits for the second one's last MFMA phase, everything in flight (the
+    // tile's constants among it) lands, then the units one after the other
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+    wait_vm<0>();
+    {
+        const float* cst = cst_base + (seq & 1) * CSTF;
+        place_pending(img, ox0, oy0, n0, true);
+        static_for<0, NUNIT>([&](auto uc) {
+            UnitOut uo;
+            unit_fold(uc, acc, cst, uo);
+            if (a.out_hi) unit_sink1(uc, cst, uo);
+            if (a.out_hi2) unit_sink2(uo);
+            unit_store(uc, acc, uo, plive, poff_f32, poff_s1, poff_s2, pn0);
+        });
+    }
+}
+
 template <int WN>
 int launch_planes(const Conv3PDev& d, int ntiles, hipStream_t s) {
     constexpr int BN = 16 * WN;
@@ -798,6 +1344,15 @@ int launch_planes(const Conv3PDev& d, int ntiles, hipStream_t s) {
         return atmvfi::check_launch("conv3x3_planes (split-K)");
     }
     const int grid = nchunks >= 2 ? std::min(ds.vblocks, atmvfi::cu_count()) : ds.vblocks;
+    if constexpr (WN <= 7) {
+        // workgroups that walk several tiles, each with at least one full chunk: the deferred-epilogue variant (above)
+        if (d.defer && !d.h2_w && (d.cf >> 5) >= 1 && nchunks >= 2 && grid < ds.vblocks) {
+            const hipError_t e2 = atmvfi::allow_dynamic_lds<conv3x3_planes_de_kernel<WN>>(lds);
+            ATMVFI_REQUIRE(e2 == hipSuccess, ATMVFI_ELAUNCH, "conv3x3_planes: hipFuncSetAttribute: %s", hipGetErrorString(e2));
+            hipLaunchKernelGGL(conv3x3_planes_de_kernel<WN>, dim3((unsigned)grid), dim3(512), lds, s, ds);
+            return atmvfi::check_launch("conv3x3_planes (deferred epilogue)");
+        }
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, s, ds);
     return atmvfi::check_launch("conv3x3_planes");
 }
@@ -965,7 +1520,9 @@ static int conv3x3_planes_impl(const void* in_hi, const void* in_lo, int64_t in_
         ATMVFI_REQUIRE(atmvfi::aligned16(out_hi) && atmvfi::aligned16(out_lo) && (!plane_prelu || atmvfi::aligned16(plane_prelu)),
                        ATMVFI_EALIGN, "conv3x3_planes: plane sink pointers must be 16-byte aligned");
     }
-    ATMVFI_REQUIRE(wn >= 0 && wn <= 8, ATMVFI_EINVAL, "conv3x3_planes: wn 0 (auto) or 1..8");
+    const bool defer = (wn & 16) == 0;        // bit 4 of wn: keep the two-accumulator kernel (A/B switch, kernel-against-kernel tests)
+    if (wn >= 0) wn &= 15;
+    ATMVFI_REQUIRE(wn >= 0 && wn <= 8, ATMVFI_EINVAL, "conv3x3_planes: wn 0 (auto) or 1..8 (+ 16: no deferred epilogue)");
     ATMVFI_REQUIRE(out_cmin >= 0 && out_cmin % 4 == 0, ATMVFI_EINVAL, "conv3x3_planes: out_cmin must be a non-negative multiple of 4");
     Conv3PDev d;
     d.in_hi = (const _Float16*)in_hi; d.in_lo = (const _Float16*)in_lo; d.in_rows = in_rows;
@@ -981,6 +1538,12 @@ static int conv3x3_planes_impl(const void* in_hi, const void* in_lo, int64_t in_
     d.tiles_x = (W + TW - 1) / TW;
     d.tiles_y = 0; d.nblocks = 0; d.tchunk = 0;
     d.h2_w = (const _Float16*)h2_w; d.h2_out = h2_out; d.h2_plane = h2_plane;
+    // the deferred-epilogue kernel addresses its outputs with 32-bit byte offsets from scalar bases
+    const long long rows_ = (long long)N * H * W;
+    const bool fit32 = (!out || (rows_ + 1) * out_ld * 4 < (1ll << 32)) &&
+                       (!out_hi || (long long)((out_c0 + Cout + 31) / 32) * plane_rows * 64 < (1ll << 32)) &&
+                       (!out_hi2 || (long long)((out_c02 + Cout + 31) / 32) * plane_rows2 * 64 < (1ll << 32));
+    d.defer = (defer && fit32) ? 1 : 0;
     const int ntiles = (Cout + 15) / 16;
     ATMVFI_REQUIRE(!workspace || atmvfi::aligned16(workspace), ATMVFI_EALIGN, "conv3x3_planes: the split-K workspace must be 16-byte aligned");
     Conv3Plan plan = conv3_plan(N, H, W, Cin, Cout, wn, workspace != nullptr);
