@@ -95,7 +95,7 @@ struct Conv3PDev {
     const _Float16* h2_w;       // [plane hi / lo][row tile 2][k-step WN/2][lane 64][8 halves], k order = this kernel's register order
     float* h2_out;
     long long h2_plane;
-    int defer;                  // 1: multi-tile launches may take conv3x3_planes_de_kernel (wn without bit 4, include/atmvfi.h)
+    int defer;                  // 1: multi-tile launches may take conv3x3_planes_de_kernel (wn with bit 4, include/atmvfi.h)
     unsigned long long* stamp;  // diagnostic builds only (ATMVFI_STAMP)
     int dbg;                    // diagnostic builds only: ATMVFI_P3_DBG bits switch pieces of the loop off (wrong results, timing only)
 };
@@ -998,14 +998,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_de_kernel(const Conv3PD
     // per lane and pixel row i: is the pixel inside the image (and is there a pending tile at all); byte offsets of (pixel, first channel
     // of the lane) in the fp32 rows and in the two sinks' planes -- n-tile pair jp then adds 128 bytes / jp chunks (32-bit offsets from
     // scalar bases: the launcher guarantees every output stays under 4 GiB)
-    bool plive[2] = {false, false};
+    unsigned plive = 0u;              // bit i: pixel row i of the lane is inside the image (and a tile is pending)
     unsigned poff_f32[2] = {0u, 0u}, poff_s1[2] = {0u, 0u}, poff_s2[2] = {0u, 0u};
     auto place_pending = [&](int simg, int sox0, int soy0, int sn0, bool valid) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int oy = soy0 + 2 * wave + i, ox = sox0 + r;
-            plive[i] = valid && oy < a.H && ox < a.W;
-            const unsigned prow_o = plive[i] ? (unsigned)((simg * a.H + oy) * a.W + ox) : 0u;
+            const bool lv_ = valid && oy < a.H && ox < a.W;
+            plive = i == 0 ? (lv_ ? 1u : 0u) : plive | (lv_ ? 2u : 0u);
+            const unsigned prow_o = lv_ ? (unsigned)((simg * a.H + oy) * a.W + ox) : 0u;
             poff_f32[i] = (prow_o * (unsigned)a.out_ld + (unsigned)(sn0 + cb)) * 4u;
             const int cs = sn0 + (g < 2 ? 0 : 16) + 8 * (g & 1);          // first of the 8 channels this lane stores for n-tile pair 0
             const int c1 = a.out_c0 + cs, c2 = a.out_c02 + cs;
@@ -1014,108 +1015,107 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_de_kernel(const Conv3PD
         }
         pn0 = sn0;
     };
-    auto select_prelu = [](const f32x4 v, const f32x4 sl) -> f32x4 {
-        return (f32x4){v.x > 0.f ? v.x : sl.x * v.x, v.y > 0.f ? v.y : sl.y * v.y, v.z > 0.f ? v.z : sl.z * v.z, v.w > 0.f ? v.w : sl.w * v.w};
-    };
-    // the six-instruction split (plain C++: the MFMA phase's instruction interleaving schedules it; split_pair()'s inline asm it cannot)
-    auto split4 = [](const f32x4 v, unsigned& h01, unsigned& h23, unsigned& l01, unsigned& l23) {
-        const f16x2 ha = __builtin_convertvector((f32x2){v.x, v.y}, f16x2), hb = __builtin_convertvector((f32x2){v.z, v.w}, f16x2);
-        const f16x2 la = __builtin_convertvector(((f32x2){v.x, v.y} - __builtin_convertvector(ha, f32x2)) * 1024.0f, f16x2);
-        const f16x2 lb = __builtin_convertvector(((f32x2){v.z, v.w} - __builtin_convertvector(hb, f32x2)) * 1024.0f, f16x2);
-        h01 = __builtin_bit_cast(unsigned, ha); h23 = __builtin_bit_cast(unsigned, hb);
-        l01 = __builtin_bit_cast(unsigned, la); l23 = __builtin_bit_cast(unsigned, lb);
-    };
-    // the two n-tiles' dwords swapped across the wave halves (conv3x3_planes_kernel's plane_sink): one 16-byte store per lane and plane
-    auto sink_pack = [&](const f32x4 u0, const f32x4 u1, u32x4& hv, u32x4& lv) {
-        unsigned h00, h01, l00, l01, h10, h11, l10, l11;
-        split4(u0, h00, h01, l00, l01);
-        split4(u1, h10, h11, l10, l11);
-        const auto sh0 = __builtin_amdgcn_permlane32_swap(h00, h10, false, false);
-        const auto sh1 = __builtin_amdgcn_permlane32_swap(h01, h11, false, false);
-        const auto sl0 = __builtin_amdgcn_permlane32_swap(l00, l10, false, false);
-        const auto sl1 = __builtin_amdgcn_permlane32_swap(l01, l11, false, false);
-        hv = (u32x4){sh0[0], sh1[0], sh0[1], sh1[1]};
-        lv = (u32x4){sl0[0], sl1[0], sl0[1], sl1[1]};
-    };
-    // A unit's results, between its arithmetic (inside the MFMA phase) and its stores (behind the phase's last MFMA)
-    struct UnitOut {
-        f32x4 v[2];                   // the two n-tiles' four channels after bias + PReLU
-        u32x4 hv, lv, hv2, lv2;       // plane sinks (the first one through its own PReLU)
-    };
+    // ---- A unit's work as a list of MICRO-STEPS of 2-8 instructions, executed one behind each MFMA of the carrying k-steps with a
+    // scheduling fence in between (hipcc's own interleaving -- sched_group_barrier -- leaves the MFMAs in a block here; the matrix pipe
+    // takes an instruction every 16 cycles, so ~4 vector instructions behind each MFMA are free: the SIMD partner is in its read phase).
+    // The state between steps lives in registers; a unit may span k-steps (narrow tiles: fewer MFMAs per k-step).
     constexpr int NUNIT = 2 * ((WN + 1) / 2);
-    static_assert(NUNIT <= 8, "one epilogue unit per k-step of a 9-k-step chunk");
-    // Stores of unit U (plain conditional stores: they are NOT counted by the k-loop's vmcnt immediates -- loads and stores do not retire
-    // in one order on gfx950, a counted wait over a mix returns early: found with this kernel, 1e-4 errors in a few pixels -- so a wait
-    // for DMA pieces also sees the unit's stores of the last phases as outstanding and waits for them too: they are a k-step old by then)
-    auto unit_store = [&](auto uc, const f32x4 (&src)[2][WN], const UnitOut& o, const bool (&live)[2], const unsigned (&of32)[2], const unsigned (&os1)[2],
-                          const unsigned (&os2)[2], int sn0) {
-        constexpr int U = decltype(uc)::value;
+    constexpr int NSTEP = 31;                     // micro-steps per unit
+    struct UnitState {
+        f32x4 c;                      // the constant vector in flight (bias / slope of an n-tile), requested three steps before its use
+        f32x4 v[2];                   // after bias + PReLU
+        f32x4 u[2];                   // slope x value; through the first sink's own PReLU
+        unsigned h[4], l[4];          // split halves (two dwords per n-tile and plane) before the cross-half swap
+    };
+    UnitState us;
+    auto unit_step = [&](auto qc, const f32x4 (&src)[2][WN], const float* scst) {
+        constexpr int Q = decltype(qc)::value;
+        constexpr int U = Q / NSTEP, S = Q % NSTEP;
         constexpr int jp = U >> 1, i = U & 1;
-        constexpr int j0 = 2 * jp;
+        constexpr int j0 = 2 * jp, j1 = (2 * jp + 1 < WN) ? 2 * jp + 1 : 2 * jp;
         constexpr bool has_j1 = 2 * jp + 1 < WN;
-        if (out_f32) {
+        // dst.xy (LO) or dst.zw = v > 0 ? v : t on that half
+        auto sel_lo = [](f32x4& d, const f32x4 v, const f32x4 t) { const float x = v.x > 0.f ? v.x : t.x, y = v.y > 0.f ? v.y : t.y; d.x = x; d.y = y; };
+        auto sel_hi = [](f32x4& d, const f32x4 v, const f32x4 t) { const float z = v.z > 0.f ? v.z : t.z, w = v.w > 0.f ? v.w : t.w; d.z = z; d.w = w; };
+        auto split2 = [](float x, float y, unsigned& hh, unsigned& ll) {
+            const f16x2 ha = __builtin_convertvector((f32x2){x, y}, f16x2);
+            const f16x2 la = __builtin_convertvector(((f32x2){x, y} - __builtin_convertvector(ha, f32x2)) * 1024.0f, f16x2);
+            hh = __builtin_bit_cast(unsigned, ha);
+            ll = __builtin_bit_cast(unsigned, la);
+        };
+        auto swap4 = [&](u32x4& hv, u32x4& lv) {
+            const auto sh0 = __builtin_amdgcn_permlane32_swap(us.h[0], us.h[2], false, false);
+            const auto sh1 = __builtin_amdgcn_permlane32_swap(us.h[1], us.h[3], false, false);
+            const auto sl0 = __builtin_amdgcn_permlane32_swap(us.l[0], us.l[2], false, false);
+            const auto sl1 = __builtin_amdgcn_permlane32_swap(us.l[1], us.l[3], false, false);
+            hv = (u32x4){sh0[0], sh1[0], sh0[1], sh1[1]};
+            lv = (u32x4){sl0[0], sl1[0], sl0[1], sl1[1]};
+        };
+        auto ld = [&](int off) { us.c = *reinterpret_cast<const f32x4*>(scst + off + cb); };
+        const int jt = g < 2 ? j0 : 2 * jp + 1;
+        const bool live = (plive >> i) & 1;
+        if constexpr (S == 0) ld(16 * j0);                                        // bias of the first n-tile
+        else if constexpr (S == 3) { us.v[0] = src[i][j0] + us.c; ld(16 * j1); }
+        else if constexpr (S == 6) { us.v[1] = src[i][j1] + us.c; ld(BN + 16 * j0); }           // slopes (an absent array reads 1.0)
+        else if constexpr (S == 9) { us.u[0] = us.c * us.v[0]; ld(BN + 16 * j1); }
+        else if constexpr (S == 10) sel_lo(us.v[0], us.v[0], us.u[0]);
+        else if constexpr (S == 11) sel_hi(us.v[0], us.v[0], us.u[0]);
+        else if constexpr (S == 12) { us.u[1] = us.c * us.v[1]; ld(2 * BN + 16 * j0); }          // the first sink's own slopes
+        else if constexpr (S == 13) sel_lo(us.v[1], us.v[1], us.u[1]);
+        else if constexpr (S == 14) sel_hi(us.v[1], us.v[1], us.u[1]);
+        else if constexpr (S == 15) {              // fp32 rows: this unit's two vectors (from out_cmin on; a ragged last group by elements)
+            if (out_f32) {
 #pragma unroll
-            for (int e = 0; e < (has_j1 ? 2 : 1); ++e) {
-                const int co = sn0 + 16 * (j0 + e) + cb;
-                const int nvalid = a.Cout - co;
-                float* p = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(out_f32) + of32[i]) + 16 * (j0 + e);
-                if (live[i] && co + 4 > a.out_cmin) {
-                    if (nvalid >= 4) {
-                        *reinterpret_cast<f32x4*>(p) = o.v[e];
-                    } else if (nvalid > 0) {
-                        p[0] = o.v[e].x;
-                        if (nvalid > 1) p[1] = o.v[e].y;
-                        if (nvalid > 2) p[2] = o.v[e].z;
+                for (int e = 0; e < (has_j1 ? 2 : 1); ++e) {
+                    const int co = pn0 + 16 * (j0 + e) + cb;
+                    const int nvalid = a.Cout - co;
+                    float* p = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(out_f32) + poff_f32[i]) + 16 * (j0 + e);
+                    if (live && co + 4 > a.out_cmin) {
+                        if (nvalid >= 4) {
+                            *reinterpret_cast<f32x4*>(p) = us.v[e];
+                        } else if (nvalid > 0) {
+                            p[0] = us.v[e].x;
+                            if (nvalid > 1) p[1] = us.v[e].y;
+                            if (nvalid > 2) p[2] = us.v[e].z;
+                        }
                     }
                 }
             }
         }
-        const int jt = g < 2 ? j0 : 2 * jp + 1;
-        const bool sink_ok_ = live[i] && jt < WN && sn0 + 16 * jt + 8 * (g & 1) < climit;
-        if (a.out_hi && sink_ok_) {
-            const unsigned off = os1[i] + (unsigned)jp * (unsigned)a.plane_rows * 64u;
-            *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(a.out_hi) + off) = o.hv;
-            *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(a.out_lo) + off) = o.lv;
+        else if constexpr (S == 16) { us.u[0] = us.c * us.v[0]; ld(2 * BN + 16 * j1); }
+        else if constexpr (S == 17) split2(us.v[0].x, us.v[0].y, us.h[0], us.l[0]);               // second sink: the raw values
+        else if constexpr (S == 18) split2(us.v[0].z, us.v[0].w, us.h[1], us.l[1]);
+        else if constexpr (S == 19) split2(us.v[1].x, us.v[1].y, us.h[2], us.l[2]);
+        else if constexpr (S == 20) split2(us.v[1].z, us.v[1].w, us.h[3], us.l[3]);
+        else if constexpr (S == 21) {
+            u32x4 hv, lv;
+            swap4(hv, lv);
+            if (a.out_hi2 && live && jt < WN && pn0 + 16 * jt + 8 * (g & 1) < climit) {
+                const unsigned off = poff_s2[i] + (unsigned)jp * (unsigned)a.plane_rows2 * 64u;
+                *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(a.out_hi2) + off) = hv;
+                *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(a.out_lo2) + off) = lv;
+            }
         }
-        if (a.out_hi2 && sink_ok_) {
-            const unsigned off = os2[i] + (unsigned)jp * (unsigned)a.plane_rows2 * 64u;
-            *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(a.out_hi2) + off) = o.hv2;
-            *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(a.out_lo2) + off) = o.lv2;
-        }
-    };
-    // unit arithmetic, stage by stage (each stage shares a scheduling region with a third of the k-step's MFMAs)
-    auto unit_fold = [&](auto uc, const f32x4 (&src)[2][WN], const float* scst, UnitOut& o) {
-        constexpr int U = decltype(uc)::value;
-        constexpr int jp = U >> 1, i = U & 1;
-        constexpr int j0 = 2 * jp, j1 = (2 * jp + 1 < WN) ? 2 * jp + 1 : 2 * jp;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int cl = 16 * (e ? j1 : j0) + cb;
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(scst + cl);
-            const f32x4 pv = *reinterpret_cast<const f32x4*>(scst + BN + cl);
-            o.v[e] = select_prelu(src[i][e ? j1 : j0] + bv, pv);       // (an absent slope array reads 1.0: x > 0 ? x : 1.0 * x is x)
-        }
-    };
-    auto unit_sink1 = [&](auto uc, const float* scst, UnitOut& o) {
-        constexpr int U = decltype(uc)::value;
-        constexpr int jp = U >> 1;
-        constexpr int j0 = 2 * jp, j1 = (2 * jp + 1 < WN) ? 2 * jp + 1 : 2 * jp;
-        const f32x4 q0 = *reinterpret_cast<const f32x4*>(scst + 2 * BN + 16 * j0 + cb);
-        const f32x4 q1 = *reinterpret_cast<const f32x4*>(scst + 2 * BN + 16 * j1 + cb);
-        sink_pack(select_prelu(o.v[0], q0), select_prelu(o.v[1], q1), o.hv, o.lv);
-    };
-    auto unit_sink2 = [&](UnitOut& o) { sink_pack(o.v[0], o.v[1], o.hv2, o.lv2); };
-    // one MFMA, then a few vector instructions, and so on: the matrix pipe takes an instruction every 16 cycles, the wave issues the VALU
-    // work in between (its SIMD partner is in its read phase: LDS and DMA, hardly any VALU)
-    auto interleave = [](auto nc, auto perc) {
-        constexpr int NM = decltype(nc)::value, PER = decltype(perc)::value;
-        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);          // the unit's six LDS reads of constants first
-#pragma unroll
-        for (int m = 0; m < NM; ++m) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, PER, 0);
+        else if constexpr (S == 22) us.u[1] = us.c * us.v[1];
+        else if constexpr (S == 23) sel_lo(us.u[0], us.v[0], us.u[0]);                            // first sink: through its own PReLU
+        else if constexpr (S == 24) sel_hi(us.u[0], us.v[0], us.u[0]);
+        else if constexpr (S == 25) sel_lo(us.u[1], us.v[1], us.u[1]);
+        else if constexpr (S == 26) sel_hi(us.u[1], us.v[1], us.u[1]);
+        else if constexpr (S == 27) { split2(us.u[0].x, us.u[0].y, us.h[0], us.l[0]); split2(us.u[0].z, us.u[0].w, us.h[1], us.l[1]); }
+        else if constexpr (S == 28) { split2(us.u[1].x, us.u[1].y, us.h[2], us.l[2]); split2(us.u[1].z, us.u[1].w, us.h[3], us.l[3]); }
+        else if constexpr (S == 30) {
+            u32x4 hv, lv;
+            swap4(hv, lv);
+            if (a.out_hi && live && jt < WN && pn0 + 16 * jt + 8 * (g & 1) < climit) {
+                const unsigned off = poff_s1[i] + (unsigned)jp * (unsigned)a.plane_rows * 64u;
+                *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(a.out_hi) + off) = hv;
+                *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(a.out_lo) + off) = lv;
+            }
         }
     };
+    // the NUNIT * NSTEP micro-steps of a tile, dealt evenly over the first eight k-steps of the next tile
+    constexpr int QTOT = NUNIT * NSTEP;
+    constexpr int QPER = (QTOT + 7) / 8;
 
     // One k-step of one wave.  T = tap (regular chunk) or tail step; FIRST: the tile's first chunk, whose k-steps 0 .. NUNIT-1 carry the
     // pending tile's epilogue units.
@@ -1128,7 +1128,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_de_kernel(const Conv3PD
 #ifdef ATMVFI_DE_EXP_NOUNITS
         constexpr bool UNIT = false;             // experiment build: no deferred units at all (wrong results; times the bare k-loop)
 #else
-        constexpr bool UNIT = FIRST && T < NUNIT;
+        constexpr bool UNIT = FIRST && T < 8 && T * QPER < QTOT;
 #endif
         // ---------------- read phase ----------------
         if constexpr (!TAIL) {
@@ -1189,56 +1189,36 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_de_kernel(const Conv3PD
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         // ---------------- MFMA phase ----------------
-        // three passes of 2 WN MFMAs (hi x hi, hi x lo, lo' x hi * 2^-10), each one scheduling region; a k-step that carries an epilogue
-        // unit puts a stage of it into each (present outputs only: uniform branches between the regions)
+        // three passes of 2 WN MFMAs (hi x hi, hi x lo * 2^-10, lo' x hi * 2^-10); MFMA number m of the k-step:
         __builtin_amdgcn_s_setprio(1);
-        auto pass1 = [&]() {
-            static_for<0, WN>([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xh[0], acc[0][j], 0, 0, 0);
-                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xh[1], acc[1][j], 0, 0, 0);
-            });
-        };
-        auto pass2 = [&]() {
-            static_for<0, WN>([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xl[0], acc[0][j], 0, 0, 0);
-                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xl[1], acc[1][j], 0, 0, 0);
-            });
-        };
-        auto pass3 = [&]() {
-            xh[0] = xh[0] * k2m10;      // hi * 2^-10 for the lo'(weights) x hi(activations) product (the weights' lo' stays scaled)
-            xh[1] = xh[1] * k2m10;
-            static_for<0, WN>([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j], xh[0], acc[0][j], 0, 0, 0);
-                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j], xh[1], acc[1][j], 0, 0, 0);
-            });
+        auto mfma_slot = [&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            constexpr int pass = m / (2 * WN), j = (m % (2 * WN)) >> 1, i = m & 1;
+            if constexpr (pass == 2 && j == 0 && i == 0) {
+                xh[0] = xh[0] * k2m10;  // hi * 2^-10 for the lo'(weights) x hi(activations) product (the weights' lo' stays scaled)
+                xh[1] = xh[1] * k2m10;
+            }
+            if constexpr (pass == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xh[i], acc[i][j], 0, 0, 0);
+            else if constexpr (pass == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xl[i], acc[i][j], 0, 0, 0);
+            else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j], xh[i], acc[i][j], 0, 0, 0);
         };
         if constexpr (UNIT) {
-            // one scheduling region: the k-step's 6 WN MFMAs and the unit's arithmetic for EVERY output kind (a launch without the
-            // second sink, say, wastes its ~30 vector instructions: free, the VALU is idle in an MFMA phase; a branch on the output
-            // kinds would cut the region -- and with MFMAs on both of its sides costs ~50 registers)
-            typedef std::integral_constant<int, T> UC;
-            UnitOut uo;
-            __builtin_amdgcn_sched_barrier(0);
-            pass1();
-            pass2();
-            pass3();
-            unit_fold(UC{}, pend, pcst, uo);
-            unit_sink1(UC{}, pcst, uo);
-            unit_sink2(uo);
-            interleave(std::integral_constant<int, 6 * WN>{}, std::integral_constant<int, (150 + 6 * WN - 1) / (6 * WN)>{});
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            unit_store(UC{}, pend, uo, plive, poff_f32, poff_s1, poff_s2, pn0);
+            // micro-steps [T * QPER, (T + 1) * QPER) of the pending tile's epilogue, each behind its MFMA: step k of the k-step goes
+            // behind MFMA floor(k * M / n) (M MFMAs, n steps; several steps behind one MFMA where n > M)
+            constexpr int M = 6 * WN;
+            constexpr int q0 = T * QPER;
+            constexpr int nq = ((T + 1) * QPER < QTOT ? (T + 1) * QPER : QTOT) - q0;
+            static_for<0, M>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                mfma_slot(mc);
+                constexpr int ka = (m * nq + M - 1) / M, kb = ((m + 1) * nq + M - 1) / M;       // steps k with floor(k * M / nq) == m
+                static_for<ka, kb>([&](auto kc) { unit_step(std::integral_constant<int, q0 + decltype(kc)::value>{}, pend, pcst); });
+                __builtin_amdgcn_sched_barrier(0);
+            });
         } else {
-            pass1();
-            pass2();
-            pass3();
-            __builtin_amdgcn_s_setprio(0);
+            static_for<0, 6 * WN>([&](auto mc) { mfma_slot(mc); });
         }
+        __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -1292,13 +1272,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_de_kernel(const Conv3PD
     {
         const float* cst = cst_base + (seq & 1) * CSTF;
         place_pending(img, ox0, oy0, n0, true);
-        static_for<0, NUNIT>([&](auto uc) {
-            UnitOut uo;
-            unit_fold(uc, acc, cst, uo);
-            if (a.out_hi) unit_sink1(uc, cst, uo);
-            if (a.out_hi2) unit_sink2(uo);
-            unit_store(uc, acc, uo, plive, poff_f32, poff_s1, poff_s2, pn0);
-        });
+        static_for<0, QTOT>([&](auto qc) { unit_step(qc, acc, cst); });
     }
 }
 
@@ -1344,8 +1318,9 @@ int launch_planes(const Conv3PDev& d, int ntiles, hipStream_t s) {
         return atmvfi::check_launch("conv3x3_planes (split-K)");
     }
     const int grid = nchunks >= 2 ? std::min(ds.vblocks, atmvfi::cu_count()) : ds.vblocks;
-    if constexpr (WN <= 7) {
-        // workgroups that walk several tiles, each with at least one full chunk: the deferred-epilogue variant (above)
+    if constexpr (WN <= 6) {
+        // workgroups that walk several tiles, each with at least one full chunk: the deferred-epilogue variant (above; its 7-n-tile
+        // instance does not fit the register file: 4-15 spilled registers, i.e. scratch loads inside the counted-vmcnt loop)
         if (d.defer && !d.h2_w && (d.cf >> 5) >= 1 && nchunks >= 2 && grid < ds.vblocks) {
             const hipError_t e2 = atmvfi::allow_dynamic_lds<conv3x3_planes_de_kernel<WN>>(lds);
             ATMVFI_REQUIRE(e2 == hipSuccess, ATMVFI_ELAUNCH, "conv3x3_planes: hipFuncSetAttribute: %s", hipGetErrorString(e2));
@@ -1520,9 +1495,9 @@ static int conv3x3_planes_impl(const void* in_hi, const void* in_lo, int64_t in_
         ATMVFI_REQUIRE(atmvfi::aligned16(out_hi) && atmvfi::aligned16(out_lo) && (!plane_prelu || atmvfi::aligned16(plane_prelu)),
                        ATMVFI_EALIGN, "conv3x3_planes: plane sink pointers must be 16-byte aligned");
     }
-    const bool defer = (wn & 16) == 0;        // bit 4 of wn: keep the two-accumulator kernel (A/B switch, kernel-against-kernel tests)
+    const bool defer = wn >= 0 && (wn & 16) != 0;        // bit 4 of wn: opt in to the deferred-epilogue kernel (experimental, include/atmvfi.h)
     if (wn >= 0) wn &= 15;
-    ATMVFI_REQUIRE(wn >= 0 && wn <= 8, ATMVFI_EINVAL, "conv3x3_planes: wn 0 (auto) or 1..8 (+ 16: no deferred epilogue)");
+    ATMVFI_REQUIRE(wn >= 0 && wn <= 8, ATMVFI_EINVAL, "conv3x3_planes: wn 0 (auto) or 1..8 (+ 16: deferred epilogue)");
     ATMVFI_REQUIRE(out_cmin >= 0 && out_cmin % 4 == 0, ATMVFI_EINVAL, "conv3x3_planes: out_cmin must be a non-negative multiple of 4");
     Conv3PDev d;
     d.in_hi = (const _Float16*)in_hi; d.in_lo = (const _Float16*)in_lo; d.in_rows = in_rows;
