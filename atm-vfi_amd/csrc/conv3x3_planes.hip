@@ -23,7 +23,7 @@
 //   * a ring slot / halo buffer is refilled by a DMA issued at least one barrier after its last reader's lgkmcnt(0).
 // Every wave issues the same number of DMA instructions in every phase (a wave without a piece of its own repeats one), and the
 // k-loop has no branch: the vmcnt waits are immediates.
-#include "conv3_common.h"
+#include "conv3p.h"
 
 #include <stdlib.h>
 
@@ -53,91 +53,7 @@ extern "C" void atmvfi_debug_set_planes_stamp_buffer(void* p) { g_planes_stamp =
 #endif
 
 namespace {
-
-struct Conv3PDev {
-    const _Float16* in_hi;      // input planes, already advanced to the first 32-channel chunk of the view
-    const _Float16* in_lo;
-    long long in_rows;          // plane rows (> N*H*W; row N*H*W of every chunk is zero): chunk stride = in_rows * 32 halves
-    int N, H, W, Cin;
-    const _Float16* w_hi;
-    const _Float16* w_lo;
-    int wrows, cf, tail;
-    int Cout;
-    float* out;                 // optional fp32 NHWC view
-    int out_ld;
-    const float* bias;
-    const float* prelu;
-    _Float16* out_hi;           // optional plane sink (chunk major), channels out_c0 .. out_c0 + Cout
-    _Float16* out_lo;
-    long long plane_rows;
-    int out_c0;
-    const float* plane_prelu;   // optional PReLU applied to the plane copy only (the next layer's leading activation)
-    _Float16* out_hi2;          // optional SECOND plane sink, raw (no PReLU of its own): a decoder map goes on both through the next
-    _Float16* out_lo2;          // stage's leading PReLU (first sink) and as it is (the U-Net's strided convs read it)
-    long long plane_rows2;
-    int out_c02;
-    int out_cmin;               // fp32 output: only channels >= out_cmin (multiple of 4) are stored
-    int tiles_x, tiles_y, nblocks, tchunk;
-    int vblocks;                // virtual blocks (tiles incl. XCD padding) walked by the persistent grid
-    // the tile decode's divisors as multiply-shift pairs (launch_planes: q = (mul_hi(n, m) + n) >> s, exact for n < 2^31): dividing by a
-    // kernel argument costs ~18 scalar instructions, and the decode of a workgroup's next-but-one tile -- five divisions -- sits on the
-    // critical path of every tile boundary (1.3-1.5 k cycles per tile, tools/stamp_conv3p.py)
-    unsigned dm_nblocks, ds_nblocks, dm_perimg, ds_perimg, dm_grp, ds_grp, dm_rows, ds_rows;
-    // split-K (under-filled grids with long K, round 4): gridDim.y = ksplit workgroups per tile; split s takes the cps full chunks from
-    // chunk s * cps on (the last one the rest and the tap-packed tail) and stores its raw fp32 sums at out + s * part_stride; a second
-    // kernel adds the partial sums in split order and runs the epilogue.  1 = off.
-    int ksplit, cps;
-    long long part_stride;
-    // fused read-out (refine_head.0 -> refine_head.1, network_base.py:257-260; WN = 2 or 4, one column block): the tile's activated
-    // output -- still in registers, in the accumulator layout, which IS the B-operand layout of the next MFMA -- is multiplied by the
-    // 27 x Cout matrix W2[(tap, o)][c] of the following 3-output 3x3 convolution; the 27 per-pixel "tap contributions" go to planar
-    // fp32 h2_out[(tap * 3 + o) * h2_plane + pixel] and atmvfi_refine_tail adds each output pixel's nine shifted contributions.
-    const _Float16* h2_w;       // [plane hi / lo][row tile 2][k-step WN/2][lane 64][8 halves], k order = this kernel's register order
-    float* h2_out;
-    long long h2_plane;
-    int defer;                  // 1: multi-tile launches may take conv3x3_planes_de_kernel (wn with bit 4, include/atmvfi.h)
-    unsigned long long* stamp;  // diagnostic builds only (ATMVFI_STAMP)
-    int dbg;                    // diagnostic builds only: ATMVFI_P3_DBG bits switch pieces of the loop off (wrong results, timing only)
-};
-
-constexpr int HALO_PIX = HW_ * HW_;           // 324
-constexpr int HALO_PLANE_PIECES = (HALO_PIX + 15) / 16;     // 21 one-KiB pieces (16 pixel rows x 64 B) per plane, 12 pad rows
-constexpr int HALO_LO = HALO_PLANE_PIECES * 1024;            // byte offset of the lo plane inside a halo buffer
-constexpr int HALO_BYTES = 2 * HALO_LO;
-
-// weight ring depth: as many k-steps as fit beside the two halo buffers and the epilogue constants in 160 KiB, at most 5
-// epilogue constants of a tile in LDS: bias, PReLU slope and the plane sink's own slope for its BN columns (three rows of BN floats)
-constexpr int planes_const_floats(int BN) { return (3 * BN + 63) / 64 * 64; }
-constexpr int ring_slots(int wn) {
-    const int free_bytes = 160 * 1024 - 2 * HALO_BYTES - 2 * planes_const_floats(16 * wn) * 4;     // two halo buffers, two buffers of epilogue constants
-    const int n = free_bytes / (2 * 16 * wn * 64);
-    return n > 5 ? 5 : n;            // the static vmcnt counts of the k-loop assume a lookahead of at most 4 k-steps
-}
-template <int N>
-__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-__device__ __forceinline__ void dma16(const unsigned char* src, unsigned char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
-// One LDS-DMA instruction per wave (4 bytes per lane): cst[c] = bias[n0 + c], cst[BN + c] = slope[n0 + c], cst[2 BN + c] = plane_slope[n0 + c]
-// for the tile's BN columns, 0 / 1 / 1 where an array is absent or the column is past Cout.  (The plane sink's slopes used to be global loads
-// inside the store loop: every one of them made hipcc wait for vmcnt(0), i.e. for the previous n-tile pair's STORES to be acknowledged --
-// the sink epilogue of a 112-column tile took 9.4 k cycles against 5.1 k for fp32 rows, tools/stamp_conv3p.py.)
-template <int BN>
-__device__ __forceinline__ void dma_planes_consts(const float* bias, const float* slope, const float* plane_slope, int Cout, int n0, float* cst,
-                                                  int wave, int lane) {
-    constexpr int NPIECE = (3 * BN + 63) / 64;
-    static_assert(NPIECE <= 8, "one piece per wave");
-    const int piece = wave % NPIECE;
-    const int t = piece * 64 + lane;
-    const int row = t / BN;
-    const int col = n0 + t - row * BN;
-    const float* src = row == 0 ? bias : row == 1 ? slope : plane_slope;
-    const float* p = (src && row < 3 && col < Cout) ? src + col : &kEpilogueDefaults[row == 0 ? 0 : 1];
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
-                                     (__attribute__((address_space(3))) void*)(cst + piece * 64), 4, 0, 0);
-}
+using namespace atmvfi;
 
 template <int WN>
 __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev a) {
@@ -759,523 +675,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_planes_kernel(const Conv3PDev 
 #endif
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------------
-// DEFERRED-EPILOGUE variant (round 4).  conv3x3_planes_kernel stops the matrix pipes at every tile boundary: both wave groups run their
-// epilogues -- VALU-bound, 4.7 k + 7.3 k cycles of a 55 k-cycle 112-column tile with a plane sink (tools/stamp_conv3p.py) -- and nothing
-// else can run, because all 256 registers of a wave hold the two accumulator sets of the f16x3 arithmetic (acc: hi x hi, cor: the two
-// cross products, folded as acc + cor / 1024).  Here the three products of a k-step go into ONE fp32 accumulator: the activation
-// fragments of the cross products are scaled by 2^-10 in registers first (hi for the weights' lo' x hi product, lo' for hi x lo':
-// 16 v_pk_mul_f16 per k-step; the results are fp16 subnormals for |x| < 2^-4, which gfx950's matrix cores keep:
-// tools/probes/mfma_denorm_probe.hip; tools/sim_single_acc.py: as exact as the two-accumulator fold for activations of ordinary size,
-// 5e-8 absolute for |x| ~ 1e-3).  The freed registers hold the PREVIOUS tile's sums, and that tile's epilogue runs unit by unit
-// (n-tile pair x pixel row: ~130 VALU instructions, 10 stores) inside the MFMA phases of the current tile's first eight k-steps,
-// interleaved with the MFMAs by sched_group_barrier -- the matrix pipe accepts an instruction every 16 cycles, the VALU is idle during
-// an MFMA phase (the SIMD partner is in its read phase).  The k-loop then runs from tile to tile without a boundary: no extra barrier,
-// no wait; every store instruction is issued unconditionally (absent outputs and dead lanes through EXEC = 0), so the counted vmcnt
-// waits stay immediates.  Not bit-identical to conv3x3_planes_kernel (fp32 summation of the three products), same tolerance class.
-// Launcher: 1-7 n-tiles, at least one full chunk, no split-K, no fused read-out (those stay on conv3x3_planes_kernel).
-template <int WN>
-__global__ __launch_bounds__(512, 1) void conv3x3_planes_de_kernel(const Conv3PDev a) {
-    fp16_saturate_on();
-    constexpr int BN = 16 * WN;
-    constexpr int WSLOT = 2 * BN * 64;                  // bytes of one ring slot: [hi BN rows][lo BN rows] x 64 B
-    constexpr int SW = (2 * WN + 7) / 8;                // weight pieces per wave and k-step (some waves one fewer)
-    constexpr int NB = ring_slots(WN);                  // weight ring slots (k-steps)
-    constexpr int LA = NB - 1;                          // k-steps between a slot's DMA issue and its first read
-    constexpr int CSTF = planes_const_floats(BN);
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const unsigned halo0 = lds_offset(smem);                        // two halo buffers
-    const unsigned ring0 = halo0 + 2 * HALO_BYTES;                  // NB weight slots
-    float* cst_base = reinterpret_cast<float*>(smem + 2 * HALO_BYTES + NB * WSLOT);     // two buffers of epilogue constants
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2;
-    const int r = lane & 15;
-    const int g = lane >> 4;
-
-    // (no split-K in this variant: the launcher keeps split launches on conv3x3_planes_kernel)
-    const _Float16* in_hi = a.in_hi;
-    const _Float16* in_lo = a.in_lo;
-    const _Float16* w_hi = a.w_hi;
-    const _Float16* w_lo = a.w_lo;
-    float* out_f32 = a.out;
-    const int nfull = a.cf >> 5;          // >= 1 (launcher)
-    const int ktail = a.tail;
-    // PERSISTENT GRID over the XCD-aware tile order (conv3x3_f16x3_row.hip): virtual block v -> column blocks of one tile back to
-    // back on one XCD, each XCD walking a contiguous eighth of the tiles in groups of 8 tile rows, column by column.  Workgroup b
-    // walks v = b, b + grid, ... (grid a multiple of 8: it stays on its XCD; the tile index only grows along the walk, so the first
-    // empty block ends it).  The DMA streams keep flowing across tiles: the slots that re-sent the last weights / the current halo
-    // "into buffers nobody reads" at the end of a tile now carry the NEXT tile's first k-steps and its first halo, so a tile's
-    // prologue (first DMA round trip + address arithmetic, 6.5 % of a 101-wide full-resolution tile) runs under the previous
-    // tile's last k-steps.
-    const int grid = gridDim.x;
-    const int per_img = a.tiles_x * a.tiles_y;
-    auto fdiv = [](int n, unsigned m, unsigned sh) -> int { return (int)((__umulhi((unsigned)n, m) + (unsigned)n) >> sh); };
-    auto decode = [&](int v, int& t_img, int& t_ox0, int& t_oy0, int& t_n0) -> bool {
-        int sgrp, nblk, L;
-        if (a.ksplit > 1) {
-            // split-K launches have fewer tiles than CUs: plain order (tile = v / nblocks), so that the workgroups -- dealt round-robin
-            // over the XCDs -- spread over the whole chip instead of filling the first eighths of the XCD-aware order
-            sgrp = fdiv(v, a.dm_nblocks, a.ds_nblocks);
-            nblk = v - sgrp * a.nblocks;
-            L = sgrp;
-        } else {
-            const int slot = v >> 3;
-            sgrp = fdiv(slot, a.dm_nblocks, a.ds_nblocks);
-            nblk = slot - sgrp * a.nblocks;
-            L = (v & 7) * a.tchunk + sgrp;
-        }
-        if (v >= a.vblocks || L >= a.N * per_img) return false;
-        t_img = fdiv(L, a.dm_perimg, a.ds_perimg);
-        L -= t_img * per_img;
-        const int tgrp = fdiv(L, a.dm_grp, a.ds_grp);              // groups of 8 tile rows
-        const int rem = L - tgrp * 8 * a.tiles_x;
-        const bool full = a.tiles_y - 8 * tgrp >= 8;
-        const int rows_here = full ? 8 : a.tiles_y - 8 * tgrp;     // (the last group of a map may be shorter: tiles_y mod 8 rows)
-        const int txb = full ? rem >> 3 : fdiv(rem, a.dm_rows, a.ds_rows);
-        const int tyb = 8 * tgrp + (rem - txb * rows_here);
-        t_ox0 = txb * TW;
-        t_oy0 = tyb * 16;
-        t_n0 = nblk * BN;
-        return true;
-    };
-    int vb = blockIdx.x;
-    int img, ox0, oy0, n0;                       // the tile of the MFMAs / of the epilogue
-    if (!decode(vb, img, ox0, oy0, n0)) return;
-    int nimg = 0, nox0 = 0, noy0 = 0, nn0 = 0;   // this workgroup's next tile
-    bool has_next = decode(vb + grid, nimg, nox0, noy0, nn0);
-
-    // ---- halo pieces of this wave: k = wave + 8 s, s = 0..5 (k < 42): pieces 0..20 = hi plane, 21..41 = lo plane, each plane
-    // a linear image of 336 pixel rows x 64 B (324 used).  Lane -> pixel row hp = 16 (k % 21) + lane / 4, physical 16-byte slot
-    // lane & 3; the slot swizzle goes on the SOURCE (the DMA destination is lane-linear).  hoff = byte offset from the plane base
-    // of the chunk; pixels outside the image (and the 12 pad rows) read the planes' zero row N*H*W.  hoff belongs to the tile
-    // whose halo is being put in flight: the tile of the MFMAs or, towards its end, the next one.
-    unsigned hoff[6];
-    const long long zero_row = (long long)a.N * a.H * a.W;
-    auto setup_halo = [&](int t_img, int t_ox0, int t_oy0) {
-        // (the lane index laundered through an empty asm: the per-lane halo coordinates of the six pieces are tile-invariant, and
-        // hipcc otherwise hoists them out of the tile loop -- 30 more live registers across the k-loop, spills at 8 n-tiles)
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
-#pragma unroll
-        for (int s = 0; s < 6; ++s) {
-            int k = wave + 8 * s;
-            if (k >= 2 * HALO_PLANE_PIECES) k -= 8;      // waves 2..7 have no sixth piece: they send their fifth twice (see below)
-            const int kp = k >= HALO_PLANE_PIECES ? k - HALO_PLANE_PIECES : k;
-            const int hp = 16 * kp + (ln >> 2);
-            const int hy = hp / HW_, hx = hp - hy * HW_;
-            const int iy = t_oy0 - 1 + hy, ix = t_ox0 - 1 + hx;
-            const bool ok = hp < HALO_PIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            const int ls = (ln & 3) ^ swz64(hp);
-            const long long row = ok ? ((long long)t_img * a.H + iy) * a.W + ix : zero_row;
-            hoff[s] = (unsigned)(row * 64 + ls * 16);
-        }
-    };
-    setup_halo(img, ox0, oy0);
-    const long long chunk_bytes = a.in_rows * 64;
-    // ---- DMA schedule.  Everything in the k-loop is branch-free and the same for every wave, so that the vmcnt waits are plain
-    // immediates: a taken scalar branch costs 20-40 cycles and the first version of this loop had ten per read phase (validity
-    // of a piece, end of the k-steps, a decision tree around s_waitcnt: 230 ticks of a 900-tick phase, tools/stamp_conv3p.py).
-    //   * weights: SW pieces per wave and k-step; piece idx = wave + 8 s -> plane idx / WN, row group idx % WN (16 rows x 64 B =
-    //     one contiguous KiB of the k-step-major planes).  A wave without a piece s (idx >= 2 WN) sends its piece s - 1 again:
-    //     same bytes to the same place.  Behind a tile's last k-step come the first k-steps of the workgroup's next tile (or,
-    //     after the last tile, the last k-step again into ring slots nobody reads any more).
-    //   * halo of the next chunk: piece wave + 8 t in k-step t = 0..5 (tail k-steps 0 and 1: three pieces each); behind a tile's
-    //     last chunk comes chunk 0 of the next tile (after the last tile: the current chunk again into the idle buffer).
-    // LDS row i of a 16-row group <- weight row 8 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3): rows 4g..4g+3 of the MFMA result are
-    // then channels {0, 8, 4, 12}[g] .. + 3 (see the epilogue)
-    const int wrow = 8 * ((lane >> 4) & 1) + 4 * (lane >> 5) + ((lane >> 2) & 3);
-    const unsigned wlane = (unsigned)(wrow * 64 + (((lane & 3) ^ swz64(lane >> 2)) << 4));
-    const long long step_bytes = (long long)a.wrows * 64;
-    const unsigned char* wsrc[SW];          // wave-uniform source of piece s at the next k-step to issue
-    const unsigned char* wnext[SW];         // the same at k-step 0 of the workgroup's next tile
-    int wdst[SW];                           // its byte offset inside a ring slot
-    auto weight_base = [&](int s, int t_n0) -> const unsigned char* {
-        int idx = wave + 8 * s;
-        if (idx >= 2 * WN) idx -= 8;
-        const int ic = idx >= 0 ? idx : 0;                       // (WN < 4: waves >= 2 WN have no piece at all and send piece 0)
-        const int icc = ic < 2 * WN ? ic : 0;
-        const int plane = icc >= WN ? 1 : 0;
-        const int j = icc - plane * WN;
-        int rg = t_n0 + 16 * j;
-        if (rg >= a.wrows) rg = a.wrows - 16;                    // row groups past the packed rows: columns never stored
-        return reinterpret_cast<const unsigned char*>(plane ? w_lo : w_hi) + (long long)rg * 64;
-    };
-#pragma unroll
-    for (int s = 0; s < SW; ++s) {
-        int idx = wave + 8 * s;
-        if (idx >= 2 * WN) idx -= 8;
-        const int ic = idx >= 0 ? idx : 0;
-        const int icc = ic < 2 * WN ? ic : 0;
-        const int plane = icc >= WN ? 1 : 0;
-        const int j = icc - plane * WN;
-        wsrc[s] = weight_base(s, n0);
-        wnext[s] = weight_base(s, nn0);
-        wdst[s] = (plane * BN + 16 * j) * 64;
-    }
-
-    const int nchunks = nfull + (ktail ? 1 : 0);
-    const int nk = 9 * nfull + (ktail ? 3 : 0);
-
-    int wr_off = 0;                       // ring slot (byte offset) the next weight issue goes to
-    int kleft = nk - 1;                   // k-steps of the issuer's tile after the one whose weights are issued next
-    auto issue_weights = [&]() {          // weights of the next k-step -> next ring slot
-        unsigned char* dst = smem + 2 * HALO_BYTES + wr_off;
-        const bool more = kleft > 0;
-#pragma unroll
-        for (int s = 0; s < SW; ++s) {
-            dma16(wsrc[s] + wlane, dst + wdst[s]);
-            wsrc[s] = more ? wsrc[s] + step_bytes : (has_next ? wnext[s] : wsrc[s]);       // (scalar selects: no branch)
-        }
-        kleft = more ? kleft - 1 : (has_next ? nk - 1 : 0);
-        wr_off = wr_off + WSLOT == NB * WSLOT ? 0 : wr_off + WSLOT;
-    };
-    const unsigned char* hsrc_hi = reinterpret_cast<const unsigned char*>(in_hi);      // plane bases of the chunk whose halo is issued next
-    const unsigned char* hsrc_lo = reinterpret_cast<const unsigned char*>(in_lo);
-    int hbuf = 0;                         // halo buffer (byte offset) that chunk goes to
-    auto issue_halo = [&](auto sc) {      // halo piece wave + 8 S (waves 2..7, S = 5: piece wave + 32 again)
-        constexpr int S = decltype(sc)::value;
-        int k = wave + 8 * S;
-        if (S == 5 && k >= 2 * HALO_PLANE_PIECES) k -= 8;
-        dma16((k >= HALO_PLANE_PIECES ? hsrc_lo : hsrc_hi) + hoff[S], smem + hbuf + k * 1024);
-    };
-    int chunks_left = nchunks - 1;        // chunks of the issuer's tile after the one whose halo is issued next
-    // all six pieces of a chunk are out: on to the tile's next chunk, to chunk 0 of the next tile, or (after the last tile) nowhere
-    auto halo_advance = [&]() {
-        if (chunks_left > 0) {
-            hsrc_hi += chunk_bytes;
-            hsrc_lo += chunk_bytes;
-            --chunks_left;
-        } else if (has_next) {
-            hsrc_hi = reinterpret_cast<const unsigned char*>(in_hi);
-            hsrc_lo = reinterpret_cast<const unsigned char*>(in_lo);
-            setup_halo(nimg, nox0, noy0);
-            chunks_left = nchunks - 1;
-        }
-        hbuf = HALO_BYTES - hbuf;
-    };
-
-    f32x4 acc[2][WN], pend[2][WN];
-
-    // tail k-steps: lane group g reads slot 0 of the halo pixel of tap 4t + g (taps 9..11 meet zero weights: tap 8 again)
-    int dtail = 0;
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        const int tap = (4 * t + g) < 9 ? 4 * t + g : 8;
-        const int ty = tap / 3;
-        dtail |= (ty * HW_ + (tap - 3 * ty)) << (8 * t);
-    }
-
-    // ---- prologue: halo of chunk 0, weights of k-steps 0 .. LA-1 (the first tile's epilogue constants go out at the top of the tile loop,
-    // like every tile's: the counted waits of a tile's first k-steps count that piece) ----
-    static_for<0, 6>([&](auto sc) { issue_halo(sc); });
-    halo_advance();
-#pragma unroll
-    for (int u = 0; u < LA; ++u) issue_weights();
-    wait_vm<0>();
-    __builtin_amdgcn_s_barrier();
-    if (grp == 1) __builtin_amdgcn_s_barrier();          // the second group runs one phase behind
-
-    f16x8 xh[2], xl[2], wh[WN], wl[WN];
-    const unsigned wfrag = ring0 + (unsigned)(r * 64 + ((g ^ swz64(r)) << 4));
-    const int prow = 2 * wave * HW_ + r;
-    unsigned xa[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) xa[k] = halo0 + (unsigned)(prow * 64 + ((g ^ swz64(prow + k)) << 4));
-    int rd_off = 0;
-    int hcur = 0;
-    int seq = 0;
-
-    // ---- the PENDING tile: its sums (pend), which constants buffer holds its bias / slopes, and per lane where its outputs go.  Its
-    // epilogue runs one unit (n-tile pair jp, pixel row i) per k-step of the current tile's first chunk, inside the MFMA phase.
-    const float* pcst = cst_base;
-    int pn0 = 0;
-    const int cb = 8 * (g & 1) + 4 * (g >> 1);
-    const int climit = (a.Cout + 7) & ~7;
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    // per lane and pixel row i: is the pixel inside the image (and is there a pending tile at all); byte offsets of (pixel, first channel
-    // of the lane) in the fp32 rows and in the two sinks' planes -- n-tile pair jp then adds 128 bytes / jp chunks (32-bit offsets from
-    // scalar bases: the launcher guarantees every output stays under 4 GiB)
-    unsigned plive = 0u;              // bit i: pixel row i of the lane is inside the image (and a tile is pending)
-    unsigned poff_f32[2] = {0u, 0u}, poff_s1[2] = {0u, 0u}, poff_s2[2] = {0u, 0u};
-    auto place_pending = [&](int simg, int sox0, int soy0, int sn0, bool valid) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int oy = soy0 + 2 * wave + i, ox = sox0 + r;
-            const bool lv_ = valid && oy < a.H && ox < a.W;
-            plive = i == 0 ? (lv_ ? 1u : 0u) : plive | (lv_ ? 2u : 0u);
-            const unsigned prow_o = lv_ ? (unsigned)((simg * a.H + oy) * a.W + ox) : 0u;
-            poff_f32[i] = (prow_o * (unsigned)a.out_ld + (unsigned)(sn0 + cb)) * 4u;
-            const int cs = sn0 + (g < 2 ? 0 : 16) + 8 * (g & 1);          // first of the 8 channels this lane stores for n-tile pair 0
-            const int c1 = a.out_c0 + cs, c2 = a.out_c02 + cs;
-            poff_s1[i] = (((unsigned)(c1 >> 5) * (unsigned)a.plane_rows + prow_o) * 32u + (unsigned)(c1 & 31)) * 2u;
-            poff_s2[i] = (((unsigned)(c2 >> 5) * (unsigned)a.plane_rows2 + prow_o) * 32u + (unsigned)(c2 & 31)) * 2u;
-        }
-        pn0 = sn0;
-    };
-    // ---- A unit's work as a list of MICRO-STEPS of 2-8 instructions, executed one behind each MFMA of the carrying k-steps with a
-    // scheduling fence in between (hipcc's own interleaving -- sched_group_barrier -- leaves the MFMAs in a block here; the matrix pipe
-    // takes an instruction every 16 cycles, so ~4 vector instructions behind each MFMA are free: the SIMD partner is in its read phase).
-    // The state between steps lives in registers; a unit may span k-steps (narrow tiles: fewer MFMAs per k-step).
-    constexpr int NUNIT = 2 * ((WN + 1) / 2);
-    constexpr int NSTEP = 31;                     // micro-steps per unit
-    struct UnitState {
-        f32x4 c;                      // the constant vector in flight (bias / slope of an n-tile), requested three steps before its use
-        f32x4 v[2];                   // after bias + PReLU
-        f32x4 u[2];                   // slope x value; through the first sink's own PReLU
-        unsigned h[4], l[4];          // split halves (two dwords per n-tile and plane) before the cross-half swap
-    };
-    UnitState us;
-    auto unit_step = [&](auto qc, const f32x4 (&src)[2][WN], const float* scst) {
-        constexpr int Q = decltype(qc)::value;
-        constexpr int U = Q / NSTEP, S = Q % NSTEP;
-        constexpr int jp = U >> 1, i = U & 1;
-        constexpr int j0 = 2 * jp, j1 = (2 * jp + 1 < WN) ? 2 * jp + 1 : 2 * jp;
-        constexpr bool has_j1 = 2 * jp + 1 < WN;
-        // dst.xy (LO) or dst.zw = v > 0 ? v : t on that half
-        auto sel_lo = [](f32x4& d, const f32x4 v, const f32x4 t) { const float x = v.x > 0.f ? v.x : t.x, y = v.y > 0.f ? v.y : t.y; d.x = x; d.y = y; };
-        auto sel_hi = [](f32x4& d, const f32x4 v, const f32x4 t) { const float z = v.z > 0.f ? v.z : t.z, w = v.w > 0.f ? v.w : t.w; d.z = z; d.w = w; };
-        auto split2 = [](float x, float y, unsigned& hh, unsigned& ll) {
-            const f16x2 ha = __builtin_convertvector((f32x2){x, y}, f16x2);
-            const f16x2 la = __builtin_convertvector(((f32x2){x, y} - __builtin_convertvector(ha, f32x2)) * 1024.0f, f16x2);
-            hh = __builtin_bit_cast(unsigned, ha);
-            ll = __builtin_bit_cast(unsigned, la);
-        };
-        auto swap4 = [&](u32x4& hv, u32x4& lv) {
-            const auto sh0 = __builtin_amdgcn_permlane32_swap(us.h[0], us.h[2], false, false);
-            const auto sh1 = __builtin_amdgcn_permlane32_swap(us.h[1], us.h[3], false, false);
-            const auto sl0 = __builtin_amdgcn_permlane32_swap(us.l[0], us.l[2], false, false);
-            const auto sl1 = __builtin_amdgcn_permlane32_swap(us.l[1], us.l[3], false, false);
-            hv = (u32x4){sh0[0], sh1[0], sh0[1], sh1[1]};
-            lv = (u32x4){sl0[0], sl1[0], sl0[1], sl1[1]};
-        };
-        auto ld = [&](int off) { us.c = *reinterpret_cast<const f32x4*>(scst + off + cb); };
-        const int jt = g < 2 ? j0 : 2 * jp + 1;
-        const bool live = (plive >> i) & 1;
-        if constexpr (S == 0) ld(16 * j0);                                        // bias of the first n-tile
-        else if constexpr (S == 3) { us.v[0] = src[i][j0] + us.c; ld(16 * j1); }
-        else if constexpr (S == 6) { us.v[1] = src[i][j1] + us.c; ld(BN + 16 * j0); }           // slopes (an absent array reads 1.0)
-        else if constexpr (S == 9) { us.u[0] = us.c * us.v[0]; ld(BN + 16 * j1); }
-        else if constexpr (S == 10) sel_lo(us.v[0], us.v[0], us.u[0]);
-        else if constexpr (S == 11) sel_hi(us.v[0], us.v[0], us.u[0]);
-        else if constexpr (S == 12) { us.u[1] = us.c * us.v[1]; ld(2 * BN + 16 * j0); }          // the first sink's own slopes
-        else if constexpr (S == 13) sel_lo(us.v[1], us.v[1], us.u[1]);
-        else if constexpr (S == 14) sel_hi(us.v[1], us.v[1], us.u[1]);
-        else if constexpr (S == 15) {              // fp32 rows: this unit's two vectors (from out_cmin on; a ragged last group by elements)
-            if (out_f32) {
-#pragma unroll
-                for (int e = 0; e < (has_j1 ? 2 : 1); ++e) {
-                    const int co = pn0 + 16 * (j0 + e) + cb;
-                    const int nvalid = a.Cout - co;
-                    float* p = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(out_f32) + poff_f32[i]) + 16 * (j0 + e);
-                    if (live && co + 4 > a.out_cmin) {
-                        if (nvalid >= 4) {
-                            *reinterpret_cast<f32x4*>(p) = us.v[e];
-                        } else if (nvalid > 0) {
-                            p[0] = us.v[e].x;
-                            if (nvalid > 1) p[1] = us.v[e].y;
-                            if (nvalid > 2) p[2] = us.v[e].z;
-                        }
-                    }
-                }
-            }
-        }
-        else if constexpr (S == 16) { us.u[0] = us.c * us.v[0]; ld(2 * BN + 16 * j1); }
-        else if constexpr (S == 17) split2(us.v[0].x, us.v[0].y, us.h[0], us.l[0]);               // second sink: the raw values
-        else if constexpr (S == 18) split2(us.v[0].z, us.v[0].w, us.h[1], us.l[1]);
-        else if constexpr (S == 19) split2(us.v[1].x, us.v[1].y, us.h[2], us.l[2]);
-        else if constexpr (S == 20) split2(us.v[1].z, us.v[1].w, us.h[3], us.l[3]);
-        else if constexpr (S == 21) {
-            u32x4 hv, lv;
-            swap4(hv, lv);
-            if (a.out_hi2 && live && jt < WN && pn0 + 16 * jt + 8 * (g & 1) < climit) {
-                const unsigned off = poff_s2[i] + (unsigned)jp * (unsigned)a.plane_rows2 * 64u;
-                *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(a.out_hi2) + off) = hv;
-                *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(a.out_lo2) + off) = lv;
-            }
-        }
-        else if constexpr (S == 22) us.u[1] = us.c * us.v[1];
-        else if constexpr (S == 23) sel_lo(us.u[0], us.v[0], us.u[0]);                            // first sink: through its own PReLU
-        else if constexpr (S == 24) sel_hi(us.u[0], us.v[0], us.u[0]);
-        else if constexpr (S == 25) sel_lo(us.u[1], us.v[1], us.u[1]);
-        else if constexpr (S == 26) sel_hi(us.u[1], us.v[1], us.u[1]);
-        else if constexpr (S == 27) { split2(us.u[0].x, us.u[0].y, us.h[0], us.l[0]); split2(us.u[0].z, us.u[0].w, us.h[1], us.l[1]); }
-        else if constexpr (S == 28) { split2(us.u[1].x, us.u[1].y, us.h[2], us.l[2]); split2(us.u[1].z, us.u[1].w, us.h[3], us.l[3]); }
-        else if constexpr (S == 30) {
-            u32x4 hv, lv;
-            swap4(hv, lv);
-            if (a.out_hi && live && jt < WN && pn0 + 16 * jt + 8 * (g & 1) < climit) {
-                const unsigned off = poff_s1[i] + (unsigned)jp * (unsigned)a.plane_rows * 64u;
-                *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(a.out_hi) + off) = hv;
-                *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(a.out_lo) + off) = lv;
-            }
-        }
-    };
-    // the NUNIT * NSTEP micro-steps of a tile, dealt evenly over the first eight k-steps of the next tile
-    constexpr int QTOT = NUNIT * NSTEP;
-    constexpr int QPER = (QTOT + 7) / 8;
-
-    // One k-step of one wave.  T = tap (regular chunk) or tail step; FIRST: the tile's first chunk, whose k-steps 0 .. NUNIT-1 carry the
-    // pending tile's epilogue units.
-    const f16x8 k2m10 = {(_Float16)0.0009765625f, (_Float16)0.0009765625f, (_Float16)0.0009765625f, (_Float16)0.0009765625f,
-                         (_Float16)0.0009765625f, (_Float16)0.0009765625f, (_Float16)0.0009765625f, (_Float16)0.0009765625f};
-    auto kstep = [&](auto tc, auto tailc, auto firstc) {
-        constexpr int T = decltype(tc)::value;
-        constexpr bool TAIL = decltype(tailc)::value;
-        constexpr bool FIRST = decltype(firstc)::value;
-#ifdef ATMVFI_DE_EXP_NOUNITS
-        constexpr bool UNIT = false;             // experiment build: no deferred units at all (wrong results; times the bare k-loop)
-#else
-        constexpr bool UNIT = FIRST && T < 8 && T * QPER < QTOT;
-#endif
-        // ---------------- read phase ----------------
-        if constexpr (!TAIL) {
-            constexpr int C0 = (T / 3) * HW_ + T % 3, C1 = C0 + HW_;
-            lds_read16<64 * C0>(xh[0], xa[C0 & 7]);
-            lds_read16<64 * C0 + HALO_LO>(xl[0], xa[C0 & 7]);
-            lds_read16<64 * C1>(xh[1], xa[C1 & 7]);
-            lds_read16<64 * C1 + HALO_LO>(xl[1], xa[C1 & 7]);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int p = prow + i * HW_ + ((dtail >> (8 * T)) & 0xff);
-                const unsigned addr = halo0 + (unsigned)hcur + (unsigned)(p * 64 + (swz64(p) << 4));
-                lds_read16<0>(xh[i], addr);
-                lds_read16<HALO_LO>(xl[i], addr);
-            }
-        }
-        const unsigned wa = wfrag + (unsigned)rd_off;
-        static_for<0, WN>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            lds_read16<j * 1024>(wh[j], wa);
-            lds_read16<j * 1024 + BN * 64>(wl[j], wa);
-        });
-        rd_off = rd_off + WSLOT == NB * WSLOT ? 0 : rd_off + WSLOT;
-        issue_weights();
-        if constexpr (!TAIL && T < 6) issue_halo(std::integral_constant<int, T>{});
-        if constexpr (TAIL && T < 2) {
-            issue_halo(std::integral_constant<int, 3 * T>{});
-            issue_halo(std::integral_constant<int, 3 * T + 1>{});
-            issue_halo(std::integral_constant<int, 3 * T + 2>{});
-        }
-        // Own pieces of the next k-step landed.  Behind its weights (issued LA - 1 read phases ago) went SW weight pieces per phase, the
-        // halo pieces of the phases T + 1 - LA .. T of this chunk and -- first LA - 1 k-steps of a tile -- the tile's constants piece.
-        // What the previous tile's last phases issued besides their weights (the three-piece halo issues of tail steps) is not counted,
-        // nor are the epilogue units' stores: counting fewer operations than are behind only waits longer.
-        {
-            constexpr int lo = T + 1 - LA > 0 ? T + 1 - LA : 0;
-            constexpr int hi = T < 5 ? T : 5;
-            constexpr int halos = !TAIL ? (hi >= lo ? hi - lo + 1 : 0) : (lo <= 0 ? 3 : 0) + ((lo <= 1 && T >= 1) ? 3 : 0);
-            constexpr int consts = (FIRST && T < LA - 1) ? 1 : 0;
-            // The LAST k-step of a chunk is also where the next chunk's halo has to be complete (the next read phase starts with it): only
-            // what was issued after its last piece may stay in flight -- the weights of taps 6, 7, 8 behind a regular chunk's tap-5 piece
-            // (at least LA - 1 phases of them), the weights of tail step 2 behind the three pieces of tail step 1.  (With a lookahead of
-            // 4 k-steps the window formula alone lets the tap-5 piece stay in flight over the chunk boundary, and all six pieces of the
-            // tail steps over a tile boundary -- there conv3x3_planes_kernel has its wait_vm<1>, this kernel has no boundary.)
-            constexpr int N = (!TAIL && T == 8) ? (LA - 1) * SW : (TAIL && T == 2) ? SW : (LA - 1) * SW + halos + consts;
-            wait_vm<N>();
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(xh[0]), "+v"(xh[1]), "+v"(xl[0]), "+v"(xl[1]));
-#pragma unroll
-        for (int j = 0; j < WN; ++j) asm volatile("" : "+v"(wh[j]), "+v"(wl[j]));
-        // lo' planes carry (x - hi) * 1024: scaled back here, in fp16 (subnormals are kept by the matrix cores:
-        // tools/probes/mfma_denorm_probe.hip), so that all three products of a k-step go into ONE accumulator
-        xl[0] = xl[0] * k2m10;
-        xl[1] = xl[1] * k2m10;
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        // ---------------- MFMA phase ----------------
-        // three passes of 2 WN MFMAs (hi x hi, hi x lo * 2^-10, lo' x hi * 2^-10); MFMA number m of the k-step:
-        __builtin_amdgcn_s_setprio(1);
-        auto mfma_slot = [&](auto mc) {
-            constexpr int m = decltype(mc)::value;
-            constexpr int pass = m / (2 * WN), j = (m % (2 * WN)) >> 1, i = m & 1;
-            if constexpr (pass == 2 && j == 0 && i == 0) {
-                xh[0] = xh[0] * k2m10;  // hi * 2^-10 for the lo'(weights) x hi(activations) product (the weights' lo' stays scaled)
-                xh[1] = xh[1] * k2m10;
-            }
-            if constexpr (pass == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xh[i], acc[i][j], 0, 0, 0);
-            else if constexpr (pass == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xl[i], acc[i][j], 0, 0, 0);
-            else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j], xh[i], acc[i][j], 0, 0, 0);
-        };
-        if constexpr (UNIT) {
-            // micro-steps [T * QPER, (T + 1) * QPER) of the pending tile's epilogue, each behind its MFMA: step k of the k-step goes
-            // behind MFMA floor(k * M / n) (M MFMAs, n steps; several steps behind one MFMA where n > M)
-            constexpr int M = 6 * WN;
-            constexpr int q0 = T * QPER;
-            constexpr int nq = ((T + 1) * QPER < QTOT ? (T + 1) * QPER : QTOT) - q0;
-            static_for<0, M>([&](auto mc) {
-                constexpr int m = decltype(mc)::value;
-                mfma_slot(mc);
-                constexpr int ka = (m * nq + M - 1) / M, kb = ((m + 1) * nq + M - 1) / M;       // steps k with floor(k * M / nq) == m
-                static_for<ka, kb>([&](auto kc) { unit_step(std::integral_constant<int, q0 + decltype(kc)::value>{}, pend, pcst); });
-                __builtin_amdgcn_sched_barrier(0);
-            });
-        } else {
-            static_for<0, 6 * WN>([&](auto mc) { mfma_slot(mc); });
-        }
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto next_chunk = [&]() {
-        const int d = hcur ? -HALO_BYTES : HALO_BYTES;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) xa[k] += d;
-        hcur += d;
-        halo_advance();
-    };
-
-    for (;;) {
-        float* cst = cst_base + (seq & 1) * CSTF;
-        // (all of this sits in the wave's read-phase slot of the tile's first k-step: the SIMD partner is in its last MFMA phase of the
-        // previous tile.)  This tile's constants: needed a whole tile from now, by its deferred epilogue.
-        dma_planes_consts<BN>(a.bias, a.prelu, a.plane_prelu, a.Cout, n0, cst, wave, lane);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < WN; ++j) {
-                pend[i][j] = acc[i][j];
-                acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                asm volatile("" : "+v"(acc[i][j]), "+v"(pend[i][j]));
-            }
-        static_for<0, 9>([&](auto tc) { kstep(tc, std::false_type{}, std::true_type{}); });
-        next_chunk();
-        for (int c = 1; c < nfull; ++c) {
-            static_for<0, 9>([&](auto tc) { kstep(tc, std::false_type{}, std::false_type{}); });
-            next_chunk();
-        }
-        if (ktail) {
-            static_for<0, 3>([&](auto tc) { kstep(tc, std::true_type{}, std::false_type{}); });
-            next_chunk();
-        }
-        if (!has_next) break;
-        // on to the next tile without a pause: its first halo and its first LA k-steps of weights are in LDS or on their way
-        place_pending(img, ox0, oy0, n0, true);
-        pcst = cst;
-        vb += grid;
-        img = nimg; ox0 = nox0; oy0 = noy0; n0 = nn0;
-        ++seq;
-        has_next = decode(vb + grid, nimg, nox0, noy0, nn0);
-#pragma unroll
-        for (int s = 0; s < SW; ++s) wnext[s] = weight_base(s, nn0);
-    }
-    // ---- the last tile's epilogue, in the open: the first group waits for the second one's last MFMA phase, everything in flight (the
-    // tile's constants among it) lands, then the units one after the other
-    if (grp == 0) __builtin_amdgcn_s_barrier();
-    wait_vm<0>();
-    {
-        const float* cst = cst_base + (seq & 1) * CSTF;
-        place_pending(img, ox0, oy0, n0, true);
-        static_for<0, QTOT>([&](auto qc) { unit_step(qc, acc, cst); });
-    }
-}
-
 template <int WN>
 int launch_planes(const Conv3PDev& d, int ntiles, hipStream_t s) {
     constexpr int BN = 16 * WN;
@@ -1318,14 +717,11 @@ int launch_planes(const Conv3PDev& d, int ntiles, hipStream_t s) {
         return atmvfi::check_launch("conv3x3_planes (split-K)");
     }
     const int grid = nchunks >= 2 ? std::min(ds.vblocks, atmvfi::cu_count()) : ds.vblocks;
-    if constexpr (WN <= 6) {
-        // workgroups that walk several tiles, each with at least one full chunk: the deferred-epilogue variant (above; its 7-n-tile
-        // instance does not fit the register file: 4-15 spilled registers, i.e. scratch loads inside the counted-vmcnt loop)
+    if constexpr (WN <= 7) {
+        // workgroups that walk several tiles, each with at least one full chunk and a second chunk or tail: the deferred-epilogue
+        // kernel (conv3x3_planes_de.hip) where the launch's outputs are its form: bias, PReLU, one raw plane sink
         if (d.defer && !d.h2_w && (d.cf >> 5) >= 1 && nchunks >= 2 && grid < ds.vblocks) {
-            const hipError_t e2 = atmvfi::allow_dynamic_lds<conv3x3_planes_de_kernel<WN>>(lds);
-            ATMVFI_REQUIRE(e2 == hipSuccess, ATMVFI_ELAUNCH, "conv3x3_planes: hipFuncSetAttribute: %s", hipGetErrorString(e2));
-            hipLaunchKernelGGL(conv3x3_planes_de_kernel<WN>, dim3((unsigned)grid), dim3(512), lds, s, ds);
-            return atmvfi::check_launch("conv3x3_planes (deferred epilogue)");
+            if (d.out_hi && !d.out && !d.plane_prelu && !d.out_hi2) return atmvfi::launch_planes_de(WN, ds, grid, lds, s);
         }
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, s, ds);
