@@ -498,9 +498,6 @@ class HipOps:
         # fp32-input f16x3 GEMM; None / 0 = the library's cost model
         self.conv3_instance = None
         self.gemm_tile_wn = 0
-        # experimental switch (ATMVFI_CONV3_DEFER=1): let multi-tile 3x3 plane launches take the deferred-epilogue kernel
-        # (conv3x3_planes: ``defer``; one fp32 accumulator, not bit-identical to the two-accumulator kernel, not faster yet)
-        self.conv3_defer = os.environ.get("ATMVFI_CONV3_DEFER", "0") == "1"
         self.warp_tiles = os.environ.get("ATMVFI_WARP_TILES", "1") != "0"     # A/B switch: planar warps with LDS-staged source tiles
         self.recording: Optional[LaunchPlan] = None     # when set: every launch is also appended to this plan
         # split-K scratch for the plane-input GEMM: a callable floats -> fp32 tensor (Network hands out workspace memory); None: never split
@@ -721,16 +718,12 @@ class HipOps:
     def conv3x3_planes(self, x: Planes, n: int, h: int, wd: int, w: PackedWeight, out=None, bias=None, prelu=None,
                        planes: Optional[Planes] = None, planes_c0: int = 0, planes_prelu=None, in_chunk0: int = 0, cin: Optional[int] = None,
                        wn: int = 0, out_cmin: int = 0, planes2: Optional[Planes] = None, planes2_c0: int = 0,
-                       workspace: Optional[torch.Tensor] = None, defer: Optional[bool] = None):
+                       workspace: Optional[torch.Tensor] = None):
         """3x3 / stride 1 / pad 1 conv (+bias, PReLU) on split-plane input ``x`` (rows = pixels of an [n,h,wd] map; channels
         ``32*in_chunk0 .. +cin``).  ``out``: fp32 NHWC view or None; ``planes``: plane sink written at channel offset ``planes_c0``
         (its own ``planes_prelu`` applied to that copy only); ``planes2``: a second, raw plane sink.  ``out_cmin``: only channels >= it are stored in ``out``.  Needs the spare
         zero row of ``Planes.alloc``.  ``workspace``: fp32 scratch of at least ``conv3x3_workspace_floats(...)`` elements: lets the launcher
-        split K over idle CUs on under-filled grids (split-K with a fixed-order reduce; small frames).  ``defer`` (default: the
-        object's ``conv3_defer``): let multi-tile launches take the deferred-epilogue kernel (one fp32 accumulator: same tolerance class,
-        not the same bits as the fp32-input kernel); True = wn | 16 of the C ABI."""
-        if defer is None:
-            defer = self.conv3_defer
+        split K over idle CUs on under-filled grids (split-K with a fixed-order reduce; small frames)."""
         cin = (x.c - 32 * in_chunk0) if cin is None else cin
         if self.precision != "f16x3" or w.hi3 is None:
             raise ValueError("conv3x3_planes: needs the f16x3 engine and the conv3x3 weight planes")
@@ -769,7 +762,7 @@ class HipOps:
                   _ptr(planes.t[0]) if planes is not None else None, _ptr(planes.t[1]) if planes is not None else None,
                   planes.ld_rows if planes is not None else 0, planes_c0, _ptr(planes_prelu) if planes is not None else None,
                   _ptr(planes2.t[0]) if planes2 is not None else None, _ptr(planes2.t[1]) if planes2 is not None else None,
-                  planes2.ld_rows if planes2 is not None else 0, planes2_c0, out_cmin, wn | (16 if defer else 0), _ptr(workspace),
+                  planes2.ld_rows if planes2 is not None else 0, planes2_c0, out_cmin, wn, _ptr(workspace),
                   workspace.numel() if workspace is not None else 0, self._stream())
 
     def pack_readout(self, w: torch.Tensor) -> torch.Tensor:

@@ -791,7 +791,7 @@ class Network(_ParamWatch, BlockRunner, nn.Module):
                 self._precision, self.use_split_planes, self.use_plane_convs, self.use_unet_planes, self.use_plane_deconvs,
                 self.use_fused_stem, self.use_splitk, self.use_fused_tail, getattr(ops, "attention_f16x3", None), self.local_motion_args["window_size"],
                 self.global_motion_args["window_size"], getattr(ops, "warp_tiles", None), getattr(ops, "conv3_instance", None),
-                getattr(ops, "gemm_tile_wn", None), getattr(ops, "conv3_defer", None), self._workspace_key(im0))
+                getattr(ops, "gemm_tile_wn", None), self._workspace_key(im0))
 
     def forward(self, im0: torch.Tensor, im1: torch.Tensor, reuse_first: bool = False):
         self._reuse_first = bool(reuse_first)

@@ -203,19 +203,13 @@ int atmvfi_conv3x3_f16x3(const float* in, int in_ld, int N, int H, int W, int Ci
  * [ceil(Cin/32)][in_rows][32], row = pixel n*H*W + y*W + x) that the producing layer's sink wrote, so the input halo goes
  * global -> LDS by LDS-DMA with no register staging and no conversion, and the two waves of each SIMD run one phase apart (one
  * issues MFMAs while the other reads fragments and issues DMA).  Bit-identical to atmvfi_conv3x3_f16x3 on the same values.
- * EXPERIMENTAL, opt-in with wn | 16: a launch whose workgroups walk several tiles (more tiles than CUs, Cin >= 32, at most 6 n-tiles,
- * outputs under 4 GiB) runs the DEFERRED-EPILOGUE kernel: the three products of the split arithmetic in ONE fp32 accumulator (the cross
- * products' activation fragments scaled by 2^-10 in fp16 first), the previous tile's epilogue inside the current tile's MFMA phases --
- * the same tolerance class, not the same bits (|x| < 2^-4 activations lose low bits of the correction terms: 5e-8 absolute at 1e-3).
- * Not faster yet; atm-vfi_amd never sets the bit unless ATMVFI_CONV3_DEFER=1.
  * Contract of the input planes: in_rows > N*H*W and row N*H*W of every chunk is ZERO (it is the source of the halo pixels that
  * fall outside the image; atm-vfi_amd's Planes.alloc reserves it); pad channels of the last chunk are zero; in_rows * 64 < 2^32.
  * Outputs: fp32 NHWC view `out` (may be NULL; only channels >= out_cmin, a multiple of 4, are stored: columns below are
  * never touched, so `out` may point out_cmin floats in front of a compact buffer of just the stored channels) and / or the plane sink
  * out_hi / out_lo (may be NULL; not both NULL) at channel offset out_c0 (multiple of 8) of a plane buffer with plane_rows rows,
  * through plane_prelu (as atmvfi_conv3x3_f16x3); plane channels from Cout up to the next multiple of 8 are written as zero.
- * wn: 0 = pick the tile width (n-tiles of 16 output channels per workgroup) from the cost model, 1..8 = force it (tests, sweeps);
- * + 16: allow the deferred-epilogue kernel (see above). */
+ * wn: 0 = pick the tile width (n-tiles of 16 output channels per workgroup) from the cost model, 1..8 = force it (tests, sweeps). */
 int atmvfi_conv3x3_planes(const void* in_hi, const void* in_lo, int64_t in_rows, int N, int H, int W, int Cin, const void* w_hi,
                           const void* w_lo, int Cout, float* out, int out_ld, const float* bias, const float* prelu, void* out_hi,
                           void* out_lo, int64_t plane_rows, int out_c0, const float* plane_prelu, int out_cmin, int wn, void* stream);

@@ -97,54 +97,6 @@ def check_planes(asm_text):
     return problems
 
 
-def check_planes_de(asm_text):
-    """conv3x3_planes_de_kernel<WN>, WN = 1..6 (the opt-in deferred-epilogue variant): no register spill (a scratch access is a
-    vector-memory operation inside a loop of counted vmcnt waits); 45 barriers (1 + 1 prologue, 2 x 21 k-steps, 1 at the end); 21 MFMA
-    phases of exactly 6 WN MFMAs; a phase without an epilogue unit touches no memory; every read phase ends with a counted vmcnt wait of
-    the kernel's own and lgkmcnt(0); no compiler-made vmcnt wait between the first and the last MFMA phase."""
-    problems = []
-    lines = asm_text.splitlines()
-    for wn in range(1, 7):
-        starts = [i for i, l in enumerate(lines) if re.match(rf"^_ZN\S*conv3x3_planes_de_kernelILi{wn}E\S*:", l)]
-        if not starts:
-            problems.append(f"planes_de<{wn}>: kernel not found")
-            continue
-        end = next(i for i in range(starts[0], len(lines)) if "s_endpgm" in lines[i])
-        raw = lines[starts[0]:end]
-        body = [l.split(";")[0] for l in raw]
-        if any("scratch_" in l for l in body):
-            problems.append(f"planes_de<{wn}>: register spill (scratch access)")
-        bars = [i for i, l in enumerate(body) if re.search(r"\bs_barrier\b", l)]
-        if len(bars) != 45:
-            problems.append(f"planes_de<{wn}>: expected 45 s_barrier, found {len(bars)}")
-        p1 = [i for i, l in enumerate(body) if re.search(r"\bs_setprio 1\b", l)]
-        p0 = [i for i, l in enumerate(body) if re.search(r"\bs_setprio 0\b", l)]
-        if len(p1) != 21 or len(p0) != 21:
-            problems.append(f"planes_de<{wn}>: expected 21 MFMA phases, found {len(p1)} / {len(p0)}")
-            continue
-        for k, (a, b) in enumerate(zip(p1, p0)):
-            seg = body[a + 1:b]
-            n_mfma = sum("v_mfma" in l for l in seg)
-            stores = sum("global_store" in l for l in seg)
-            mem = [l for l in seg if re.search(r"\b(ds_|global_|buffer_|flat_|scratch_)", l)]
-            if n_mfma != 6 * wn or (stores == 0 and not any("ds_read" in l for l in seg) and mem):
-                problems.append(f"planes_de<{wn}>: MFMA phase {k} has {n_mfma} MFMAs, {len(mem)} memory instructions")
-            if any(re.search(r"\b(buffer_|flat_|scratch_|global_load)", l) for l in seg):
-                problems.append(f"planes_de<{wn}>: MFMA phase {k} loads from global memory")
-            bar = max(i for i in bars if i < a)
-            prev = max([i for i in bars if i < bar] + [0])
-            rd = body[prev + 1:bar]
-            waits = [l.strip() for l in rd if "s_waitcnt" in l]
-            if sum("ds_read_b128" in l for l in rd) < 4 + 2 * wn or sum("global_load_lds" in l for l in rd) == 0:
-                problems.append(f"planes_de<{wn}>: read phase {k}: unexpected fragment read / DMA count")
-            if not any("lgkmcnt(0)" in w for w in waits) or not any(re.search(r"vmcnt\(\d+\)", w) for w in waits):
-                problems.append(f"planes_de<{wn}>: read phase {k} lacks lgkmcnt(0) or a counted vmcnt wait")
-        for i in range(p1[0], p0[-1]):
-            if re.search(r"s_waitcnt.*vmcnt", raw[i]) and "ASMSTART" not in raw[i - 1]:
-                problems.append(f"planes_de<{wn}>: compiler-inserted '{raw[i].strip()}' inside the k-loop region (line {i})")
-    return problems
-
-
 def check_pp(asm_text):
     """gemm_pp_kernel<CONVM>: every MFMA phase (between s_setprio 1 and s_setprio 0) holds exactly 48 MFMAs and nothing that
     touches memory; every read phase in front of one (back to the previous s_barrier) holds the 16 fragment reads; no register is
@@ -225,7 +177,6 @@ def main():
         problems = check(compile_asm("conv3x3_f16x3_row.hip", os.path.join(td, "row.s")))
         planes = compile_asm("conv3x3_planes.hip", os.path.join(td, "planes.s"))
         problems += check_planes(planes)
-        problems += check_planes_de(planes)
         problems += check_no_slp_pairs(planes, "conv3x3_planes.hip")
         pp = compile_asm("gemm_pp.hip", os.path.join(td, "pp.s"))
         problems += check_pp(pp)
