@@ -170,7 +170,8 @@ __global__ __launch_bounds__(256) void dwconv_gelu_rows_kernel(const float* __re
     const float* base = in + ((long long)n * H * W + x) * in_ld + c;
     const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
     // Borders: a column outside the image gets ZERO WEIGHTS (its loads are clamped to a valid address, and finite x * 0 adds exactly
-    // nothing), a row outside the image is a block-uniform case and becomes zeros without a load -- so a loaded value is first touched by
+    // nothing; the blocks on the left / right image edge -- a block-uniform case -- also select a zero VALUE at the use, so that an
+    // Inf / NaN centre pixel in column 0 or W - 1 adds nothing either, as zero padding does: ADVICE round 4), a row outside the image is a block-uniform case and becomes zeros without a load -- so a loaded value is first touched by
     // the FMAs, and row y + 2 can be requested one iteration ahead: the wait for it then sits behind a whole row of arithmetic and behind
     // this row's stores in program order (vmcnt retires in order: waiting for a load issued AFTER the previous row's stores also waited
     // for those stores to be acknowledged -- once per row, with the load latency on top).
@@ -181,8 +182,9 @@ __global__ __launch_bounds__(256) void dwconv_gelu_rows_kernel(const float* __re
     }
     // A strip whose RS + 2 input rows all lie inside the image (all but the first and the last strip of a map) runs without any row test:
     // straight-line code, so that hipcc's waits are counted ones (at a control-flow join it waits for vmcnt(0)).
-    auto run = [&](auto interior_tag) {
+    auto run = [&](auto interior_tag, auto xedge_tag) {
         constexpr bool INTERIOR = decltype(interior_tag)::value;
+        constexpr bool XEDGE = decltype(xedge_tag)::value;
         f32x4 win[4][3];        // [row slot][x-1, x, x+1]
         const long long xm = xm_ok ? in_ld : 0, xp = xp_ok ? in_ld : 0;
         auto load_row = [&](int y, f32x4 (&dst)[3]) {
@@ -211,7 +213,9 @@ __global__ __launch_bounds__(256) void dwconv_gelu_rows_kernel(const float* __re
                     const f32x4* row = win[(r + ky) % 4];
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
-                        const f32x4 v = row[kx], wt = wv[ky * 3 + kx];
+                        f32x4 v = row[kx];
+                        const f32x4 wt = wv[ky * 3 + kx];
+                        if (XEDGE && kx != 1) v = (kx == 0 ? xm_ok : xp_ok) ? v : zero;
                         a01 = __builtin_elementwise_fma(v.xy, wt.xy, a01);
                         a23 = __builtin_elementwise_fma(v.zw, wt.zw, a23);
                     }
@@ -226,8 +230,14 @@ __global__ __launch_bounds__(256) void dwconv_gelu_rows_kernel(const float* __re
             }
         }
     };
-    if (y0 >= 1 && y0 + RS + 1 <= H) run(std::true_type{});
-    else run(std::false_type{});
+    const bool xedge = xb == 0 || xb == xblocks - 1;
+    if (y0 >= 1 && y0 + RS + 1 <= H) {
+        if (xedge) run(std::true_type{}, std::true_type{});
+        else run(std::true_type{}, std::false_type{});
+    } else {
+        if (xedge) run(std::false_type{}, std::true_type{});
+        else run(std::false_type{}, std::false_type{});
+    }
 }
 
 __global__ void pack_dw_kernel(const float* __restrict__ src, float* __restrict__ dst, int C) {
@@ -909,9 +919,11 @@ __global__ __launch_bounds__(256) void refine_tail_kernel(const float* __restric
     }
 }
 
-__global__ __launch_bounds__(256) void l1_mean_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                      float* __restrict__ out, long long per_sample) {
-    fp16_saturate_on();
+// mean |a - b| per sample in two passes with a FIXED summation order (run-to-run bit-identical: the ensemble's pick compares these means,
+// and a launch plan's self-check replays the forward): pass 1 = one partial sum per block (wave shuffle tree, then the four waves in
+// order), pass 2 = one block per sample adds the partial sums, thread by thread in index order, then the same tree.
+__global__ __launch_bounds__(256) void l1_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         float* __restrict__ part, long long per_sample) {
     __shared__ float red[4];
     const int s = blockIdx.y;
     const float* pa = a + (long long)s * per_sample;
@@ -923,12 +935,25 @@ __global__ __launch_bounds__(256) void l1_mean_kernel(const float* __restrict__ 
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out + s, (red[0] + red[1] + red[2] + red[3]) / (float)per_sample);
+    if (threadIdx.x == 0) part[(long long)s * gridDim.x + blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+__global__ __launch_bounds__(256) void l1_final_kernel(const float* __restrict__ part, int nparts, float* __restrict__ out, long long per_sample) {
+    __shared__ float red[4];
+    const int s = blockIdx.x;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += blockDim.x) acc += part[(long long)s * nparts + i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[s] = (((red[0] + red[1]) + red[2]) + red[3]) / (float)per_sample;
 }
 
 // multiscale_global_motion_ensemble's per-sample pick (network_base.py:591-603): the candidate whose alignment loss is the minimum, the
 // FIRST one on ties (the reference's if / elif chain over levels 0, 1, 2), copied into the output flows.  Candidates are already at the
-// level-0 flow resolution (the x2 / x4 up-sampling of levels 1 / 2 is the candidates' resize).
+// level-0 flow resolution (the x2 / x4 up-sampling of levels 1 / 2 is the candidates' resize).  The minimum is Python's min(l0, l1, l2)
+// -- start from l0, replace by a later value only if that one compares LESS -- and the pick its `==` chain: with a NaN loss every
+// comparison is false, so a NaN l0 makes the chain fall through to level 2, exactly as the reference does (fminf would skip the NaN).
 __global__ __launch_bounds__(256) void ensemble_select_kernel(const float* __restrict__ l0, const float* __restrict__ l1, const float* __restrict__ l2,
                                                               const float* __restrict__ a0, const float* __restrict__ b0,
                                                               const float* __restrict__ a1, const float* __restrict__ b1,
@@ -939,7 +964,9 @@ __global__ __launch_bounds__(256) void ensemble_select_kernel(const float* __res
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
         const int s = (int)(idx / per_sample);
         const float x0 = l0[s], x1 = l1[s], x2 = l2[s];
-        const float mn = fminf(fminf(x0, x1), x2);
+        float mn = x0;
+        if (x1 < mn) mn = x1;
+        if (x2 < mn) mn = x2;
         const int pick = x0 == mn ? 0 : (x1 == mn ? 1 : 2);
         out0[idx] = pick == 0 ? a0[idx] : (pick == 1 ? a1[idx] : a2[idx]);
         out1[idx] = pick == 0 ? b0[idx] : (pick == 1 ? b1[idx] : b2[idx]);
@@ -1202,14 +1229,21 @@ extern "C" int atmvfi_ensemble_select(const float* loss0, const float* loss1, co
     return atmvfi::check_launch("ensemble_select");
 }
 
-extern "C" int atmvfi_l1_mean(const float* a, const float* b, float* out, int B, int64_t per_sample, void* stream) {
-    ATMVFI_REQUIRE(a && b && out && B > 0 && per_sample > 0, ATMVFI_EINVAL, "l1_mean: bad arguments");
-    // the accumulator is cleared here, on the caller's stream (the launch is self-contained: recordable into a launch plan)
-    const hipError_t me = hipMemsetAsync(out, 0, (size_t)B * sizeof(float), (hipStream_t)stream);
-    ATMVFI_REQUIRE(me == hipSuccess, ATMVFI_ELAUNCH, "l1_mean: hipMemsetAsync: %s", hipGetErrorString(me));
+static int l1_mean_blocks(int64_t per_sample) {
     long long bx = (per_sample + 256 * 16 - 1) / (256 * 16);
-    if (bx > 1024) bx = 1024;
-    hipLaunchKernelGGL(l1_mean_kernel, dim3((unsigned)bx, (unsigned)B), dim3(256), 0, (hipStream_t)stream, a, b, out,
+    return (int)(bx > 1024 ? 1024 : bx);
+}
+extern "C" int64_t atmvfi_l1_mean_workspace_floats(int B, int64_t per_sample) {
+    return (B > 0 && per_sample > 0) ? (int64_t)B * l1_mean_blocks(per_sample) : 0;
+}
+extern "C" int atmvfi_l1_mean(const float* a, const float* b, float* out, int B, int64_t per_sample, float* workspace, int64_t workspace_floats,
+                              void* stream) {
+    ATMVFI_REQUIRE(a && b && out && B > 0 && per_sample > 0, ATMVFI_EINVAL, "l1_mean: bad arguments");
+    const int bx = l1_mean_blocks(per_sample);
+    ATMVFI_REQUIRE(workspace && workspace_floats >= (int64_t)B * bx, ATMVFI_EINVAL,
+                   "l1_mean: needs a workspace of atmvfi_l1_mean_workspace_floats(B, per_sample) = %lld floats", (long long)B * bx);
+    hipLaunchKernelGGL(l1_partial_kernel, dim3((unsigned)bx, (unsigned)B), dim3(256), 0, (hipStream_t)stream, a, b, workspace,
                        (long long)per_sample);
+    hipLaunchKernelGGL(l1_final_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, workspace, bx, out, (long long)per_sample);
     return atmvfi::check_launch("l1_mean");
 }

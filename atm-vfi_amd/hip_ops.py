@@ -127,7 +127,8 @@ SIGNATURES = {
     "atmvfi_frame_f32_to_u8": (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_f]),
     "atmvfi_pack_frames": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_f]),
     "atmvfi_final_residual": (c_i, [c_f, c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_f]),
-    "atmvfi_l1_mean": (c_i, [c_f, c_f, c_f, c_i, c_l, c_f]),
+    "atmvfi_l1_mean": (c_i, [c_f, c_f, c_f, c_i, c_l, c_f, c_l, c_f]),
+    "atmvfi_l1_mean_workspace_floats": (c_l, [c_i, c_l]),
     "atmvfi_ensemble_select": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_l, c_f]),
     "atmvfi_stem_fused": (c_i, [c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_l, c_f]),
     "atmvfi_plan_fn_id": (c_i, [ctypes.c_char_p]),
@@ -1183,12 +1184,20 @@ class HipOps:
         self._run("final_residual", {"bytes": 4.0 * b * h * w * 12}, self.lib.atmvfi_final_residual, _ptr(it), _ptr(r), rld,
                   _ptr(it_sum), _ptr(it_clamped), b, h, w, self._stream())
 
-    def l1_mean(self, a, b, out):
+    def l1_mean_workspace_floats(self, n: int, per_sample: int) -> int:
+        return int(self.lib.atmvfi_l1_mean_workspace_floats(n, per_sample))
+
+    def l1_mean(self, a, b, out, workspace=None):
+        """mean |a - b| per sample, fixed summation order (run-to-run bit-identical).  ``workspace``: fp32 scratch of at least
+        ``l1_mean_workspace_floats`` elements (workspace memory of the caller; allocated here if absent: tests)."""
         _chk(a, "l1_mean.a"); _chk(b, "l1_mean.b")
         if not a.is_contiguous() or not b.is_contiguous() or a.shape != b.shape:
             raise ValueError("l1_mean: inputs must be contiguous and of equal shape")
         n = a.shape[0]
-        self._run("l1_mean", {"bytes": 8.0 * a.numel()}, self.lib.atmvfi_l1_mean, _ptr(a), _ptr(b), _ptr(out), n, a.numel() // n, self._stream())
+        if workspace is None:
+            workspace = torch.empty(self.l1_mean_workspace_floats(n, a.numel() // n), dtype=torch.float32, device=a.device)
+        self._run("l1_mean", {"bytes": 8.0 * a.numel()}, self.lib.atmvfi_l1_mean, _ptr(a), _ptr(b), _ptr(out), n, a.numel() // n,
+                  _ptr(workspace), workspace.numel(), self._stream())
 
     def ensemble_select(self, losses, cands, out0, out1):
         """Per sample the candidate flow pair of the level with the smallest loss (first on ties): losses = three [B] tensors,

@@ -43,22 +43,34 @@ _PARAM_EPOCH = [0]       # bumped whenever a Parameter OBJECT is (re)assigned, r
 
 class _ParamWatch:
     """Mixin: replacing a parameter object (``module.weight = nn.Parameter(...)``, ``register_parameter``, pruning or
-    re-parametrisation hooks, ``del module.weight``) bumps ``_PARAM_EPOCH``, which ``Network._param_sig`` compares on every forward:
-    its cached parameter list would otherwise keep the OLD objects and the packed weights, plans and graphs would stay stale."""
+    re-parametrisation hooks, ``del module.weight``) OR a whole sub-module (``net.x = other_node``, ``add_module`` /
+    ``register_module``, ``del net.x``: parametrize / prune wrappers swap modules) bumps ``_PARAM_EPOCH``, which ``Network._param_sig``
+    compares on every forward: its cached parameter list would otherwise keep the OLD objects and the packed weights, plans and graphs
+    would stay stale."""
 
     def __setattr__(self, name, value):
-        if isinstance(value, nn.Parameter) or name in self.__dict__.get("_parameters", ()):
+        d = self.__dict__
+        if isinstance(value, (nn.Parameter, nn.Module)) or name in d.get("_parameters", ()) or name in d.get("_modules", ()):
             _PARAM_EPOCH[0] += 1
         super().__setattr__(name, value)
 
     def __delattr__(self, name):
-        if name in self.__dict__.get("_parameters", ()):
+        d = self.__dict__
+        if name in d.get("_parameters", ()) or name in d.get("_modules", ()):
             _PARAM_EPOCH[0] += 1
         super().__delattr__(name)
 
     def register_parameter(self, name, param):
         _PARAM_EPOCH[0] += 1
         super().register_parameter(name, param)
+
+    def add_module(self, name, module):
+        _PARAM_EPOCH[0] += 1
+        super().add_module(name, module)
+
+    def register_module(self, name, module):
+        _PARAM_EPOCH[0] += 1
+        super().register_module(name, module)
 
 
 class _Node(_ParamWatch, nn.Module):
@@ -723,7 +735,8 @@ class Network(_ParamWatch, BlockRunner, nn.Module):
             u1 = self.buf(f"ens{lvl}u1", b, 2, h, w); ops.resize(f1, u1, float(factor))
             wa = self.buf("ens_wa", b, 3, h, w); ops.flow_warp(im0, u0, wa)
             wb = self.buf("ens_wb", b, 3, h, w); ops.flow_warp(im1, u1, wb)
-            loss = self.buf(f"ens{lvl}loss", b); ops.l1_mean(wa, wb, loss)
+            loss = self.buf(f"ens{lvl}loss", b)
+            ops.l1_mean(wa, wb, loss, workspace=self.buf("ens_l1_ws", ops.l1_mean_workspace_floats(b, 3 * h * w)) if hasattr(ops, "l1_mean_workspace_floats") else None)
             # candidate at the level-0 flow resolution (H/16): x1, x2, x4 up-sampling of the coarser flows
             if lvl == 0:
                 k0 = self.buf("ens_c0_0", b, 2, h // 16, w // 16); ops.resize(f0, k0, 1.0)

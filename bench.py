@@ -221,7 +221,7 @@ def dry_run(args, dist):
     print(f"rank {rank} of {world}: rendezvous at {os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')} ok", flush=True)
     if rank == 0:
         print(json.dumps({"metric": "dry-run (launcher self-test, nothing measured)", "value": None, "n_gpus": world,
-                          "steps": args.steps, "warmup": args.warmup, "rccl_world_size": group_world, "per_rank_ms_per_step": per_rank}),
+                          "steps": args.steps, "warmup": args.warmup, "collective_world_size": group_world, "per_rank_ms_per_step": per_rank}),
               file=_REAL_STDOUT, flush=True)
 
 
@@ -420,6 +420,29 @@ def main():
                                 "frac": round(ach / peak, 4), "traffic": None, "kernel": fam, "launches": nl,
                                 "avg_launch_ms": round(ms / nl, 4), "algorithmic_gflop_per_forward": round(fl / 1e9, 1),
                                 "share_of_forward_time": round(ms / total_ms, 4)}
+            # The plane-input GEMM launches that their BYTES bound, not their flops (short K, wide scatter epilogues: the last decoder
+            # deconvs, the refiner's first strided convs): algorithmic bytes / 8 TB/s exceeds algorithmic flops / 833 TFLOP/s.  They get an
+            # HBM entry of their own (a traffic-bound launch graded against MFMA says nothing); the family entry
+            # above keeps every launch and also says what the MFMA-bound ones alone reach.
+            gemm_names = ("linear_split", "deconv2x2_split", "conv2d_split")
+            hb = [(n, m, s.elapsed_time(e)) for n, m, s, e in prof if n in gemm_names and m.get("bytes", 0.0) / (PEAK_HBM_GBS * 1e9) > m.get("flops", 0.0) / (PEAK_F16_MFMA_TFLOPS / 3.0 * 1e12)]
+            if hb:
+                ms_h = sum(t for _, _, t in hb)
+                by_h = sum(m.get("bytes", 0.0) for _, m, _ in hb)
+                fl_h = sum(m.get("flops", 0.0) for _, m, _ in hb)
+                ach = by_h / (ms_h * 1e-3) / 1e9
+                kh = "gemm_pp_kernel / gemm_duo_kernel launches bounded by their bytes (algorithmic bytes / 8 TB/s > algorithmic flops / 833 TFLOP/s)"
+                fam_out[kh] = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4),
+                               "frac_of_achievable_6300": round(ach / 6300.0, 4), "traffic": None, "kernel": kh, "launches": len(hb),
+                               "avg_launch_ms": round(ms_h / len(hb), 4), "algorithmic_gbytes_per_forward": round(by_h / 1e9, 3),
+                               "mfma_tflops_of_these_launches": round(fl_h / (ms_h * 1e-3) / 1e12, 1),
+                               "shapes": sorted({m.get("shape", "?") for _, m, _ in hb}), "share_of_forward_time": round(ms_h / total_ms, 4)}
+                for fam in fam_out:
+                    if fam.startswith("gemm_pp_kernel + gemm_duo_kernel"):
+                        ms_all = sum(agg[n]["ms"] for n in gemm_names if n in agg)
+                        fl_all = sum(agg[n]["flops"] for n in gemm_names if n in agg)
+                        if ms_all > ms_h:
+                            fam_out[fam]["frac_without_the_byte_bound_launches"] = round((fl_all - fl_h) / ((ms_all - ms_h) * 1e-3) / 1e12 / (PEAK_F16_MFMA_TFLOPS / 3.0), 4)
             # HBM traffic per launch: PMC counters cannot be read from inside this process (rocprofv3 wraps the run), so the value
             # comes from the committed passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH doubled per the
             # gfx950 correction; tools/pmc_hbm.sh) -- and only while the kernel sources are the ones those passes were taken on
@@ -519,8 +542,13 @@ def main():
                                                 f"{med:.2f} s per forward (runs {', '.join(f'{t:.2f}' for t in runs)})"}
         if collective:
             result["collective_backend"] = dist.get_backend()
-            result["rccl_world_size"] = dist.get_world_size()          # what the communicator itself reports, not WORLD_SIZE
+            result["collective_world_size"] = dist.get_world_size()          # what the communicator itself reports, not WORLD_SIZE
             result["per_rank_ms_per_step"] = per_rank_ms
+            if rehearsal:
+                # every rank on ONE card, gloo instead of RCCL: the code path, not a scaling measurement -- the line must not read as one
+                result["rehearsal_frames_per_s"] = result["value"]
+                result["value"] = None
+                result["metric"] = "rehearsal (all ranks on cuda:0 over gloo: the N > 1 code path, not a scaling measurement)"
         print(json.dumps(result), file=_REAL_STDOUT, flush=True)
     if collective:
         dist.barrier()                      # rank 0's instrumented pass is over: nobody tears the communicator down under it

@@ -405,11 +405,14 @@ int atmvfi_refine_tail(const float* contrib, int64_t contrib_plane, const float*
 int atmvfi_frame_u8_to_f32(const void* src, int H, int W, int bgr, float* dst, int Hp, int Wp, int pad_top, int pad_left, void* stream);
 int atmvfi_frame_f32_to_u8(const float* src, int Hp, int Wp, int pad_top, int pad_left, void* dst, int H, int W, int bgr, void* stream);
 
-/* mean |a - b| per sample: global_alignmentness (network_base.py:560-561).  out[B] is cleared by the call (on `stream`). */
-int atmvfi_l1_mean(const float* a, const float* b, float* out, int B, int64_t per_sample, void* stream);
+/* mean |a - b| per sample: global_alignmentness (network_base.py:560-561).  Two passes with a fixed summation order -- the result is
+ * run-to-run bit-identical (the ensemble's pick compares these means) -- through `workspace`: at least
+ * atmvfi_l1_mean_workspace_floats(B, per_sample) floats of scratch, the caller's. */
+int64_t atmvfi_l1_mean_workspace_floats(int B, int64_t per_sample);
+int atmvfi_l1_mean(const float* a, const float* b, float* out, int B, int64_t per_sample, float* workspace, int64_t workspace_floats, void* stream);
 /* multiscale_global_motion_ensemble's per-sample pick (network_base.py:591-603): out0 / out1 [B, per_sample] = the candidate flow pair
  * (c0_lL, c1_lL, already at the level-0 flow resolution) of the level whose loss[b] is the minimum, the first one on ties (the
- * reference's if / elif chain).  Keeps the ensemble forward free of device arithmetic outside this ABI. */
+ * reference's min() / if / elif chain, NaN losses included: a NaN loss of level 0 falls through to level 2).  Keeps the ensemble forward free of device arithmetic outside this ABI. */
 int atmvfi_ensemble_select(const float* loss0, const float* loss1, const float* loss2, const float* c0_l0, const float* c1_l0,
                            const float* c0_l1, const float* c1_l1, const float* c0_l2, const float* c1_l2, float* out0, float* out1, int B,
                            int64_t per_sample, void* stream);

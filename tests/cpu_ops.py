@@ -211,6 +211,6 @@ class CpuOps:
         it_sum.copy_(s)
         it_clamped.copy_(s.clamp(0, 1))
 
-    def l1_mean(self, a, b, out):
+    def l1_mean(self, a, b, out, workspace=None):
         self.calls.append("l1_mean")
         out.copy_((a - b).abs().mean(dim=[1, 2, 3]))

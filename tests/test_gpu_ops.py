@@ -424,7 +424,7 @@ def test_pack_final_l1(hip, cpu, dev):
     cpu.l1_mean(im0, im1, lc)
     hip.l1_mean(im0.to(dev), im1.to(dev), lg)
     assert maxdiff(lg, lc) <= 1e-6
-    hip.l1_mean(im0.to(dev), im1.to(dev), lg)                 # the call clears its accumulator itself: a second call does not add up
+    hip.l1_mean(im0.to(dev), im1.to(dev), lg)                 # a second call does not add up
     assert maxdiff(lg, lc) <= 1e-6
     # ensemble pick (network_base.py:591-603): per sample the candidate pair of the smallest loss, the FIRST on ties
     g2 = torch.Generator().manual_seed(77)
@@ -437,6 +437,28 @@ def test_pack_final_l1(hip, cpu, dev):
     torch.cuda.synchronize()
     for i, pk in enumerate(picks):
         assert torch.equal(o0[i], cands[pk][0][i]) and torch.equal(o1[i], cands[pk][1][i]), (i, pk)
+    # NaN losses: Python's min(l0, l1, l2) keeps its first argument unless a later one compares LESS, and nothing equals a NaN -- so a
+    # NaN l0 makes the reference's chain fall through to level 2, a NaN l1 / l2 is never the minimum (network_base.py:591-603)
+    nan = float("nan")
+    losses = [torch.tensor(v, device=dev) for v in ([nan, 0.2, 0.5, nan, 0.4], [0.2, nan, 0.4, nan, 0.3], [0.9, 0.1, nan, nan, nan])]
+    def ref_pick(a, b, c):
+        m = min(a, b, c)
+        return 0 if a == m else (1 if b == m else 2)
+    picks = [ref_pick(*(float(l[i]) for l in losses)) for i in range(B)]
+    assert picks == [2, 2, 1, 2, 1]
+    hip.ensemble_select(losses, cands, o0, o1)
+    torch.cuda.synchronize()
+    for i, pk in enumerate(picks):
+        assert torch.equal(o0[i], cands[pk][0][i]) and torch.equal(o1[i], cands[pk][1][i]), (i, pk)
+    # l1_mean sums in a fixed order: bit-identical from call to call, at a size of many blocks per sample
+    big0, big1 = torch.rand(3, 3, 544, 960, generator=g2).to(dev), torch.rand(3, 3, 544, 960, generator=g2).to(dev)
+    outs = []
+    for _ in range(4):
+        o = torch.empty(3, device=dev)
+        hip.l1_mean(big0, big1, o)
+        outs.append(o.clone())
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    assert maxdiff(outs[0].cpu(), (big0 - big1).abs().double().mean(dim=[1, 2, 3]).float().cpu()) <= 1e-6
 
 
 # ------------------------------------------------------------------ a whole ATMFormer block (reference fixture)

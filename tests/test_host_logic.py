@@ -339,7 +339,7 @@ def test_bench_launcher_with_eight_ranks():
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout
     rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 8 and rec["rccl_world_size"] == 8 and rec["per_rank_ms_per_step"] == [float(i) for i in range(8)]
+    assert rec["n_gpus"] == 8 and rec["collective_world_size"] == 8 and rec["per_rank_ms_per_step"] == [float(i) for i in range(8)]
     assert all(f"rank {i} of 8: rendezvous" in r.stderr for i in range(8))
 
 
@@ -526,3 +526,21 @@ def test_parameter_replacement_and_data_swaps_are_noticed(nets):
     y1 = net(im0, im1)["I_t"]
     assert not torch.equal(y0, y1)
     assert torch.equal(y1, net(im0, im1)["im_t_list"][0].clamp(0, 1))
+    # a whole sub-module swapped (parametrize / prune wrappers replace modules, not parameters): the cached list must
+    # follow, by attribute assignment, add_module and deletion + re-registration alike
+    import copy
+    parent = net.refine_head._modules["1"]
+    sig4 = net._param_sig()
+    twin = copy.deepcopy(node)
+    with torch.no_grad():
+        twin.bias.fill_(0.25)
+    parent._modules["0"] = node                                  # (same object: the dict write itself is not watched, nothing changed)
+    assert net._param_sig() == sig4
+    setattr(parent, "0", twin)
+    sig5 = net._param_sig()
+    assert sig5 != sig4 and any(p is twin.bias for p in net._plist) and not any(p is node.bias for p in net._plist)
+    y2 = net(im0, im1)["I_t"]
+    assert not torch.equal(y1, y2)
+    parent.add_module("0", node)
+    assert net._param_sig() != sig5 and any(p is node.bias for p in net._plist)
+    assert torch.equal(net(im0, im1)["I_t"], y1)
