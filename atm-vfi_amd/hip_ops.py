@@ -134,7 +134,11 @@ SIGNATURES = {
     "atmvfi_plan_fn_id": (c_i, [ctypes.c_char_p]),
     "atmvfi_plan_run": (c_i, [ctypes.POINTER(PlanOp), c_i, ctypes.POINTER(PlanPatch), c_i, ctypes.POINTER(ctypes.c_uint64), c_i,
                               ctypes.POINTER(c_i), c_f]),
+    "atmvfi_plan_run_lanes": (c_i, [ctypes.POINTER(PlanOp), c_i, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(PlanPatch), c_i,
+                                    ctypes.POINTER(ctypes.c_uint64), c_i, ctypes.POINTER(c_i), ctypes.POINTER(ctypes.c_void_p), c_i,
+                                    ctypes.POINTER(ctypes.c_void_p), c_i]),
 }
+PLAN_RECORD, PLAN_WAIT = -2, -3        # include/atmvfi.h: the two synchronisation ops of atmvfi_plan_run_lanes
 
 
 def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
@@ -331,6 +335,8 @@ class LaunchPlan:
         self.c_ops = self.c_patches = self.c_slots = None
         self._fn_ids = {}
         self.by_tensor = self.by_address = 0      # pointer arguments classified per-call by their tensor / refused by raw address
+        self.lanes = []                    # per op: the lane (stream index) it is issued on; lane 0 = the caller's stream
+        self.n_events = 0                  # synchronisation ops (HipOps.branch / join) number their events per plan
 
     # ---- recording ----
     def _add_slot(self, t: torch.Tensor):
@@ -359,7 +365,13 @@ class LaunchPlan:
         self.out_meta.append((tuple(t.shape), t.dtype))
         self.out_tensors.append(t)
 
-    def add_op(self, fn, args):
+    def add_sync(self, kind: int, event: int, lane: int):
+        """A PLAN_RECORD / PLAN_WAIT op of event ``event`` on ``lane`` (HipOps.branch / join while recording)."""
+        self.ops_list.append((kind, [("i", event)]))
+        self.lanes.append(lane)
+        self.n_events = max(self.n_events, event + 1)
+
+    def add_op(self, fn, args, lane: int = 0):
         """Pointer arguments are ``TPtr`` (hip_ops._ptr): the tensor they were derived from decides whether they are per-call
         pointers (patched on replay, offset relative to the slot's base -- it may be negative or past the end) or fixed ones.  A
         pointer WITHOUT a tensor (a raw integer) must not lie in per-call memory: the plan refuses it rather than guess."""
@@ -406,6 +418,7 @@ class LaunchPlan:
                     raise PlanUnsupported(f"{name}: argument {j} is a raw address inside per-call memory with no tensor to attribute it to")
             vals.append(("u" if v >= 0 else "i", v))
         self.ops_list.append((fid, vals))
+        self.lanes.append(lane)
 
     def finish(self, result):
         """Freeze the plan; ``result`` is what the recorded forward returned (tensors must be whole output slots)."""
@@ -437,12 +450,15 @@ class LaunchPlan:
         self.c_slots = (ctypes.c_uint64 * len(self.slots))()
         self.failed = c_i(-1)
         self.out_tensors = []
+        self.n_lanes = max(self.lanes) + 1 if self.lanes else 1
+        self.c_lanes = (ctypes.c_int32 * n)(*self.lanes) if self.n_lanes > 1 else None
         return self
 
     # ---- replay ----
-    def run(self, inputs, device, stream, poison: bool = False):
+    def run(self, inputs, device, stream, poison: bool = False, lane_streams=None, lane_events=None):
         """``poison``: fill the fresh outputs with NaN first (the record-time self-check: an element the replay does not write, or
-        writes somewhere else, then differs from the recording forward's result)."""
+        writes somewhere else, then differs from the recording forward's result).  A plan recorded with branches (``n_lanes`` > 1)
+        needs ``lane_streams`` (stream handles of lanes 1..; lane 0 is ``stream``) and ``lane_events`` (``n_events`` event handles)."""
         outs = [torch.empty(shape, dtype=dt, device=device) for shape, dt in self.out_meta]
         if poison:
             for t in outs:
@@ -467,6 +483,13 @@ class LaunchPlan:
                 torch.cuda.synchronize()
                 if rc:
                     break
+        elif self.n_lanes > 1:
+            if lane_streams is None or len(lane_streams) < self.n_lanes - 1 or lane_events is None or len(lane_events) < self.n_events:
+                raise RuntimeError(f"the plan has {self.n_lanes} lanes and {self.n_events} events: the caller must supply their streams and events")
+            st = (ctypes.c_void_p * self.n_lanes)(stream, *lane_streams[:self.n_lanes - 1])
+            ev = (ctypes.c_void_p * max(1, self.n_events))(*lane_events[:self.n_events])
+            rc = self.lib.atmvfi_plan_run_lanes(self.c_ops, len(self.ops_list), self.c_lanes, self.c_patches, len(self.patches), sl, len(self.slots),
+                                                ctypes.byref(self.failed), st, self.n_lanes, ev, self.n_events)
         else:
             rc = self.lib.atmvfi_plan_run(self.c_ops, len(self.ops_list), self.c_patches, len(self.patches), sl, len(self.slots),
                                           ctypes.byref(self.failed), stream)
@@ -501,6 +524,12 @@ class HipOps:
         self.gemm_tile_wn = 0
         self.warp_tiles = os.environ.get("ATMVFI_WARP_TILES", "1") != "0"     # A/B switch: planar warps with LDS-staged source tiles
         self.recording: Optional[LaunchPlan] = None     # when set: every launch is also appended to this plan
+        # Lanes: independent branches of a forward on side streams (HipOps.branch / join; include/atmvfi.h "LANES").  lane 0 = the
+        # caller's current stream; lanes 1.. = side streams of this object, created on first use.
+        self.lane = 0
+        self._side_streams: List[torch.cuda.Stream] = []
+        self._lane_events: List[torch.cuda.Event] = []
+        self._next_event = 0
         # split-K scratch for the plane-input GEMM: a callable floats -> fp32 tensor (Network hands out workspace memory); None: never split
         self.gemm_workspace = None
 
@@ -519,8 +548,67 @@ class HipOps:
         self.recording = None
 
     # ------------------------------------------------------------------ utils
+    def _lane_stream(self, lane: int) -> "torch.cuda.Stream":
+        if lane == 0:
+            return torch.cuda.current_stream(self.device)
+        while len(self._side_streams) < lane:
+            self._side_streams.append(torch.cuda.Stream(device=self.device))
+        return self._side_streams[lane - 1]
+
     def _stream(self):
-        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return ctypes.c_void_p(self._lane_stream(self.lane).cuda_stream)
+
+    def _sync_event(self) -> int:
+        """The next synchronisation event of this forward (events are reused from call to call; a plan records their indices)."""
+        k = self._next_event
+        self._next_event += 1
+        while len(self._lane_events) <= k:
+            ev = torch.cuda.Event()
+            ev.record(self._lane_stream(0))          # (materialises the handle)
+            self._lane_events.append(ev)
+        return k
+
+    def begin_forward(self):
+        """Called by Network at the top of every forward: lane 0, event numbering from 0."""
+        self.lane = 0
+        self._next_event = 0
+
+    def _order(self, first: int, then: int):
+        """Everything issued so far on lane ``first`` happens before whatever lane ``then`` is given from now on."""
+        k = self._sync_event()
+        ev = self._lane_events[k]
+        ev.record(self._lane_stream(first))
+        self._lane_stream(then).wait_event(ev)
+        if self.recording is not None:
+            self.recording.add_sync(PLAN_RECORD, k, first)
+            self.recording.add_sync(PLAN_WAIT, k, then)
+
+    def branch(self, lane: int):
+        """``with ops.branch(k): ...`` -- the launches of the block go to lane ``k`` (a side stream), ordered after everything issued so
+        far on the current lane; afterwards the current lane continues WITHOUT waiting for them.  ``ops.join(k)`` orders the current
+        lane after lane ``k``.  The caller guarantees that, until the join, the two sides touch disjoint memory (workspace scratch
+        included: Network hands out per-lane split-K buffers)."""
+        ops = self
+
+        class _Branch:
+            def __enter__(self_inner):
+                self_inner.prev = ops.lane
+                if lane != ops.lane:
+                    ops._order(ops.lane, lane)
+                ops.lane = lane
+
+            def __exit__(self_inner, *exc):
+                ops.lane = self_inner.prev
+                return False
+        return _Branch()
+
+    def join(self, lane: int):
+        if lane != self.lane:
+            self._order(lane, self.lane)
+
+    def lane_handles(self):
+        """(stream handles of lanes 1.., event handles) for ``LaunchPlan.run``."""
+        return ([ctypes.c_void_p(s.cuda_stream) for s in self._side_streams], [ctypes.c_void_p(e.cuda_event) for e in self._lane_events])
 
     def _check(self, rc: int, name: str):
         if rc != 0:
@@ -528,15 +616,16 @@ class HipOps:
 
     def _run(self, name: str, meta: dict, fn, *args):
         if self.recording is not None:
-            self.recording.add_op(fn, args)
+            self.recording.add_op(fn, args, self.lane)
         if self.profile is None:
             self._check(fn(*args), name)
             return
         s = torch.cuda.Event(enable_timing=True)
         e = torch.cuda.Event(enable_timing=True)
-        s.record()
+        st = self._lane_stream(self.lane)
+        s.record(st)
         self._check(fn(*args), name)
-        e.record()
+        e.record(st)
         self.profile.append((name, meta, s, e))
 
     def empty(self, *shape) -> torch.Tensor:

@@ -228,6 +228,11 @@ class Network(_ParamWatch, BlockRunner, nn.Module):
         self.use_fused_stem = os.environ.get("ATMVFI_FUSED_STEM", "1") != "0"         # A/B switch: the encoder's first three layers in one launch
         self.use_fused_tail = os.environ.get("ATMVFI_FUSED_TAIL", "1") != "0"         # A/B switch: refine_head.1 folded into refine_head.0's epilogue
         self.use_splitk = os.environ.get("ATMVFI_SPLITK", "1") != "0"                 # A/B switch: split-K of under-filled long-K 3x3 launches
+        # independent branches of a forward on side streams (HipOps.branch; ATMVFI_LANES=1).  OFF by default: bit-identical and planned
+        # like everything else, but not faster -- 256x256 860.7 -> 853.3 frames/s, 256x448 1062.6 -> 1063.0, 576x960 169.9 -> 170.7,
+        # 1088x1920 51.9 -> 52.0 (profiles/r05_lanes_ab.txt): what the overlapped launches save (~100 us of 1.2 ms at 256x256) the four
+        # cross-queue event waits of a forward cost again
+        self.use_lanes = os.environ.get("ATMVFI_LANES", "0") == "1"
         self._prepared: Dict[str, object] = {}
         self._prepared_sig = None
         # Workspaces: one dict of named buffers per (device, input shape, mode) key, least recently used first.  The reference's
@@ -345,7 +350,10 @@ class Network(_ParamWatch, BlockRunner, nn.Module):
 
     def _gemm_scratch(self, floats: int) -> Optional[torch.Tensor]:
         """Split-K scratch of the plane-input GEMM (hip_ops.HipOps.gemm_workspace): workspace memory like every other buffer."""
-        return self.buf("gemm_splitk_ws", floats) if self.use_splitk else None
+        if not self.use_splitk:
+            return None
+        lane = getattr(self._ops_obj, "lane", 0)          # (a branch on a side stream gets scratch of its own: HipOps.branch)
+        return self.buf("gemm_splitk_ws" if not lane else f"gemm_splitk_ws_l{lane}", floats)
 
     def release_workspace(self):
         self._plans.clear()           # recorded plans and
@@ -498,7 +506,7 @@ class Network(_ParamWatch, BlockRunner, nn.Module):
             # sums is workspace memory like every other buffer
             need = ops.conv3x3_workspace_floats(n, h, w, P[wk].cin, P[wk].cout)
             if need:
-                extra["workspace"] = self.buf("splitk_ws", need)
+                extra["workspace"] = self.buf("splitk_ws" if not getattr(ops, "lane", 0) else f"splitk_ws_l{ops.lane}", need)
         ops.conv3x3_planes(xp, n, h, w, P[wk], out=out, bias=bias, prelu=prelu, planes=sink, planes_c0=sink_c0, planes_prelu=sink_prelu,
                            out_cmin=out_cmin, **extra)
 
@@ -622,7 +630,7 @@ class Network(_ParamWatch, BlockRunner, nn.Module):
         flat = buf.reshape(b * h * w, ld)[:, off:off + 2 * c]
         return flat.unflatten(1, (2, c)).permute(1, 0, 2)
 
-    def _motion_branch(self, ops, P, branch, mlp, x_tokens, b, h, w, ws, tag):
+    def _motion_branch(self, ops, P, branch, mlp, x_tokens, b, h, w, ws, tag, mlp_lane=None):
         """Two ATMFormer blocks + motion MLP (estimate_{local,global}_motion, network_base.py:367-415).
         Returns (mlp_in buffer, last hidden map) -- the caller runs the 1x1 head into its own slice."""
         c = x_tokens.shape[-1]
@@ -648,9 +656,16 @@ class Network(_ParamWatch, BlockRunner, nn.Module):
             if not getattr(ops, "motion_head_sink", False):
                 ops.split_planes(flat[:, 0:8], mlp_in_p, c0=0)
             t1p = self.planes(f"{tag}mm1_p", b * h * w, hid)
-            self._c3p(ops, P, f"{mlp}.0", mlp_in_p, b, h, w, sink=t1p)
             t2p = self.planes(f"{tag}mm2_p", b * h * w, hid)
-            self._c3p(ops, P, f"{mlp}.1", t1p, b, h, w, sink=t2p)
+
+            def convs():
+                self._c3p(ops, P, f"{mlp}.0", mlp_in_p, b, h, w, sink=t1p)
+                self._c3p(ops, P, f"{mlp}.1", t1p, b, h, w, sink=t2p)
+            if mlp_lane is not None:
+                with ops.branch(mlp_lane):
+                    convs()
+            else:
+                convs()
             return mlp_in, t2p
         t1 = self.buf(f"{tag}mm1", b, h, w, hid); self._conv_act(ops, P, f"{mlp}.0", mlp_in, t1)
         t2 = self.buf(f"{tag}mm2", b, h, w, hid); self._conv_act(ops, P, f"{mlp}.1", t1, t2)
@@ -804,7 +819,7 @@ class Network(_ParamWatch, BlockRunner, nn.Module):
                 self._precision, self.use_split_planes, self.use_plane_convs, self.use_unet_planes, self.use_plane_deconvs,
                 self.use_fused_stem, self.use_splitk, self.use_fused_tail, getattr(ops, "attention_f16x3", None), self.local_motion_args["window_size"],
                 self.global_motion_args["window_size"], getattr(ops, "warp_tiles", None), getattr(ops, "conv3_instance", None),
-                getattr(ops, "gemm_tile_wn", None), self._workspace_key(im0))
+                getattr(ops, "gemm_tile_wn", None), self.use_lanes, self._workspace_key(im0))
 
     def forward(self, im0: torch.Tensor, im1: torch.Tensor, reuse_first: bool = False):
         self._reuse_first = bool(reuse_first)
@@ -840,6 +855,9 @@ class Network(_ParamWatch, BlockRunner, nn.Module):
                 # differently aligned view takes the direct launches, which choose again
                 return self._forward_eager(im0, im1)
             self._select_workspace(key[-1])                  # replay counts as a use for the workspace LRU
+            if ent.n_lanes > 1:
+                ls, le = ops.lane_handles()
+                return ent.run((a, b), ops.device, ops._stream(), lane_streams=ls, lane_events=le)
             return ent.run((a, b), ops.device, ops._stream())
 
     @staticmethod
@@ -875,7 +893,8 @@ class Network(_ParamWatch, BlockRunner, nn.Module):
         # for bit (the forward is run-to-run deterministic).  A pointer patched into the wrong slot, a missed patch or a launch that
         # was not recorded shows up here, before the plan ever serves a caller; such a shape stays on direct launches.
         with torch.cuda.device(a.device):
-            again = plan.run((a, b), ops.device, ops._stream(), poison=True)
+            ls, le = ops.lane_handles() if plan.n_lanes > 1 else (None, None)
+            again = plan.run((a, b), ops.device, ops._stream(), poison=True, lane_streams=ls, lane_events=le)
         if self._same_results(out, again):
             self._plans[key] = plan
         else:
@@ -928,9 +947,19 @@ class Network(_ParamWatch, BlockRunner, nn.Module):
                 return self._forward_on_device(ops, im0, im1)
         return self._forward_on_device(ops, im0, im1)
 
+    def _lanes_on(self, ops, b: int, H: int, W: int) -> bool:
+        """Independent branches of the forward on side streams (HipOps.branch)?  ``use_lanes``, except on the CPU test double and under
+        per-launch profiling (which times launches on one stream)."""
+        if not hasattr(ops, "branch") or getattr(ops, "profile", None) is not None:
+            return False
+        return bool(self.use_lanes)
+
     def _forward_on_device(self, ops, im0: torch.Tensor, im1: torch.Tensor):
         self._select_workspace(self._workspace_key(im0))
+        if hasattr(ops, "begin_forward"):
+            ops.begin_forward()
         b, _, H, W = im0.shape
+        lanes = self._lanes_on(ops, b, H, W)
         # the plane kernels address a chunk's pixel rows with 32-bit byte offsets (64 B per row): beyond 2^26 rows of the largest
         # map (2 B frames at full resolution; e.g. batch 8 at 4K) the forward takes the fp32-input kernels instead
         self._rows_fit_planes = 2 * b * H * W < (1 << 26)
@@ -983,9 +1012,17 @@ class Network(_ParamWatch, BlockRunner, nn.Module):
                     gtok[n_g:].copy_(g_one)
             else:
                 e1, e2, fuse_l = self._encoder(ops, P, x0, "")
-                feat = self._fusion(ops, P, "cross_scale_feature_fusion", e1, e2, fuse_l, d[2], d[1], "l")   # [2B*h*w, C]
-                if glob:
-                    gtok = self._global_tokens(ops, P, e2, fuse_l, "")                                        # [2B*h_*w_, cg]
+                if glob and lanes and isinstance(fuse_l, _PMap):
+                    # the global branch's per-frame half (last_feat_extract + global fusion: reads e2 and the s3 chunks of the fusion
+                    # planes, writes its own buffers) beside the local fusion (writes the OTHER chunks of those planes)
+                    with ops.branch(1):
+                        gtok = self._global_tokens(ops, P, e2, fuse_l, "")                                    # [2B*h_*w_, cg]
+                    feat = self._fusion(ops, P, "cross_scale_feature_fusion", e1, e2, fuse_l, d[2], d[1], "l")
+                    ops.join(1)
+                else:
+                    feat = self._fusion(ops, P, "cross_scale_feature_fusion", e1, e2, fuse_l, d[2], d[1], "l")   # [2B*h*w, C]
+                    if glob:
+                        gtok = self._global_tokens(ops, P, e2, fuse_l, "")                                    # [2B*h_*w_, cg]
             if cache_ok:
                 keep = self.buf("frame_cache_tokens", b * h * w, C)
                 keep.copy_(feat[b * h * w:])
@@ -1034,21 +1071,33 @@ class Network(_ParamWatch, BlockRunner, nn.Module):
             # local motion (:490) -> raw motion map goes straight into the decoder input
             cdec = 2 * C + S.MOTION_OUT
             dec_in = self.buf("dec_in", b, h, w, _r4(cdec))
-            mlp_in, t2 = self._motion_branch(ops, P, "local_motion_atmformer", "local_motion_mlp", x_tokens, b, h, w,
-                                             self.local_motion_args["window_size"], "l")
             motion8 = dec_in[..., 2 * C:2 * C + 5]
-            self._head1x1(ops, P, "local_motion_mlp.2", t2, b, h, w, motion8)
+            a, c, t = (ops.empty(b, 3, h, w) for _ in range(3))
+            # With lanes: the motion MLP (two 3x3 convs on the blocks' plane output), its 1x1 head and the H/8 synthesis run on lane 1
+            # beside the two feature-enhancement blocks (which read the blocks' fp32 output and write their own buffers); both meet
+            # at the warps of the enhanced features below.
+            mlp_in, t2 = self._motion_branch(ops, P, "local_motion_atmformer", "local_motion_mlp", x_tokens, b, h, w,
+                                             self.local_motion_args["window_size"], "l", mlp_lane=1 if lanes else None)
+
+            def motion_tail():
+                self._head1x1(ops, P, "local_motion_mlp.2", t2, b, h, w, motion8)
+                ops.warp_blend(pyr0[3], pyr1[3], motion8, a, c, t)      # synthesis at H/8 (:496-506)
+            if lanes:
+                with ops.branch(1):
+                    motion_tail()
+            else:
+                motion_tail()
             # feature enhancement (:493-494)
             x = self._stacked(mlp_in, 8, C)
             e_mid = self.buf("enh0", 2 * b * h * w, C)
             self._block(ops, P, "feat_enhance_transformer.0", x, 2 * b, h, w, 8, 0, False, e_mid, None, "e")
             enh = self.buf("enh1", 2 * b, h, w, C)
             self._block(ops, P, "feat_enhance_transformer.1", e_mid, 2 * b, h, w, 8, 4, False, enh.reshape(2 * b * h * w, C), None, "e")
-            # synthesis at H/8 and warped features (:496-506)
+            if lanes:
+                ops.join(1)
+            # warped features (:496-506)
             fl0 = motion8[..., 0:2].permute(0, 3, 1, 2)
             fl1 = motion8[..., 2:4].permute(0, 3, 1, 2)
-            a, c, t = (ops.empty(b, 3, h, w) for _ in range(3))
-            ops.warp_blend(pyr0[3], pyr1[3], motion8, a, c, t)
             w0_list.insert(0, a); w1_list.insert(0, c); it_list.insert(0, t)
             ops.flow_warp_nhwc(enh[:b], fl0, dec_in[..., 0:C])
             ops.flow_warp_nhwc(enh[b:], fl1, dec_in[..., C:2 * C])

@@ -441,6 +441,15 @@ int atmvfi_stem_fused(const float* x, int F, int H, int W, int C0, int C1, const
  * and then issues the ops in order on `stream`, stopping at the first failure (*failed_op = its index; the return value and
  * atmvfi_last_error() are that op's).  Nothing is cached inside the library: the plan is the caller's array.
  * atmvfi_plan_fn_id(name) gives the `fn` of an entry point by name (-1 if it is not a launch entry point).
+ *
+ * LANES (round 5; small frames: a forward at 256x256 is ~120 launches of 5-18 us on a few dozen CUs each, and its dependency graph has
+ * independent branches -- the local cross-scale fusion beside the global branch's feature extraction, the two feature-enhancement blocks
+ * beside the local motion MLP): atmvfi_plan_run_lanes() issues op i on streams[lanes[i]] and understands two more ops,
+ *   fn = ATMVFI_PLAN_RECORD, a[0].i = e : hipEventRecord(events[e], streams[lanes[i]])
+ *   fn = ATMVFI_PLAN_WAIT,   a[0].i = e : hipStreamWaitEvent(streams[lanes[i]], events[e])
+ * The streams and events are the caller's (lane 0 = the stream whose order the caller sees; every other lane must be joined back into
+ * it -- RECORD on that lane, WAIT on lane 0 -- before the plan ends); the same kernels run, in a partial order: results are bit-identical
+ * to atmvfi_plan_run() on one stream as long as concurrent branches touch disjoint memory, which is the recorder's obligation.
  * ---------------------------------------------------------------------------------- */
 typedef union atmvfi_plan_arg { uint64_t u; int64_t i; double f; } atmvfi_plan_arg;
 #define ATMVFI_PLAN_MAX_ARGS 28
@@ -453,6 +462,11 @@ typedef struct atmvfi_plan_patch { int32_t op, arg, slot, reserved; int64_t offs
 int atmvfi_plan_fn_id(const char* name);
 int atmvfi_plan_run(atmvfi_plan_op* ops, int n_ops, const atmvfi_plan_patch* patches, int n_patches, const uint64_t* slots, int n_slots,
                     int* failed_op, void* stream);
+#define ATMVFI_PLAN_RECORD (-2)
+#define ATMVFI_PLAN_WAIT (-3)
+int atmvfi_plan_run_lanes(atmvfi_plan_op* ops, int n_ops, const int32_t* lanes, const atmvfi_plan_patch* patches, int n_patches,
+                          const uint64_t* slots, int n_slots, int* failed_op, void* const* streams, int n_streams, void* const* events,
+                          int n_events);
 
 #ifdef __cplusplus
 }

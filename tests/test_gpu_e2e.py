@@ -622,6 +622,34 @@ def test_launch_plan_equals_direct_launches_at_1080p_base(dev, weights):
     torch.cuda.empty_cache()
 
 
+def test_lanes_equal_single_stream(dev, weights):
+    """Branches of the forward on side streams (HipOps.branch / join, atmvfi_plan_run_lanes): the same kernels
+    in a partial order -- bit for bit the single-stream forward, on direct launches and replayed from a launch plan, for both variants,
+    global branch on and off, batch 1 and 2, call after call (a race between concurrent branches would show as a run-to-run difference)."""
+    for variant, cls, (bsz, H, W), glob in (("lite", pkg.NetworkLite, (1, 256, 256), True), ("lite", pkg.NetworkLite, (2, 256, 448), False),
+                                            ("base", pkg.NetworkBase, (1, 192, 320), True), ("base", pkg.NetworkBase, (1, 576, 960), True)):
+        net = cls()
+        net.load_state_dict(weights(variant), strict=True)
+        net.global_motion = glob
+        net.to(dev).eval()
+        p0 = [t.to(dev) for t in pairs.random_pair(bsz, H, W, seed=11)]
+        p1 = [t.to(dev) for t in pairs.smooth_pair(bsz, H, W, seed=12)]
+        net.use_lanes = False
+        net.enable_plans(False)
+        want = [[t.clone() for t in _flat(net(*p))] for p in (p0, p1)]
+        net.use_lanes = True
+        for plans in (False, True):
+            net.enable_plans(plans)
+            for rep in range(5):
+                for p, w in zip((p0, p1), want):
+                    for t, r in zip(_flat(net(*p)), w):
+                        assert torch.equal(t, r), (variant, H, W, plans, rep)
+        recorded = [p for p in net._plans.values() if not isinstance(p, (int, bool))]
+        assert recorded and all(p.n_lanes == 2 and p.n_events >= (4 if glob else 2) for p in recorded)
+        net.release_workspace()
+    torch.cuda.empty_cache()
+
+
 def test_library_that_ran_is_built_from_these_sources(dev):
     """On the GPU box: the library this process loaded reports the digest of the sources in this tree (tools/source_digest.py)."""
     import sys
