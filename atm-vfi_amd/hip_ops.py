@@ -476,6 +476,8 @@ class LaunchPlan:
                 self.c_ops[k].a[j].u = sl[slot] + off
             rc = 0
             for i in range(len(self.ops_list)):
+                if self.c_ops[i].fn in (PLAN_RECORD, PLAN_WAIT):        # (one stream, synchronised after every op: the lane ordering is moot)
+                    continue
                 print(f"plan op {i} {names.get(self.c_ops[i].fn)} args " + " ".join(hex(self.c_ops[i].a[j].u) for j in range(self.c_ops[i].nargs)),
                       file=sys.stderr, flush=True)
                 one = ctypes.cast(ctypes.byref(self.c_ops[i]), ctypes.POINTER(PlanOp))
