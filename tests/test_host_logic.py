@@ -437,6 +437,26 @@ def test_plan_run_patches_dispatches_and_reports_the_failing_op():
     assert lib.atmvfi_plan_run(ops, 1, None, 0, None, 0, ctypes.byref(failed), None) != 0
     patches[0].slot = 7
     assert lib.atmvfi_plan_run(ops, 2, patches, 1, slots, 2, ctypes.byref(failed), None) != 0 and b"out of range" in lib.atmvfi_last_error()
+    # atmvfi_plan_run_lanes: an op on a lane without a stream, a synchronisation op without / outside the event table and a stream
+    # table of length zero are refused with the op's index before anything is issued; the recorder's LaunchPlan keeps lanes and events
+    ops[0].fn, ops[0].nargs = fid, 6
+    lanes = (ctypes.c_int32 * 2)(0, 3)
+    streams = (ctypes.c_void_p * 1)(None)
+    rc = lib.atmvfi_plan_run_lanes(ops, 2, lanes, None, 0, None, 0, ctypes.byref(failed), streams, 1, None, 0)
+    assert rc != 0 and failed.value == 0                     # op 0 itself: B = 0 is the entry point's EINVAL, on lane 0
+    ops[0].fn, ops[0].nargs = hip_ops.PLAN_RECORD, 1
+    ops[0].a[0].i = 0
+    assert lib.atmvfi_plan_run_lanes(ops, 2, lanes, None, 0, None, 0, ctypes.byref(failed), streams, 1, None, 0) != 0 and failed.value == 0
+    assert b"event" in lib.atmvfi_last_error()
+    ops[0].fn, ops[0].nargs = fid, 6
+    lanes[0] = 1
+    assert lib.atmvfi_plan_run_lanes(ops, 2, lanes, None, 0, None, 0, ctypes.byref(failed), streams, 1, None, 0) != 0 and failed.value == 0
+    assert b"lane" in lib.atmvfi_last_error()
+    assert lib.atmvfi_plan_run_lanes(ops, 2, lanes, None, 0, None, 0, ctypes.byref(failed), None, 0, None, 0) != 0
+    plan = hip_ops.LaunchPlan(lib, ())
+    plan.add_sync(hip_ops.PLAN_RECORD, 0, 0)
+    plan.add_sync(hip_ops.PLAN_WAIT, 0, 1)
+    assert plan.lanes == [0, 1] and plan.n_events == 1 and [k for k, _ in plan.ops_list] == [hip_ops.PLAN_RECORD, hip_ops.PLAN_WAIT]
 
 
 def test_launch_plan_recorder_on_the_host():
