@@ -4,6 +4,7 @@
 #include "common.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -238,6 +239,178 @@ __global__ __launch_bounds__(256) void dwconv_gelu_rows_kernel(const float* __re
         if (xedge) run(std::false_type{}, std::true_type{});
         else run(std::false_type{}, std::false_type{});
     }
+}
+
+// LDS-DMA variant for the plane sink (the Mlp's dw-conv always feeds fc2's split planes).  The sliding-window kernel above keeps ONE
+// row of prefetch in registers and runs 3 waves per SIMD (158 registers): ~12 KB of unique input in flight per CU, and it reaches
+// 4.0 TB/s of algorithmic traffic where a plain fp32 -> planes copy (split_planes) reaches 5.6.  Here every WAVE owns 8 x-positions x
+// 32 channels and a private ring of DW_RING input rows in LDS (10 columns x 128 B: its 8 columns + the two neighbours), filled by
+// global_load_lds_dwordx4 DW_RING rows ahead: no register holds a value in flight, the fetch depth is the ring's, nothing is shared
+// between waves (no barrier; a wave's own counted vmcnt orders its reads behind its DMA).  Per input row: two DMA instructions (1 KiB +
+// 256 B on lanes 0-15), three ds_read_b128 per lane (the new row of the 3x3 window; the other two rows stay in registers), and per
+// output row the two 8-byte plane stores -- the vmcnt immediates count all of them (vmcnt retires in issue order on gfx9).
+// Every strip has exactly RS output rows (the launcher picks RS | H, or lets the last strip overlap the one before: same values
+// written twice), so the instruction stream -- and the counts -- are the same for every wave.  Arithmetic and its order are those of
+// the sliding-window kernel: bit-identical results.
+constexpr int DW_RING = 6;          // (5, 6 and 7 rows measure the same: tools/dw_ab.sh, profiles/r05_dwconv_dma_ab.txt)
+constexpr int DW_SLOT = 10 * 128;
+template <int OFF>
+__device__ __forceinline__ void lds_read4f(f32x4& d, unsigned addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field is 16 bits");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// VM operations a wave has issued behind the DMA of input row j when it comes to wait for that row at the top of step j.  Program order:
+// prologue DMA(0) .. DMA(DW_RING - 1); step i: [DMA(i + DW_RING) if that row exists], [the two stores of output row i - 2 if i >= 2].
+template <int RS>
+constexpr int dw_behind(int j) {
+    const int rows = RS + 2;
+    int n = 0;
+    if (j < DW_RING) {
+        n += 2 * ((DW_RING < rows ? DW_RING : rows) - 1 - j);
+        for (int i = 0; i < j; ++i) n += (i + DW_RING < rows ? 2 : 0) + (i >= 2 ? 2 : 0);
+    } else {
+        const int i0 = j - DW_RING;          // the step that issued DMA(j)
+        n += i0 >= 2 ? 2 : 0;
+        for (int i = i0 + 1; i < j; ++i) n += (i + DW_RING < rows ? 2 : 0) + (i >= 2 ? 2 : 0);
+    }
+    return n;
+}
+template <int RS>
+__global__ __launch_bounds__(256) void dwconv_gelu_dma_kernel(const float* __restrict__ in, int in_ld, _Float16* __restrict__ out_hi,
+                                                              _Float16* __restrict__ out_lo, long long plane_rows,
+                                                              const float* __restrict__ w9, const float* __restrict__ bias, int N, int H,
+                                                              int W, int C, int xgroups, int cblocks, int strips) {
+    static_assert(RS + 2 >= DW_RING, "the prologue fills the whole ring");
+    fp16_saturate_on();
+    extern __shared__ __attribute__((aligned(16))) unsigned char dw_smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // unit = one wave's strip: x-group fastest (the four waves of a block are neighbours in x and share their halo columns in L1),
+    // then the 32-channel block (adjacent 128-byte lines), the strip, the image
+    unsigned u = blockIdx.x * 4u + (unsigned)wave;          // (the launcher keeps the unit count below 2^31)
+    const int xg = (int)(u % (unsigned)xgroups); u /= (unsigned)xgroups;
+    const int cbk = (int)(u % (unsigned)cblocks); u /= (unsigned)cblocks;
+    const int sb = (int)(u % (unsigned)strips);
+    const int n = (int)(u / (unsigned)strips);
+    if (n >= N) return;
+    int y0 = sb * RS;
+    if (y0 + RS > H) y0 = H - RS;          // (the last strip of a map whose height RS does not divide overlaps the previous one)
+    const int c = cbk * 32 + ((lane & 7) << 2);
+    const int x = xg * 8 + (lane >> 3);
+    unsigned char* ring = dw_smem + wave * (DW_RING * DW_SLOT);
+    const unsigned rd = lds_offset(ring) + (unsigned)(lane * 16);      // column (lane >> 3) of a slot = x - 1; + 128 k: x - 1 + k
+
+    f32x4 wv[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const f32x4*>(w9 + t * C + c);
+    f32x4 bv = *reinterpret_cast<const f32x4*>(bias + c);
+    const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool xm_ok = x > 0, xp_ok = x + 1 < W;
+    // borders as in the sliding-window kernel: a column outside the image has zero weights and a clamped (valid) load address; the waves
+    // on the image's left / right edge also select a zero VALUE; a row outside the image (row -1 of the first strip, row H of the last)
+    // is loaded from a clamped address and replaced by zeros
+    // DMA sources: piece A = columns 0..7 of the slot (x-group's x - 1 .. + 6), piece B = columns 8, 9 on lanes 0..15
+    auto clampx = [&](int xx) { return xx < 0 ? 0 : (xx >= W ? W - 1 : xx); };
+    const int xa = clampx(xg * 8 - 1 + (lane >> 3));
+    const int xb = clampx(xg * 8 + 7 + ((lane >> 3) & 1));
+    const long long img = (long long)n * H * W;
+    const float* src_a = in + (img + xa) * in_ld + c;
+    const float* src_b = in + (img + xb) * in_ld + c;
+    const long long row_stride = (long long)W * in_ld;
+    auto issue_row = [&](int j) {          // input row j of the strip = image row y0 - 1 + j -> slot j % DW_RING
+        int y = y0 - 1 + j;
+        y = y < 0 ? 0 : (y >= H ? H - 1 : y);
+        unsigned char* dst = ring + (j % DW_RING) * DW_SLOT;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_a + y * row_stride),
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        // piece B on lanes 0..15 only, as ONE instruction whatever the compiler makes of the code around it (an `if (lane < 16)` around the
+        // builtin was tail-merged with the next row's piece A in the 8-row instance: four DMA instructions where the counts assume
+        // three).  EXEC is all ones here (wave-uniform control flow, full waves); M0 is written in the statement that uses it.
+        unsigned keep_m0;
+        unsigned long long keep_exec;
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_mov_b64 %1, exec\n\t"
+                     "s_mov_b32 m0, %3\n\t"
+                     "s_mov_b64 exec, 0xffff\n\t"
+                     "global_load_lds_dwordx4 %2, off\n\t"
+                     "s_mov_b64 exec, %1\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep_m0), "=&s"(keep_exec)
+                     : "v"(src_b + y * row_stride), "s"(lds_offset(dst + 1024))
+                     : "memory");
+    };
+    const bool top = y0 == 0, bottom = y0 + RS == H;
+    const long long orow0 = img + (long long)y0 * W + x;
+    const long long obase = ((long long)(c >> 5) * plane_rows) * 32 + (c & 31);
+    // the whole ring goes in flight behind the weight loads and before their first use (hipcc counts the DMAs in its wait for the weights)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < DW_RING; ++j) issue_row(j);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        if (!xm_ok) wv[ky * 3 + 0] = zero;
+        if (!xp_ok) wv[ky * 3 + 2] = zero;
+    }
+
+    auto run = [&](auto xedge_tag) {
+        constexpr bool XEDGE = decltype(xedge_tag)::value;
+        f32x4 win[3][3];
+        static_for<0, RS + 2>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            constexpr int slot = (j % DW_RING) * DW_SLOT;
+            wait_vmcnt<dw_behind<RS>(j)>();
+            lds_read4f<slot>(win[j % 3][0], rd);
+            lds_read4f<slot + 128>(win[j % 3][1], rd);
+            lds_read4f<slot + 256>(win[j % 3][2], rd);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(win[j % 3][0]), "+v"(win[j % 3][1]), "+v"(win[j % 3][2])::"memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (j + DW_RING < RS + 2) issue_row(j + DW_RING);
+            __builtin_amdgcn_sched_barrier(0);       // (the counts above assume this order: DMA, then the step's stores)
+            if constexpr (j == 0) {
+                if (top) { win[0][0] = zero; win[0][1] = zero; win[0][2] = zero; }
+            }
+            if constexpr (j == RS + 1) {
+                if (bottom) { win[j % 3][0] = zero; win[j % 3][1] = zero; win[j % 3][2] = zero; }
+            }
+            if constexpr (j >= 2) {
+                constexpr int r = j - 2;
+                f32x2 a01 = bv.xy, a23 = bv.zw;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const f32x4* row = win[(r + ky) % 3];
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        f32x4 v = row[kx];
+                        const f32x4 wt = wv[ky * 3 + kx];
+                        if (XEDGE && kx != 1) v = (kx == 0 ? xm_ok : xp_ok) ? v : zero;
+                        a01 = __builtin_elementwise_fma(v.xy, wt.xy, a01);
+                        a23 = __builtin_elementwise_fma(v.zw, wt.zw, a23);
+                    }
+                }
+                f32x4 o;
+                o.x = gelu_erf2(a01.x);
+                o.y = gelu_erf2(a01.y);
+                o.z = gelu_erf2(a23.x);
+                o.w = gelu_erf2(a23.y);
+                f16x2 h0, l0, h1, l1;
+                split_pair((f32x2){o.x, o.y}, h0, l0);
+                split_pair((f32x2){o.z, o.w}, h1, l1);
+                const f16x4 h = {h0.x, h0.y, h1.x, h1.y}, l = {l0.x, l0.y, l1.x, l1.y};
+                const long long off = obase + (orow0 + (long long)r * W) * 32;
+                // (x >= W: lanes of the last x-group past the image; the store instructions are still issued -- some lane of the group is inside)
+                if (x < W) {
+                    *reinterpret_cast<f16x4*>(out_hi + off) = h;
+                    *reinterpret_cast<f16x4*>(out_lo + off) = l;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+    };
+    if (xg == 0 || xg == xgroups - 1) run(std::true_type{});
+    else run(std::false_type{});
 }
 
 __global__ void pack_dw_kernel(const float* __restrict__ src, float* __restrict__ dst, int C) {
@@ -1011,6 +1184,29 @@ extern "C" int atmvfi_dwconv3x3_gelu(const float* in, int in_ld, float* out, int
     const RowSink sink{out, out_ld, (_Float16*)out_hi, (_Float16*)out_lo, plane_ld};
     ATMVFI_REQUIRE(atmvfi::aligned16(in) && atmvfi::aligned16(out) && atmvfi::aligned16(weight9) && atmvfi::aligned16(bias),
                    ATMVFI_EALIGN, "dwconv3x3_gelu: pointers must be 16-byte aligned");
+    static const bool rows_only = getenv("ATMVFI_DWCONV_ROWS") != nullptr;     // diagnostic: same-box A/B against the sliding-window kernel (tools/dw_ab.sh)
+    if (!out && C % 64 == 0 && H >= 8 && !rows_only) {
+        // plane sink only: the LDS-DMA kernel (one wave = 8 x-positions x 32 channels x RS rows; C % 64 as for the sliding-window kernel,
+        // whose fused multiply-adds it repeats -- the per-pixel kernel below rounds products and sums separately).  RS: the tallest strip that divides H
+        // (1088 / 8 = 136 = 8 x 17), else 16 (or 8) with the last strip overlapping the one before
+        const int xgroups = (W + 7) / 8, cblocks = C / 32;
+        int RS = H % 17 == 0 ? 17 : H % 16 == 0 ? 16 : H % 8 == 0 ? 8 : H >= 16 ? 16 : 8;
+        // (small maps: 8-row strips when the taller ones leave fewer than two waves per SIMD)
+        if ((long long)N * ((H + RS - 1) / RS) * xgroups * cblocks < 8ll * atmvfi::cu_count()) RS = 8;
+        const int strips = (H + RS - 1) / RS;
+        const long long units = (long long)N * strips * xgroups * cblocks;
+        const long long blocks = (units + 3) / 4;
+        ATMVFI_REQUIRE(units < (1ll << 31), ATMVFI_EINVAL, "dwconv3x3_gelu: grid too large");
+        const size_t lds = 4 * DW_RING * DW_SLOT;
+        auto go = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, in, in_ld, (_Float16*)out_hi,
+                               (_Float16*)out_lo, (long long)plane_ld, weight9, bias, N, H, W, C, xgroups, cblocks, strips);
+        };
+        if (RS == 17) go(dwconv_gelu_dma_kernel<17>);
+        else if (RS == 16) go(dwconv_gelu_dma_kernel<16>);
+        else go(dwconv_gelu_dma_kernel<8>);
+        return atmvfi::check_launch("dwconv3x3_gelu");
+    }
     if (C % 64 == 0) {     // sliding-window kernel: 16 x-positions x 64 channels per block, strips of 8 or 16 rows
         // a strip re-reads its two neighbour rows: 10 / 8 of the input with 8-row strips, 18 / 16 with 16-row ones; the taller strip
         // when it still leaves a few blocks per CU

@@ -234,6 +234,34 @@ def test_dwconv_gelu(shape, hip, cpu, dev):
     assert maxdiff(og, oc) <= 2e-5
 
 
+@pytest.mark.parametrize("shape", [(2, 34, 24, 192), (1, 17, 37, 448), (2, 16, 9, 64), (1, 32, 40, 128), (1, 24, 5, 64), (2, 19, 21, 320),
+                                   (1, 11, 8, 64), (1, 8, 64, 64), (1, 136, 16, 1536)], ids=lambda s: "x".join(map(str, s)))
+def test_dwconv_gelu_dma_planes(shape, hip, dev):
+    """Plane sink only -> the LDS-DMA kernel (a private row ring per wave, counted vmcnt): strips of 17 / 16 / 8 rows that divide H, the
+    overlapping last strip when none does, x-groups cut by the image edge, W < 8.  Its
+    planes are the exact split of the sliding-window kernel's fp32 rows (same arithmetic in the same order), Inf in an edge column
+    included (zero padding adds nothing: ADVICE round 4)."""
+    n, h, w_, c = shape
+    g = torch.Generator().manual_seed(60 + h + c)
+    x = rnd(g, n, h, w_, c, scale=2.0).to(dev)
+    x[0, h // 2, 0, 3] = float("inf")
+    x[-1, 0, w_ - 1, c - 1] = float("-inf")
+    wt = hip.pack_dw_weight(rnd(g, c, 1, 3, 3, scale=0.5).to(dev))
+    b = rnd(g, c, scale=0.3).to(dev)
+    of = torch.empty(n, h, w_, c, device=dev)
+    hip.dwconv_gelu(x, of, wt, b)                      # fp32 rows: the sliding-window (or per-pixel) kernel
+    p = hip_ops.Planes.alloc(n * h * w_, c, dev)
+    hip.dwconv_gelu(x, None, wt, b, planes=p)
+    torch.cuda.synchronize()
+    rows = of.reshape(-1, c)
+    hi = torch.where(torch.isinf(rows), rows, rows.clamp(-65504, 65504)).half()      # (finite values saturate, an infinity stays one)
+    lo = ((rows - hi.float()) * 1024).clamp(-65504, 65504).half()
+    got = p.to_rows()
+    same = lambda a, b_: torch.equal(torch.nan_to_num(a.float(), nan=-7.0), torch.nan_to_num(b_.float(), nan=-7.0))
+    assert same(got[0, :, :c], hi) and same(got[1, :, :c], lo)
+    assert torch.isinf(rows).sum() > 0
+
+
 ATTN_CASES = [
     # ws, hd, frames, h, w, shift, cross
     (8, 48, 2, 16, 24, 0, True), (8, 48, 2, 16, 24, 4, True), (8, 28, 2, 12, 20, 4, True),     # 12x20 -> pad 16x24 + shift

@@ -139,6 +139,68 @@ def check_pp(asm_text):
     return problems
 
 
+def check_dw_dma(asm_text):
+    """dwconv_gelu_dma_kernel<RS> (pointwise.hip): every wave fills a private LDS ring by LDS-DMA and waits for input row j with a vmcnt
+    immediate that counts what it has issued behind that row's DMA -- two DMA instructions per row, two plane stores per output row, in
+    that order.  Per instance: no spill; the prologue puts DW_RING rows in flight; then two copies of the body (image-edge x-groups / the
+    others), each RS + 2 steps of {counted wait, three ds_read_b128, lgkmcnt(0), [2 DMA], [2 stores]}; replaying the instruction stream,
+    the DMA of row j must be exactly N + 1 .. N + 2 operations back at its `s_waitcnt vmcnt(N)`; no other vmcnt wait inside a body."""
+    problems = []
+    lines = asm_text.splitlines()
+    ring = 6
+    for rs in (8, 16, 17):
+        starts = [i for i, l in enumerate(lines) if re.match(rf"^_ZN\S*dwconv_gelu_dma_kernelILi{rs}E\S*:", l)]
+        if not starts:
+            problems.append(f"dw_dma<{rs}>: kernel not found")
+            continue
+        end = next(i for i in range(starts[0], len(lines)) if ".end_amdhsa_kernel" in lines[i] or lines[i].startswith(".Lfunc_end"))
+        body = lines[starts[0]:end]
+        if any(re.search(r"scratch_(load|store)", l) for l in body):
+            problems.append(f"dw_dma<{rs}>: register spill")
+        ev = []
+        for l in body:
+            t = l.strip()
+            if t.startswith("global_load_lds_dwordx4"):
+                ev.append("dma")
+            elif t.startswith("global_store_dwordx2"):
+                ev.append("store")
+            elif t.startswith("global_store") or t.startswith("global_load") or t.startswith("buffer_") or t.startswith("flat_"):
+                ev.append("other")
+            elif t.startswith("s_waitcnt") and "vmcnt(" in t:
+                ev.append(int(re.search(r"vmcnt\((\d+)\)", t).group(1)))
+        rows = rs + 2
+        # prologue: the weight loads ("other"), 2 * ring DMAs, hipcc's own wait for the weights
+        k = 0
+        while k < len(ev) and ev[k] == "other":
+            k += 1
+        if ev[k:k + 2 * ring] != ["dma"] * (2 * ring):
+            problems.append(f"dw_dma<{rs}>: the prologue does not issue {2 * ring} DMAs behind the weight loads")
+            continue
+        k += 2 * ring
+        while k < len(ev) and isinstance(ev[k], int) and ev[k] == 0:
+            k += 1
+        for copy in range(2):
+            queue = [("dma", j) for j in range(ring) for _ in range(2)]          # what is in flight, oldest first (upper bound)
+            for j in range(rows):
+                if k >= len(ev) or not isinstance(ev[k], int):
+                    problems.append(f"dw_dma<{rs}> body {copy}, step {j}: expected a counted vmcnt wait, found {ev[k] if k < len(ev) else 'the end'}")
+                    break
+                last = max(i for i, q in enumerate(queue) if q == ("dma", j))
+                behind = len(queue) - 1 - last
+                if ev[k] != behind:
+                    problems.append(f"dw_dma<{rs}> body {copy}, step {j}: vmcnt({ev[k]}) but {behind} operations were issued behind row {j}'s DMA")
+                k += 1
+                want = (["dma", "dma"] if j + ring < rows else []) + (["store", "store"] if j >= 2 else [])
+                if ev[k:k + len(want)] != want:
+                    problems.append(f"dw_dma<{rs}> body {copy}, step {j}: expected {want}, found {ev[k:k + len(want)]}")
+                    break
+                k += len(want)
+                queue += [("dma", j + ring)] * (2 if j + ring < rows else 0) + [("store", j - 2)] * (2 if j >= 2 else 0)
+        if k != len(ev):
+            problems.append(f"dw_dma<{rs}>: {len(ev) - k} unexpected vector-memory operations / waits after the two bodies: {ev[k:k + 6]}")
+    return problems
+
+
 def check_no_slp_pairs(asm_text, what):
     """No packed fp32 instruction with a LOW-half operand select (v_pk_*_f32 ... op_sel:[..]): the library's own f32x2 code only ever
     broadcasts through op_sel_hi; op_sel:[..] on fp32 pairs is the shape the SLP vectorizer builds when it pairs (x, y) chains, and
@@ -182,6 +244,7 @@ def main():
         problems += check_pp(pp)
         if "-fno-slp-vectorize" not in makefile_flags():
             problems.append("csrc/Makefile: CXXFLAGS lost -fno-slp-vectorize")
+        problems += check_dw_dma(compile_asm("pointwise.hip", os.path.join(td, "pointwise.s")))
         for name, text in (("gemm_pp.hip", pp), ("attention.hip", compile_asm("attention.hip", os.path.join(td, "attn.s"))),
                            ("stem.hip", compile_asm("stem.hip", os.path.join(td, "stem.s")))):
             problems += check_no_slp_pairs(text, name)
