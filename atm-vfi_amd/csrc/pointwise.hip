@@ -1184,7 +1184,11 @@ extern "C" int atmvfi_dwconv3x3_gelu(const float* in, int in_ld, float* out, int
     const RowSink sink{out, out_ld, (_Float16*)out_hi, (_Float16*)out_lo, plane_ld};
     ATMVFI_REQUIRE(atmvfi::aligned16(in) && atmvfi::aligned16(out) && atmvfi::aligned16(weight9) && atmvfi::aligned16(bias),
                    ATMVFI_EALIGN, "dwconv3x3_gelu: pointers must be 16-byte aligned");
-    static const bool rows_only = getenv("ATMVFI_DWCONV_ROWS") != nullptr;     // diagnostic: same-box A/B against the sliding-window kernel (tools/dw_ab.sh)
+#if defined(ATMVFI_ABLATE)
+    static const bool rows_only = getenv("ATMVFI_DWCONV_ROWS") != nullptr;     // diagnostic builds only (make ablate): same-box A/B against the sliding-window kernel, tools/dw_ab.sh
+#else
+    constexpr bool rows_only = false;
+#endif
     if (!out && C % 64 == 0 && H >= 8 && !rows_only) {
         // plane sink only: the LDS-DMA kernel (one wave = 8 x-positions x 32 channels x RS rows; C % 64 as for the sliding-window kernel,
         // whose fused multiply-adds it repeats -- the per-pixel kernel below rounds products and sums separately).  RS: the tallest strip that divides H
