@@ -244,6 +244,10 @@ def test_dwconv_gelu_dma_planes(shape, hip, dev):
     n, h, w_, c = shape
     g = torch.Generator().manual_seed(60 + h + c)
     x = rnd(g, n, h, w_, c, scale=2.0).to(dev)
+    if h == 19:      # a channel slice of a wider map (row pitch > C): the DMA sources step by the pitch
+        wide = torch.full((n, h, w_, c + 64), 7.0, device=dev)
+        wide[..., 64:] = x
+        x = wide[..., 64:]
     x[0, h // 2, 0, 3] = float("inf")
     x[-1, 0, w_ - 1, c - 1] = float("-inf")
     wt = hip.pack_dw_weight(rnd(g, c, 1, 3, 3, scale=0.5).to(dev))
