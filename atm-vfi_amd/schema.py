@@ -277,14 +277,19 @@ _STRESS_GAINS = {
 }
 
 
-def synthetic_state_dict(variant: str, seed: int = 0) -> Dict[str, torch.Tensor]:
+def synthetic_state_dict(variant: str, seed: int = 0, motion_gain: float = 1.0) -> Dict[str, torch.Tensor]:
     """Deterministic *stress* weights for parity tests and the benchmark.
 
     Reference init leaves every bias at zero, every PReLU at 0.25 and the flows at
     ~0.03 px, which would leave the bias/PReLU/LayerNorm-affine/warp
     paths almost untested.  Here biases, LN affine terms and PReLU slopes are
     randomised and the motion heads are scaled (``_STRESS_GAINS``) so flows reach
-    about a pixel at every pyramid level without pushing content out of frame."""
+    about a pixel at every pyramid level without pushing content out of frame.
+
+    ``motion_gain`` > 1 is the *large-motion* weight set: the four flow rows (weights and biases) of every motion head -- global
+    (network_base.py:391-415), local (:367-389) and the three decoder stages (:511-521) -- are multiplied by it on top of the stress
+    gains, so the flows reach tens of pixels at full resolution: the regime the global branch exists for (:457-485), where the tiled
+    warps overflow their staged bounding boxes and taps leave the frame.  Everything else (and the RNG stream) is unchanged."""
     v = VARIANTS[variant]
     gen = torch.Generator().manual_seed(seed)
     sd: Dict[str, torch.Tensor] = {}
@@ -303,9 +308,9 @@ def synthetic_state_dict(variant: str, seed: int = 0) -> Dict[str, torch.Tensor]
 
     def scale_head(wkey: str, bkey: str, gains):
         fg, fb, mg = gains
-        sd[wkey][-MOTION_OUT:-1] *= fg
+        sd[wkey][-MOTION_OUT:-1] *= fg * motion_gain
         sd[wkey][-1] *= mg
-        sd[bkey][-MOTION_OUT:-1] = torch.randn(4, generator=gen) * fb
+        sd[bkey][-MOTION_OUT:-1] = torch.randn(4, generator=gen) * (fb * motion_gain)
 
     scale_head("global_motion_mlp.2.weight", "global_motion_mlp.2.bias", g["global"])
     scale_head("local_motion_mlp.2.weight", "local_motion_mlp.2.bias", g["local"])

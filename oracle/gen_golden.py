@@ -125,6 +125,14 @@ E2E_CASES = [
     ("base_384x576_ens_b3_mixed", "base", 3, 384, 576, True, True, "mixed", 40, 4),
     # BASELINE config C5: 2160x4096 through test_xiph.py:115-128's InputPadder(divisor 32) = 2176x4096, untiled, global on
     ("base_2176x4096_g_c5", "base", 1, 2176, 4096, True, False, "smooth", 25, 16),
+    # LARGE MOTION (an 11th field: ``motion_gain`` of schema.synthetic_state_dict): the flow rows of every motion head x4, so that the
+    # global branch moves content by tens of pixels (network_base.py:391-415, 457-485), the decoder flows reach 50-70 px
+    # (:511-525) and taps leave the frame (flow_warp.py:26-60).  The manifest records flow|max| at every level's warp and the number
+    # of 32 x 8 output tiles whose taps do not fit the tiled warps' 64 x 24 staged box (golden_util.tiled_warp_fallback_tiles: the
+    # gather fallback of pointwise.hip); tests/test_oracle_golden.py asserts both are non-trivial.
+    ("base_384x576_g_large", "base", 1, 384, 576, True, False, "smooth", 26, 2, 4.0),
+    ("lite_384x576_g_large", "lite", 1, 384, 576, True, False, "smooth", 27, 2, 4.0),
+    ("base_1088x1920_g_large", "base", 1, 1088, 1920, True, False, "smooth", 28, 8, 4.0),   # BASELINE config C4's shape, strided store
 ]
 # (name, variant, H, W, global): uint8 frames through demo_2x.inference_2frame (demo_2x.py:54-87)
 DEMO_CASES = [
@@ -136,11 +144,17 @@ DEMO_CASES = [
 LARGE = {"base_2176x4096_g_c5"}     # minutes of CPU time and ~30 GB of host memory each
 
 
+def case_fields(c):
+    """(name, variant, B, H, W, global, ensemble, kind, seed, step, motion_gain)"""
+    return tuple(c) + ((1.0,) if len(c) == 10 else ())
+
+
 def generate(gold: str, only=None) -> dict:
     """Write the fixtures into ``gold``; returns the manifest.  ``only``: set of case / op names (None = all)."""
     ref = import_reference()
     sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
     import pairs
+    import golden_util
     schema = importlib.import_module("atm-vfi_amd.schema")
     from oracle import atmvfi_oracle as O
 
@@ -171,15 +185,32 @@ def generate(gold: str, only=None) -> dict:
         sds[v] = schema.synthetic_state_dict(v, seed=1)
         nets[v] = mod.Network().eval()
         nets[v].load_state_dict(sds[v], strict=True)      # pins names+shapes
-    for (name, v, b, h, w, g, ens, kind, seed, step) in E2E_CASES:
+    for (name, v, b, h, w, g, ens, kind, seed, step, mgain) in map(case_fields, E2E_CASES):
         if not want(name):
             continue
         im0, im1 = pairs.PAIR_KINDS[kind](b, h, w, seed)
+        sd_case = sds[v]
+        if mgain != 1.0:
+            sd_case = schema.synthetic_state_dict(v, seed=1, motion_gain=mgain)
+            drop_mask_cache(nets[v])
+            nets[v].load_state_dict(sd_case, strict=True)
         net = nets[v]
         drop_mask_cache(net)
         net.global_motion = g
         net.ensemble_global_motion = ens
-        out = net(im0, im1)
+        warp_log = []          # (channels, H, W, flow|max|) of every flow_warp call of the reference's forward, in call order
+        if mgain != 1.0:
+            real_warp = mods[v].flow_warp
+
+            def spy(feature, flow, *a, _real=real_warp, **k):
+                warp_log.append([int(feature.shape[1]), int(feature.shape[2]), int(feature.shape[3]), float(flow.abs().max())])
+                return _real(feature, flow, *a, **k)
+            mods[v].flow_warp = spy
+        try:
+            out = net(im0, im1)
+        finally:
+            if mgain != 1.0:
+                mods[v].flow_warp = real_warp
         arrs = {
             "I_t": sub(out["I_t"], step),
             "im_t0": sub(out["im_t_list"][0], step),
@@ -199,10 +230,18 @@ def generate(gold: str, only=None) -> dict:
         np.savez_compressed(os.path.join(gold, name + ".npz"), **arrs)
         n_lists = len(out["im_t_list"])
         flow_max = out["opt_flow_0"].abs().max().item()
+        large = {}
+        if mgain != 1.0:
+            large = {"motion_gain": mgain, "flow_max": max(flow_max, out["opt_flow_1"].abs().max().item()),
+                     "global_flow_max_full_res": max(r[3] for r in warp_log[:12] if r[1] == h),
+                     "warp_flow_max": warp_log,
+                     "fallback_tiles": [golden_util.tiled_warp_fallback_tiles(out[k].numpy()) for k in ("opt_flow_0", "opt_flow_1")],
+                     "tiles": ((h + 7) // 8) * ((w + 31) // 32) * b,
+                     "out_of_frame_fraction": float((golden_util.taps_out_of_frame(out["opt_flow_0"].numpy())).mean())}
         keep = {k: out[k] for k in ("I_t",)}
         lists = [t for t in out["im_t_list"]]
         del out
-        ora = O.forward(sds[v], im0, im1, global_motion=g, ensemble_global_motion=ens)
+        ora = O.forward(sd_case, im0, im1, global_motion=g, ensemble_global_motion=ens)
         picks = []
         if ens:      # which level each sample's global flow came from (the oracle is bit-identical to the reference on these cases)
             O.ensemble_global_flows(sds[v], im0, im1, schema.VARIANTS[v].global_window, picks)
@@ -212,7 +251,10 @@ def generate(gold: str, only=None) -> dict:
         manifest["cases"].append({"name": name, "variant": v, "B": b, "H": h, "W": w, "global": g,
                                   "ensemble": ens, "kind": kind, "seed": seed, "step": step,
                                   "n_lists": n_lists, "oracle_vs_ref_I_t": d,
-                                  "oracle_vs_ref_lists": dl, **({"ensemble_picks": picks} if ens else {})})
+                                  "oracle_vs_ref_lists": dl, **({"ensemble_picks": picks} if ens else {}), **large})
+        if mgain != 1.0:
+            drop_mask_cache(nets[v])                       # (the lazily registered mask buffers are not in the schema)
+            nets[v].load_state_dict(sds[v], strict=True)
         print(f"{name:24s} oracle-vs-reference max|d| I_t {d:.2e} lists {dl:.2e}  flow|max| {flow_max:.2f}", flush=True)
 
     # ---- 3. demo path: uint8 frames through the reference's inference_2frame ----

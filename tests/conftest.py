@@ -31,10 +31,12 @@ def schema():
 def weights(schema):
     cache = {}
 
-    def get(variant):
-        if variant not in cache:
-            cache[variant] = schema.synthetic_state_dict(variant, seed=1)
-        return cache[variant]
+    def get(variant, motion_gain=1.0):
+        """The stress weights (seed 1); ``motion_gain`` != 1: the large-motion set of the ``*_large`` fixtures."""
+        key = (variant, float(motion_gain))
+        if key not in cache:
+            cache[key] = schema.synthetic_state_dict(variant, seed=1, motion_gain=float(motion_gain))
+        return cache[key]
     return get
 
 
