@@ -635,13 +635,17 @@ int launch_attn_x3(const float* qkv, const RowSink out, float* motion, const int
     // persistent grid: as many workgroups as the CUs hold at once (LDS, registers, threads: asked of the runtime once per instance
     // and LDS size), a multiple of 8, at most one per item
     const int vitems = (Bw + 7) / 8 * 8 * heads;
-    static std::atomic<long long> occ_cache{0};   // (lds bytes << 8) | workgroups per CU
-    long long oc = occ_cache.load(std::memory_order_relaxed);
+    // (lds bytes << 8) | workgroups per CU, cached PER DEVICE like common.h's cu_count / allow_dynamic_lds: one process may drive
+    // several GPUs (the occupancy answer belongs to the current device's copy of the function)
+    static std::atomic<long long> occ_cache[atmvfi::kMaxDevices];
+    int dev = 0;
+    const bool cached = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < atmvfi::kMaxDevices;
+    long long oc = cached ? occ_cache[dev].load(std::memory_order_relaxed) : 0;
     if ((oc >> 8) != (long long)lds || (oc & 255) == 0) {
         int n = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, window_attn_x3_kernel<NT, DCH>, 64 * NT, lds) != hipSuccess || n < 1) n = 1;
         oc = ((long long)lds << 8) | (n > 255 ? 255 : n);
-        occ_cache.store(oc, std::memory_order_relaxed);
+        if (cached) occ_cache[dev].store(oc, std::memory_order_relaxed);
     }
     const int per_cu = (int)(oc & 255);
     int grid = atmvfi::cu_count() * per_cu;

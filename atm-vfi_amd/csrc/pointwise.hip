@@ -487,6 +487,58 @@ __global__ __launch_bounds__(256) void flow_warp_planar_kernel(const float* __re
     }
 }
 
+// The non-default forms of the reference's flow_warp (flow_warp.py:50-60 -> bilinear_sample :26-47): padding_mode 'border' /
+// 'reflection' (grid_sample's coordinate maps for align_corners=True: clip to [0, size-1]; reflect about 0 and size-1, then clip)
+// and return_mask (the normalised coordinate inside [-1, 1] on both axes, evaluated on the reference's own fp32 expression
+// 2 p / (size - 1) - 1, so that a coordinate a rounding below zero is "inside" exactly when the reference says so).  Off the hot path:
+// one lane per pixel, direct gathers.  mode: 0 zeros, 1 border, 2 reflection.
+__device__ __forceinline__ float pad_coord(float c, int size, int mode) {
+    if (mode == 0) return c;
+    const float hi = (float)(size - 1);
+    if (mode == 2) {                                         // reflect_coordinates(c, 0, 2 (size - 1)) of ATen's GridSampler.h
+        if (size == 1) c = 0.f;
+        else {
+            const float a = fabsf(c), extra = fmodf(a, hi);
+            const int flips = (int)floorf(a / hi);
+            c = (flips & 1) ? hi - extra : extra;
+        }
+    }
+    return fminf(hi, fmaxf(c, 0.f));                         // clip_coordinates
+}
+__global__ __launch_bounds__(256) void flow_warp_ex_kernel(const float* __restrict__ src, const float* __restrict__ flow, float* __restrict__ dst,
+                                                           unsigned char* __restrict__ mask, int B, int C, int H, int W, int mode) {
+    fp16_saturate_on();
+    const long long hw = (long long)H * W;
+    const long long total = (long long)B * hw;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(idx / hw);
+        const long long pix = idx - (long long)b * hw;
+        const int y = (int)(pix / W), x = (int)(pix - (long long)y * W);
+        const float* fp = flow + (long long)b * 2 * hw + pix;
+        const float px = (float)x + fp[0], py = (float)y + fp[hw];
+        const float gx = 2.0f * px / (float)(W - 1) - 1.0f, gy = 2.0f * py / (float)(H - 1) - 1.0f;
+        if (mask) mask[idx] = (gx >= -1.0f) && (gy >= -1.0f) && (gx <= 1.0f) && (gy <= 1.0f);
+        const float ix = pad_coord(((gx + 1.0f) / 2.0f) * (float)(W - 1), W, mode), iy = pad_coord(((gy + 1.0f) / 2.0f) * (float)(H - 1), H, mode);
+        const float fx0 = floorf(ix), fy0 = floorf(iy);
+        const float cx = fminf(fmaxf(fx0, -2.0f), (float)W + 1.0f), cy = fminf(fmaxf(fy0, -2.0f), (float)H + 1.0f);
+        Taps t;
+        t.x0 = (int)cx;
+        t.y0 = (int)cy;
+        const float ax = ix - fx0, ay = iy - fy0;
+        const bool far = (cx != fx0) || (cy != fy0) || !(ix == ix) || !(iy == iy);
+        t.in00 = !far && t.x0 >= 0 && t.x0 < W && t.y0 >= 0 && t.y0 < H;
+        t.in01 = !far && t.x0 + 1 >= 0 && t.x0 + 1 < W && t.y0 >= 0 && t.y0 < H;
+        t.in10 = !far && t.x0 >= 0 && t.x0 < W && t.y0 + 1 >= 0 && t.y0 + 1 < H;
+        t.in11 = !far && t.x0 + 1 >= 0 && t.x0 + 1 < W && t.y0 + 1 >= 0 && t.y0 + 1 < H;
+        t.w00 = (1.0f - ax) * (1.0f - ay);
+        t.w01 = ax * (1.0f - ay);
+        t.w10 = (1.0f - ax) * ay;
+        t.w11 = ax * ay;
+        for (int c = 0; c < C; ++c)
+            dst[((long long)b * C + c) * hw + pix] = sample_plane(src + ((long long)b * C + c) * hw, t, W);
+    }
+}
+
 // flow_warp of a planar image by a planar flow AND the x2 up-sampling of that flow to the next finer level (upsample_flow,
 // network_base.py:11-18: bilinear, align_corners=True, values x 2) in one launch: the global flow's walk down the image pyramid
 // (network_base.py:468-485) is four warps and three up-samplings in a chain.  The two halves of the index space are independent
@@ -1247,6 +1299,16 @@ extern "C" int atmvfi_flow_warp(const float* src, const float* flow, int64_t flo
     hipLaunchKernelGGL(flow_warp_planar_kernel, dim3(grid_for((long long)B * H * W)), dim3(256), 0, (hipStream_t)stream, src,
                        flow, (long long)flow_bstride, flow_pstride, flow_cstride, dst, B, C, H, W);
     return atmvfi::check_launch("flow_warp");
+}
+
+extern "C" int atmvfi_flow_warp_ex(const float* src, const float* flow, float* dst, uint8_t* mask, int B, int C, int H, int W,
+                                    int padding_mode, void* stream) {
+    ATMVFI_REQUIRE(src && flow && dst, ATMVFI_EINVAL, "flow_warp_ex: null pointer");
+    ATMVFI_REQUIRE(B > 0 && C > 0 && H > 1 && W > 1, ATMVFI_EINVAL, "flow_warp_ex: bad shape (H, W must be > 1)");
+    ATMVFI_REQUIRE(padding_mode >= 0 && padding_mode <= 2, ATMVFI_EINVAL, "flow_warp_ex: padding_mode must be 0 (zeros), 1 (border) or 2 (reflection), got %d", padding_mode);
+    hipLaunchKernelGGL(flow_warp_ex_kernel, dim3(grid_for((long long)B * H * W)), dim3(256), 0, (hipStream_t)stream, src, flow, dst,
+                       (unsigned char*)mask, B, C, H, W, padding_mode);
+    return atmvfi::check_launch("flow_warp_ex");
 }
 
 extern "C" int atmvfi_flow_warp_tiled(const float* src, const float* flow, int64_t flow_bstride, int flow_pstride,

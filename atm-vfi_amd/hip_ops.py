@@ -115,6 +115,7 @@ SIGNATURES = {
     "atmvfi_motion_head_planes": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_l, c_i, c_l, c_i, c_f, c_f, c_l, c_i, c_i, c_f]),
     "atmvfi_flow_warp": (c_i, [c_f, c_f, c_l, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_f]),
     "atmvfi_flow_warp_tiled": (c_i, [c_f, c_f, c_l, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_f]),
+    "atmvfi_flow_warp_ex": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
     "atmvfi_flow_warp_nhwc": (c_i, [c_f, c_i, c_l, c_f, c_l, c_i, c_i, c_f, c_i, c_l, c_i, c_i, c_i, c_i, c_f]),
     "atmvfi_warp_blend": (c_i, [c_f, c_f, c_f, c_i, c_l, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i,
                                 c_i, c_i, c_i, c_f]),
@@ -529,6 +530,7 @@ class HipOps:
         # Lanes: independent branches of a forward on side streams (HipOps.branch / join; include/atmvfi.h "LANES").  lane 0 = the
         # caller's current stream; lanes 1.. = side streams of this object, created on first use.
         self.lane = 0
+        self._lane0: Optional[torch.cuda.Stream] = None      # lane 0's stream while a branch body runs (see branch())
         self._side_streams: List[torch.cuda.Stream] = []
         self._lane_events: List[torch.cuda.Event] = []
         self._next_event = 0
@@ -552,7 +554,8 @@ class HipOps:
     # ------------------------------------------------------------------ utils
     def _lane_stream(self, lane: int) -> "torch.cuda.Stream":
         if lane == 0:
-            return torch.cuda.current_stream(self.device)
+            # (inside a branch torch's current stream IS the side stream: lane 0 stays the stream the branch was entered from)
+            return self._lane0 if self._lane0 is not None else torch.cuda.current_stream(self.device)
         while len(self._side_streams) < lane:
             self._side_streams.append(torch.cuda.Stream(device=self.device))
         return self._side_streams[lane - 1]
@@ -573,6 +576,7 @@ class HipOps:
     def begin_forward(self):
         """Called by Network at the top of every forward: lane 0, event numbering from 0."""
         self.lane = 0
+        self._lane0 = None
         self._next_event = 0
 
     def _order(self, first: int, then: int):
@@ -1162,6 +1166,23 @@ class HipOps:
         fn = self.lib.atmvfi_flow_warp_tiled if self._tiled_warp_ok(w, src) else self.lib.atmvfi_flow_warp
         self._run("flow_warp", meta, fn, _ptr(src), _ptr(flow), bs, ps, cs, _ptr(dst), b, c, h, w, self._stream())
 
+    PADDING_MODES = {"zeros": 0, "border": 1, "reflection": 2}
+
+    def flow_warp_ex(self, src, flow, dst, mask=None, padding_mode="zeros"):
+        """flow_warp(feature, flow, mask=..., padding_mode=...) of the reference in its non-default forms (flow_warp.py:50-60):
+        contiguous planar src / dst [B,C,H,W], flow [B,2,H,W]; ``mask``: a [B,H,W] bool / uint8 tensor to fill, or None."""
+        _chk(src, "flow_warp_ex.src"); _chk(dst, "flow_warp_ex.dst"); _chk(flow, "flow_warp_ex.flow")
+        b, c, h, w = src.shape
+        if padding_mode not in self.PADDING_MODES:
+            raise ValueError(f"flow_warp: padding_mode must be one of {sorted(self.PADDING_MODES)}, got {padding_mode!r}")
+        if (not all(t.is_contiguous() for t in (src, flow, dst)) or tuple(dst.shape) != (b, c, h, w) or tuple(flow.shape) != (b, 2, h, w)):
+            raise ValueError("flow_warp_ex: contiguous src/dst [B,C,H,W] and flow [B,2,H,W] expected")
+        if mask is not None and (mask.device != src.device or not mask.is_contiguous() or tuple(mask.shape) != (b, h, w) or mask.element_size() != 1):
+            raise ValueError("flow_warp_ex: mask must be a contiguous [B,H,W] bool / uint8 tensor on the source's device")
+        meta = {"bytes": 4.0 * b * h * w * (2 * c + 2)}
+        self._run("flow_warp_ex", meta, self.lib.atmvfi_flow_warp_ex, _ptr(src), _ptr(flow), _ptr(dst), 0 if mask is None else mask.data_ptr(),
+                  b, c, h, w, self.PADDING_MODES[padding_mode], self._stream())
+
     def flow_warp_up2(self, src, flow, dst, flow_up):
         """flow_warp(src, flow) -> dst and the flow up-sampled x2 (values doubled) -> flow_up, one launch; all contiguous planar."""
         b, c, h, w = src.shape
@@ -1280,13 +1301,21 @@ class HipOps:
 
     def l1_mean(self, a, b, out, workspace=None):
         """mean |a - b| per sample, fixed summation order (run-to-run bit-identical).  ``workspace``: fp32 scratch of at least
-        ``l1_mean_workspace_floats`` elements (workspace memory of the caller; allocated here if absent: tests)."""
+        ``l1_mean_workspace_floats`` elements (workspace memory of the caller).  Without one (direct callers, tests) the scratch is
+        kept on this object per (samples, elements): a temporary would be handed back to torch's allocator while the two passes may
+        still be in flight on a side lane, and would turn into a stale pointer inside a recorded plan."""
         _chk(a, "l1_mean.a"); _chk(b, "l1_mean.b")
         if not a.is_contiguous() or not b.is_contiguous() or a.shape != b.shape:
             raise ValueError("l1_mean: inputs must be contiguous and of equal shape")
         n = a.shape[0]
         if workspace is None:
-            workspace = torch.empty(self.l1_mean_workspace_floats(n, a.numel() // n), dtype=torch.float32, device=a.device)
+            cache = self.__dict__.setdefault("_l1_scratch", {})
+            key = (n, a.numel() // n)
+            workspace = cache.get(key)
+            if workspace is None:
+                if self.recording is not None:
+                    raise PlanUnsupported("l1_mean scratch created while recording")
+                workspace = cache[key] = torch.empty(self.l1_mean_workspace_floats(*key), dtype=torch.float32, device=a.device)
         self._run("l1_mean", {"bytes": 8.0 * a.numel()}, self.lib.atmvfi_l1_mean, _ptr(a), _ptr(b), _ptr(out), n, a.numel() // n,
                   _ptr(workspace), workspace.numel(), self._stream())
 

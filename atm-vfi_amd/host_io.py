@@ -174,6 +174,51 @@ def interpolate_video_2x(frames, model, isBGR: bool = True, divisor: int = 64, d
     yield originals.popleft()          # the last frame is written once (demo_2x.py:160)
 
 
+# cv2.VideoCapture property ids (cv2.CAP_PROP_*; the image has no OpenCV, and the adapters below only need the numbers)
+CAP_PROP_FRAME_WIDTH, CAP_PROP_FRAME_HEIGHT, CAP_PROP_FPS, CAP_PROP_FRAME_COUNT = 3, 4, 5, 7
+
+
+def capture_frames(cap):
+    """The decode end of demo_2x.py:129-163 as an iterator: ``cap`` is a ``cv2.VideoCapture`` or anything with its ``isOpened()`` /
+    ``read() -> (ok, frame)`` pair; yields uint8 [H,W,3] frames until a read fails (the reference's loop exit, :159-163).  Each frame
+    is copied (``prev_frame = curr_frame.copy()``, :156: OpenCV may reuse its buffer)."""
+    while cap.isOpened():
+        ok, frame = cap.read()
+        if not ok:
+            break
+        yield np.array(frame, copy=True)
+
+
+def video_2x(cap, make_writer, model, isBGR: bool = True, divisor: int = 64, depth: int = 3, interpolator=None):
+    """The video branch of demo_2x.py:129-168 end to end over a capture / writer pair: reads FPS, W, H from ``cap``
+    (``cap.get(CAP_PROP_*)``, :130-133), opens the sink with ``make_writer(2 * FPS, (W, H))`` (:134-135: the processed video plays at
+    twice the rate), writes f0, I(f0,f1), f1, ..., f_{n-1} -- every original once, the last frame once (:148-150, 160) -- and releases
+    both ends (:165-166).  The codec stays with the caller: with OpenCV, ``cap = cv2.VideoCapture(path)`` and ``make_writer = lambda
+    fps, size: cv2.VideoWriter(out, cv2.VideoWriter_fourcc(*'mp4v'), fps, size)``.  ``interpolator(frames, model, ...)`` defaults to
+    ``interpolate_video_2x`` (the pipelined HIP path).  Returns ``{"fps_in", "fps_out", "size", "frames_in", "frames_out"}``.
+    Not provided: ``--combine_video`` (cv2.putText drawing, :88-97).  An empty video writes nothing (the reference raises NameError)."""
+    fps = int(cap.get(CAP_PROP_FPS))
+    w, h = int(cap.get(CAP_PROP_FRAME_WIDTH)), int(cap.get(CAP_PROP_FRAME_HEIGHT))
+    out = make_writer(2 * fps, (w, h))
+    n_in = [0]
+
+    def counted():
+        for f in capture_frames(cap):
+            if f.shape[:2] != (h, w):
+                raise ValueError(f"video_2x: the capture announced {w}x{h} frames and delivered {f.shape[1]}x{f.shape[0]}")
+            n_in[0] += 1
+            yield f
+    n_out = 0
+    try:
+        for frame in (interpolator or interpolate_video_2x)(counted(), model, isBGR=isBGR, divisor=divisor, depth=depth):
+            out.write(frame)
+            n_out += 1
+    finally:
+        cap.release()
+        out.release()
+    return {"fps_in": fps, "fps_out": 2 * fps, "size": (w, h), "frames_in": n_in[0], "frames_out": n_out}
+
+
 def interpolate_video_2x_distributed(frames, model, rank: int, world: int, isBGR: bool = True, divisor: int = 64, block: int = 4,
                                      group=None):
     """``interpolate_video_2x`` over the GPUs of one node (one process per GPU, ``torch.distributed`` initialised by the caller):

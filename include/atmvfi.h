@@ -318,6 +318,12 @@ int atmvfi_flow_warp(const float* src /*[B,C,H,W]*/, const float* flow, int64_t 
  * otherwise: the caller uses atmvfi_flow_warp). */
 int atmvfi_flow_warp_tiled(const float* src /*[B,C,H,W]*/, const float* flow, int64_t flow_bstride,
                            int flow_pstride, int flow_cstride, float* dst, int B, int C, int H, int W, void* stream);
+/* The reference's non-default forms of flow_warp (flow_warp.py:50-60 with mask=True and / or padding_mode != 'zeros';
+ * bilinear_sample :26-47): planar flow [B,2,H,W]; padding_mode 0 'zeros', 1 'border', 2 'reflection' (grid_sample's coordinate maps,
+ * align_corners=True); mask (may be NULL): [B,H,W] bytes, 1 where the normalised sampling coordinate lies in [-1, 1] on both axes
+ * (flow_warp.py:43, on the reference's own fp32 expression).  Not on the forward's path. */
+int atmvfi_flow_warp_ex(const float* src /*[B,C,H,W]*/, const float* flow /*[B,2,H,W]*/, float* dst, uint8_t* mask /*[B,H,W] or NULL*/,
+                        int B, int C, int H, int W, int padding_mode, void* stream);
 int atmvfi_flow_warp_nhwc(const float* src, int src_ld, int64_t src_bstride,
                           const float* flow, int64_t flow_bstride, int flow_pstride, int flow_cstride,
                           float* dst, int dst_ld, int64_t dst_bstride, int B, int C, int H, int W, void* stream);

@@ -1,5 +1,5 @@
 """Drop-in for the reference's ``network/flow_warp.py`` (flow_warp.py:50-60): the same
-``flow_warp(feature, flow)`` signature backed by the HIP bilinear-gather kernel."""
+``flow_warp(feature, flow, mask=False, padding_mode='zeros')`` signature backed by the HIP bilinear-gather kernels."""
 import os
 import sys
 
@@ -14,12 +14,21 @@ _ops = {}
 
 
 def flow_warp(feature, flow, mask=False, padding_mode="zeros"):
-    """feature [B,C,H,W], flow [B,2,H,W] (CUDA/HIP fp32) -> backward-warped feature."""
-    if mask or padding_mode != "zeros":
-        raise NotImplementedError("only the hot-path form flow_warp(feature, flow) is provided")
+    """feature [B,C,H,W], flow [B,2,H,W] (CUDA/HIP fp32) -> backward-warped feature; with ``mask=True`` the pair
+    (warped, in-range mask [B,H,W] bool) of bilinear_sample(return_mask=True) (flow_warp.py:26-47); ``padding_mode`` as
+    ``F.grid_sample`` takes it ('zeros', 'border', 'reflection')."""
+    assert flow.size(1) == 2                                    # flow_warp.py:55
     dev = feature.device
     if dev not in _ops:
         _ops[dev] = _hip.HipOps(dev)
-    out = torch.empty_like(feature, memory_format=torch.contiguous_format)
-    _ops[dev].flow_warp(feature.contiguous().float(), flow.contiguous().float(), out)
-    return out
+    ops = _ops[dev]
+    src = feature.contiguous().float()
+    fl = flow.contiguous().float()
+    out = torch.empty_like(src, memory_format=torch.contiguous_format)
+    if not mask and padding_mode == "zeros":                    # the hot-path form
+        ops.flow_warp(src, fl, out)
+        return out
+    b, _, h, w = src.shape
+    m = torch.empty(b, h, w, dtype=torch.bool, device=dev) if mask else None
+    ops.flow_warp_ex(src, fl, out, mask=m, padding_mode=padding_mode)
+    return (out, m) if mask else out

@@ -76,10 +76,10 @@ def resize_ac_explicit(x: Tensor, oh: int, ow: int, value_scale: float = 1.0) ->
     return (top * (1 - wy)[:, None] + bot * wy[:, None]) * value_scale
 
 
-def flow_warp(feature: Tensor, flow: Tensor) -> Tensor:
-    """Backward bilinear warp with zero padding (flow_warp.py:50-60, 26-47, 7-23):
-    pixel grid + flow, normalised with ``2*p/(dim-1)-1`` and sampled with
-    ``grid_sample(bilinear, zeros, align_corners=True)``."""
+def flow_warp(feature: Tensor, flow: Tensor, mask: bool = False, padding_mode: str = "zeros"):
+    """Backward bilinear warp (flow_warp.py:50-60, 26-47, 7-23): pixel grid + flow, normalised with ``2*p/(dim-1)-1`` and sampled
+    with ``grid_sample(bilinear, padding_mode, align_corners=True)``; zero padding is the forward's form.  ``mask=True`` also
+    returns bilinear_sample's in-range mask (:42-45)."""
     b, c, h, w = feature.shape
     ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32),
                             torch.arange(w, dtype=torch.float32), indexing="ij")
@@ -88,7 +88,10 @@ def flow_warp(feature: Tensor, flow: Tensor) -> Tensor:
     gx = 2 * px / (w - 1) - 1
     gy = 2 * py / (h - 1) - 1
     grid = torch.stack([gx, gy], dim=-1)
-    return F.grid_sample(feature, grid, mode="bilinear", padding_mode="zeros", align_corners=True)
+    out = F.grid_sample(feature, grid, mode="bilinear", padding_mode=padding_mode, align_corners=True)
+    if mask:
+        return out, (gx >= -1) & (gy >= -1) & (gx <= 1) & (gy <= 1)
+    return out
 
 
 def flow_warp_explicit(feature: Tensor, flow: Tensor) -> Tensor:

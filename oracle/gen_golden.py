@@ -324,6 +324,26 @@ def generate(gold: str, only=None) -> dict:
         manifest["ops"].append("op_flow_warp")
         print(f"op flow_warp: oracle-vs-reference {(wv - O.flow_warp(feat, flow)).abs().max():.2e} "
               f"explicit {(wv - O.flow_warp_explicit(feat, flow)).abs().max():.2e}")
+    # flow_warp's non-default forms (flow_warp.py:50-60, bilinear_sample :26-47): mask=True and padding_mode 'border' / 'reflection';
+    # flows from sub-pixel to several image sizes (reflection folds more than once), exact-edge coordinates included
+    if want("op_flow_warp_modes"):
+        g2 = torch.Generator().manual_seed(6)
+        feat2 = torch.rand(2, 3, 12, 20, generator=g2)
+        flow2 = (torch.rand(2, 2, 12, 20, generator=g2) - 0.5) * 10
+        flow2[1] *= 9.0                                                   # up to +-45 px on a 12 x 20 image
+        flow2[0, :, 0, 0] = torch.tensor([0.0, 0.0]); flow2[0, :, 0, 1] = torch.tensor([-1.0, 0.0])      # coordinate exactly 0
+        flow2[0, :, 11, 19] = torch.tensor([0.0, 0.0]); flow2[0, :, 11, 18] = torch.tensor([1.0, 0.0])   # exactly size - 1
+        flow2[0, :, 5, 0] = torch.tensor([-1e-9, 0.0])                    # a rounding below zero: 2 p / (w - 1) - 1 == -1 in fp32
+        arrs = {"feat": feat2.numpy(), "flow": flow2.numpy()}
+        for pm in ("zeros", "border", "reflection"):
+            o, m = ref_warp.flow_warp(feat2, flow2, mask=True, padding_mode=pm)
+            arrs["out_" + pm] = o.numpy()
+            arrs["mask"] = m.numpy()
+            o2 = ref_warp.flow_warp(feat2, flow2, padding_mode=pm)
+            assert torch.equal(o, o2)
+        np.savez_compressed(os.path.join(gold, "op_flow_warp_modes.npz"), **arrs)
+        manifest["ops"].append("op_flow_warp_modes")
+        print(f"op flow_warp_modes: mask true on {arrs['mask'].mean():.2f} of the pixels")
     # InputPadder (benchmark/utils.py:57-80)
     pads = {}
     for (h, w, dv) in ((270, 480, 64), (1080, 1920, 64), (256, 256, 64), (1080, 2048, 32), (100, 180, 64), (540, 960, 64),
@@ -402,7 +422,7 @@ def main():
         return 0
     only = set(args.only.split(",")) if args.only else None
     if args.skip_large:
-        names = {"schema", "demo_lite_asset_crop", "op_atm_ws7_shift0", "op_atm_ws7_shift3", "op_flow_warp"}
+        names = {"schema", "demo_lite_asset_crop", "op_atm_ws7_shift0", "op_atm_ws7_shift3", "op_flow_warp", "op_flow_warp_modes"}
         names |= {c[0] for c in E2E_CASES} | {c[0] for c in DEMO_CASES}
         only = (only if only is not None else names) - LARGE
     if args.check:

@@ -45,3 +45,19 @@ def uint8_pair(h: int, w: int, seed: int = 0):
     noise = rng.integers(-12, 13, big.shape)
     big = np.clip(np.round(big + noise), 0, 255).astype(np.uint8)
     return big[4:4 + h, 4:4 + w].copy(), big[2:2 + h, 7:7 + w].copy()
+
+
+def uint8_video(n: int, h: int, w: int, seed: int = 0):
+    """n consecutive uint8 [H,W,3] frames of a short synthetic clip: a smooth texture drifting by (2, -3) px per frame with fresh
+    grain on every frame (the video-loop tests: demo_2x.py:129-168)."""
+    rng = np.random.default_rng(seed)
+    m = 4 * n + 8
+    a = rng.integers(0, 256, (h // 8 + m // 8 + 3, w // 8 + m // 8 + 3, 3)).astype(np.float32)
+    t = torch.from_numpy(a).permute(2, 0, 1)[None]
+    big = F.interpolate(t, size=(h + m, w + m), mode="bilinear", align_corners=True)[0].permute(1, 2, 0).numpy()
+    out = []
+    for i in range(n):
+        y, x = 4 + 2 * i, m - 4 - 3 * i
+        crop = big[y:y + h, x:x + w]
+        out.append(np.clip(np.round(crop + rng.integers(-10, 11, crop.shape)), 0, 255).astype(np.uint8))
+    return out

@@ -385,29 +385,103 @@ def test_frame_pipeline_matches_sequential(nets, dev):
     assert d.max() <= 1 and (d > 0).mean() < 5e-3
 
 
-def test_video_2x_frame_order(nets, dev):
-    """interpolate_video_2x reproduces the output sequence of the reference's video loop (demo_2x.py:144-163)."""
+def same_uint8_frame(got, want) -> bool:
+    """An interpolated uint8 frame against the oracle's: |d| <= 1e-3 in fp32 can flip a rounding here and there, never more than one
+    level (the criterion of test_inference_2frame_uint8)."""
+    d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    return got.shape == want.shape and got.dtype == np.uint8 and d.max() <= 1 and (d > 0).mean() < 5e-3
+
+
+def oracle_video_2x(sd, frames, global_motion):
+    """The output sequence of the reference's video loop (demo_2x.py:144-163) computed by the CPU oracle pair by pair:
+    f0, I(f0,f1), f1, ..., f_{n-1}."""
+    out = []
+    for i in range(len(frames) - 1):
+        out += [frames[i], O.inference_2frame(sd, frames[i], frames[i + 1], isBGR=True, global_motion=global_motion)]
+    return out + [frames[-1]] if frames else out
+
+
+def check_video(got, want):
+    assert len(got) == len(want)
+    for i, (g, w) in enumerate(zip(got, want)):
+        if i % 2 == 0:
+            assert np.array_equal(g, w), f"original frame {i // 2} was altered"
+        else:
+            assert same_uint8_frame(g, w), f"interpolated frame {i // 2} differs from the oracle's"
+
+
+class FakeCapture:
+    """An in-memory stand-in for cv2.VideoCapture (demo_2x.py:129-133, 144-147): get(CAP_PROP_*), isOpened(), read(), release()."""
+
+    def __init__(self, frames, fps):
+        self.frames, self.fps, self.i, self.open, self.released = list(frames), fps, 0, True, 0
+        self.buf = None if not frames else np.empty_like(frames[0])
+
+    def get(self, prop):
+        h, w = self.frames[0].shape[:2] if self.frames else (0, 0)
+        return {host_io.CAP_PROP_FPS: float(self.fps) + 0.97, host_io.CAP_PROP_FRAME_WIDTH: float(w), host_io.CAP_PROP_FRAME_HEIGHT: float(h),
+                host_io.CAP_PROP_FRAME_COUNT: float(len(self.frames))}[prop]
+
+    def isOpened(self):
+        return self.open
+
+    def read(self):
+        if self.i >= len(self.frames):
+            return False, None
+        np.copyto(self.buf, self.frames[self.i])       # like OpenCV, the decoder hands out ONE reused buffer
+        self.i += 1
+        return True, self.buf
+
+    def release(self):
+        self.open = False
+        self.released += 1
+
+
+class FakeWriter:
+    def __init__(self, fps, size):
+        self.fps, self.size, self.frames, self.released = fps, size, [], 0
+
+    def write(self, frame):
+        assert frame.shape == (self.size[1], self.size[0], 3) and frame.dtype == np.uint8
+        self.frames.append(frame.copy())
+
+    def release(self):
+        self.released += 1
+
+
+def test_video_2x_frame_order(nets, dev, weights):
+    """interpolate_video_2x against the CPU ORACLE's output sequence of the reference's video loop (demo_2x.py:144-163), and the
+    capture -> pairs -> writer adapters (host_io.video_2x, :129-168) over an in-memory fake codec: frame rate doubled, every original
+    once, the last frame once, both ends released."""
     net = nets["lite"]
-    net.global_motion = False
-    rng = np.random.default_rng(9)
-    frames = [rng.integers(0, 256, (64, 96, 3), dtype=np.uint8) for _ in range(5)]
-    out = list(host_io.interpolate_video_2x(iter(frames), net))
-    assert len(out) == 9
-    for i, f in enumerate(frames):
-        assert np.array_equal(out[2 * i], f)
-    for i in range(4):
-        assert np.array_equal(out[2 * i + 1], host_io.inference_2frame(frames[i], frames[i + 1], net, isBGR=True))
+    sd = weights("lite")
+    for glob in (False, True):
+        net.global_motion = glob
+        frames = pairs.uint8_video(5, 64, 96, seed=9 + glob)
+        want = oracle_video_2x(sd, frames, glob)
+        assert len(want) == 9
+        check_video(list(host_io.interpolate_video_2x(iter(frames), net)), want)
+        cap, sinks = FakeCapture(frames, fps=24), []
+
+        def make_writer(fps, size):
+            sinks.append(FakeWriter(fps, size))
+            return sinks[-1]
+        info = host_io.video_2x(cap, make_writer, net)
+        assert info == {"fps_in": 24, "fps_out": 48, "size": (96, 64), "frames_in": 5, "frames_out": 9}
+        assert len(sinks) == 1 and sinks[0].fps == 48 and sinks[0].size == (96, 64) and sinks[0].released == 1 and cap.released == 1
+        check_video(sinks[0].frames, want)
     assert list(host_io.interpolate_video_2x(iter([]), net)) == []
     one = list(host_io.interpolate_video_2x(iter(frames[:1]), net))
     assert len(one) == 1 and np.array_equal(one[0], frames[0])
     net.global_motion = True
 
 
-def test_frame_cache_is_exact_and_video_distributed_single_rank(nets, dev):
+def test_frame_cache_is_exact_and_video_distributed_single_rank(nets, dev, weights):
     """Network.enable_frame_cache(): with the global branch off, forward(b, c, reuse_first=True) after forward(a, b) must equal
-    forward(b, c) bit for bit (the encoder and the cross-scale fusion are per frame, network_base.py:342-352); and the
-    multi-GPU video loop (host_io.interpolate_video_2x_distributed, here with one rank) must yield exactly the single-GPU sequence,
-    with and without the global branch."""
+    forward(b, c) bit for bit (the encoder and the cross-scale fusion are per frame, network_base.py:342-352) AND the oracle's
+    forward(b, c) within the parity budget; and the multi-GPU video loop (host_io.interpolate_video_2x_distributed, here with one
+    rank, frame cache on inside its blocks) must yield the ORACLE's sequence of the reference's loop (demo_2x.py:144-163), with and
+    without the global branch."""
     net = nets["lite"]
     net.ensemble_global_motion = False
     net.global_motion = False
@@ -421,6 +495,8 @@ def test_frame_cache_is_exact_and_video_distributed_single_rank(nets, dev):
         cached = net(b, c, reuse_first=True)
         for k, v in plain.items():
             assert torch.equal(cached[k], v), k
+        ref = O.forward(weights("lite"), b.cpu(), c.cpu(), global_motion=False)
+        assert (cached["I_t"].cpu() - ref["I_t"]).abs().max().item() <= TOL
         # a cache filled at another shape (or a call without reuse_first) must not be used
         x, y = pairs.smooth_pair(1, 64, 96, seed=93)
         net(x.to(dev), y.to(dev))
@@ -428,19 +504,22 @@ def test_frame_cache_is_exact_and_video_distributed_single_rank(nets, dev):
         assert torch.equal(again["I_t"], plain["I_t"])
     finally:
         net.enable_frame_cache(False)
-    rng = np.random.default_rng(11)
-    frames = [rng.integers(0, 256, (64, 96, 3), dtype=np.uint8) for _ in range(6)]
+    frames = pairs.uint8_video(6, 64, 96, seed=11)
     for g in (False, True):
         net.global_motion = g
-        want = list(host_io.interpolate_video_2x(iter(frames), net))
+        want = oracle_video_2x(weights("lite"), frames, g)
         got = list(host_io.interpolate_video_2x_distributed(frames, net, 0, 1, block=2))
-        assert len(got) == len(want) == 11 and all(np.array_equal(p, q) for p, q in zip(got, want)), g
+        assert len(got) == len(want) == 11
+        check_video(got, want)
+        single = list(host_io.interpolate_video_2x(iter(frames), net))       # ... and exactly the single-GPU loop's frames
+        assert all(np.array_equal(p, q) for p, q in zip(got, single)), g
     net.global_motion = True
 
 
-def test_video_distributed_under_rccl_one_rank(nets, dev):
+def test_video_distributed_under_rccl_one_rank(nets, dev, weights):
     """interpolate_video_2x_distributed under a real RCCL communicator (one rank: what a one-GPU box can exercise): sharding.HostGather's
-    all-gather on its side stream and the pinned host copies must reproduce interpolate_video_2x frame for frame."""
+    all-gather on its side stream and the pinned host copies must reproduce the ORACLE's sequence of the reference's video loop
+    (demo_2x.py:144-163; 270 x 480 frames through the padder) and interpolate_video_2x frame for frame."""
     import socket
     import torch.distributed as dist
     if dist.is_initialized():
@@ -452,9 +531,9 @@ def test_video_distributed_under_rccl_one_rank(nets, dev):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     net = nets["lite"]
     net.global_motion, net.ensemble_global_motion = True, False
-    rng = np.random.default_rng(3)
-    frames = [rng.integers(0, 256, (270, 480, 3), dtype=np.uint8) for _ in range(7)]
+    frames = pairs.uint8_video(7, 270, 480, seed=3)
     ref = list(host_io.interpolate_video_2x(frames, net))
+    check_video(ref, oracle_video_2x(weights("lite"), frames, True))
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     try:
         for block in (1, 3):
@@ -672,6 +751,30 @@ def test_lanes_equal_single_stream(dev, weights):
         recorded = [p for p in net._plans.values() if not isinstance(p, (int, bool))]
         assert recorded and all(p.n_lanes == 2 and p.n_events >= (4 if glob else 2) for p in recorded)
         net.release_workspace()
+    torch.cuda.empty_cache()
+
+
+def test_lanes_on_a_fresh_workspace(dev, weights):
+    """the FIRST forward of a shape with lanes on creates workspace inside a branch body (the global branch's plane
+    buffers are zero-filled by torch on their first use).  That fill must be ordered with the lane's kernels -- the result of a
+    lanes-first model equals the single-stream model's bit for bit, first call included, and again after release_workspace()."""
+    for variant, cls, (H, W) in (("lite", pkg.NetworkLite, (256, 256)), ("base", pkg.NetworkBase, (192, 320))):
+        p0 = [t.to(dev) for t in pairs.random_pair(1, H, W, seed=21)]
+        ref_net = cls()
+        ref_net.load_state_dict(weights(variant), strict=True)
+        ref_net.to(dev).eval()
+        ref_net.use_lanes = False
+        want = [t.clone() for t in _flat(ref_net(*p0))]
+        ref_net.release_workspace()
+        net = cls()
+        net.load_state_dict(weights(variant), strict=True)
+        net.to(dev).eval()
+        net.use_lanes = True
+        for rep in range(3):
+            for call in range(4):                       # first call builds the workspace inside the branches; the third records
+                for t, r in zip(_flat(net(*p0)), want):
+                    assert torch.equal(t, r), (variant, rep, call)
+            net.release_workspace()
     torch.cuda.empty_cache()
 
 

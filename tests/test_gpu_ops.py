@@ -382,6 +382,37 @@ def test_flow_warp_golden_and_random(hip, cpu, dev):
     assert og[0, :, :3].abs().max().item() == 0.0
 
 
+def test_flow_warp_mask_and_padding_modes_vs_reference(hip, dev):
+    """flow_warp(feature, flow, mask=True, padding_mode=...) of the drop-in shim (network/flow_warp.py -> atmvfi_flow_warp_ex)
+    against the reference's own outputs (tests/golden/op_flow_warp_modes.npz, flow_warp.py:26-60): the three padding modes of
+    grid_sample, the in-range mask bit for bit (incl. exact-edge coordinates and one a rounding below zero), flows of several image
+    sizes (reflection folds repeatedly); then a larger random case against torch's grid_sample on the GPU."""
+    import importlib
+    shim = importlib.import_module("network.flow_warp")
+    gold = G.load_npz("op_flow_warp_modes")
+    feat, flow = torch.from_numpy(gold["feat"]).to(dev), torch.from_numpy(gold["flow"]).to(dev)
+    for pm in ("zeros", "border", "reflection"):
+        out, m = shim.flow_warp(feat, flow, mask=True, padding_mode=pm)
+        assert m.dtype == torch.bool and tuple(m.shape) == (2, 12, 20)
+        assert np.array_equal(m.cpu().numpy(), gold["mask"]), pm
+        assert np.abs(out.cpu().numpy() - gold["out_" + pm]).max() <= 2e-6, pm
+        assert torch.equal(shim.flow_warp(feat, flow, padding_mode=pm), out)          # without the mask: the same values
+    assert torch.equal(shim.flow_warp(feat, flow), shim.flow_warp(feat, flow, mask=True)[0])     # hot-path kernel == the general one
+    g = torch.Generator().manual_seed(19)
+    src = rnd(g, 2, 5, 37, 53).to(dev)
+    fl = rnd(g, 2, 2, 37, 53, scale=60.0).to(dev)
+    ys, xs = torch.meshgrid(torch.arange(37, dtype=torch.float32, device=dev), torch.arange(53, dtype=torch.float32, device=dev), indexing="ij")
+    gx, gy = 2 * (xs[None] + fl[:, 0]) / 52 - 1, 2 * (ys[None] + fl[:, 1]) / 36 - 1
+    for pm in ("zeros", "border", "reflection"):
+        want = torch.nn.functional.grid_sample(src, torch.stack([gx, gy], -1), mode="bilinear", padding_mode=pm, align_corners=True)
+        got, m = shim.flow_warp(src, fl, mask=True, padding_mode=pm)
+        # (torch's own GPU kernel, not the reference: coordinates of a few hundred px carry ~2e-5 px of fp32 rounding each way)
+        assert maxdiff(got, want) <= 1e-4, pm
+        assert torch.equal(m, (gx >= -1) & (gy >= -1) & (gx <= 1) & (gy <= 1))
+    with pytest.raises(ValueError):
+        shim.flow_warp(src, fl, padding_mode="wrap")
+
+
 def test_flow_warp_nhwc_views(hip, cpu, dev):
     g = torch.Generator().manual_seed(10)
     B, H, W, C = 2, 12, 20, 224

@@ -188,6 +188,77 @@ def test_demo_host_path_on_double(nets):
     assert d.max() <= 1 and (d > 0).mean() < 1e-3
 
 
+def test_video_adapters_on_a_fake_codec():
+    """host_io.capture_frames / video_2x (demo_2x.py:129-168) without a GPU: an in-memory capture and writer, and a stand-in
+    interpolator (the pair mean) in place of the HIP loop.  Checks the adapter's own contract: properties read through
+    cap.get(CAP_PROP_*) and truncated like the reference's int(...), the sink opened at 2 x FPS with (W, H), frames copied out of the
+    decoder's reused buffer, f0 I f1 I ... f_{n-1} order with the last frame once, both ends released -- also when a frame fails."""
+    import pairs
+    frames = pairs.uint8_video(4, 32, 48, seed=1)
+
+    class Cap:
+        def __init__(self, frs):
+            self.frs, self.i, self.open, self.released = frs, 0, True, 0
+            self.buf = np.zeros_like(frs[0]) if frs else None
+
+        def get(self, prop):
+            return {host_io.CAP_PROP_FPS: 29.97, host_io.CAP_PROP_FRAME_WIDTH: 48.0, host_io.CAP_PROP_FRAME_HEIGHT: 32.0,
+                    host_io.CAP_PROP_FRAME_COUNT: float(len(self.frs))}[prop]
+
+        def isOpened(self):
+            return self.open
+
+        def read(self):
+            if self.i >= len(self.frs):
+                return False, None
+            self.i += 1
+            if self.frs[self.i - 1].shape != self.buf.shape:
+                return True, self.frs[self.i - 1]
+            np.copyto(self.buf, self.frs[self.i - 1])
+            return True, self.buf                       # ONE reused buffer, like OpenCV's decoder
+
+        def release(self):
+            self.open = False; self.released += 1
+
+    class Sink:
+        def __init__(self, fps, size):
+            self.fps, self.size, self.got, self.released = fps, size, [], 0
+
+        def write(self, f):
+            self.got.append(f.copy())
+
+        def release(self):
+            self.released += 1
+
+    def mean_interpolator(frs, model, isBGR=True, divisor=64, depth=3):
+        prev = None
+        for f in frs:
+            if prev is not None:
+                yield prev
+                yield ((prev.astype(np.uint16) + f.astype(np.uint16)) // 2).astype(np.uint8)
+            prev = f
+        if prev is not None:
+            yield prev
+    assert [f.tolist() for f in host_io.capture_frames(Cap(frames))] == [f.tolist() for f in frames]
+    cap, sinks = Cap(frames), []
+    info = host_io.video_2x(cap, lambda fps, size: sinks.append(Sink(fps, size)) or sinks[-1], None, interpolator=mean_interpolator)
+    assert info == {"fps_in": 29, "fps_out": 58, "size": (48, 32), "frames_in": 4, "frames_out": 7}
+    assert sinks[0].fps == 58 and sinks[0].size == (48, 32) and sinks[0].released == 1 and cap.released == 1
+    for i, f in enumerate(frames):
+        assert np.array_equal(sinks[0].got[2 * i], f)
+    assert np.array_equal(sinks[0].got[1], ((frames[0].astype(np.uint16) + frames[1]) // 2).astype(np.uint8))
+    # an empty video: nothing written, both ends still released
+    cap, sinks = Cap([]), []
+    info = host_io.video_2x(cap, lambda fps, size: sinks.append(Sink(fps, size)) or sinks[-1], None, interpolator=mean_interpolator)
+    assert info["frames_in"] == 0 and info["frames_out"] == 0 and sinks[0].released == 1 and cap.released == 1
+    # a frame of another size than the capture announced: ValueError, and the ends are released all the same
+    bad = Cap(frames[:2] + [np.zeros((16, 48, 3), np.uint8)])
+    sinks = []
+    with pytest.raises(ValueError):
+        host_io.video_2x(bad, lambda fps, size: sinks.append(Sink(fps, size)) or sinks[-1], None, interpolator=mean_interpolator)
+    assert bad.released == 1 and sinks[0].released == 1
+
+
 def test_checkpoint_wire_format_and_tta_helpers(tmp_path, nets):
     """save_checkpoint writes the trainer's 5-key dict (trainer.py:438-446); forward_tta is the flip-average of
     benchmark/test_snufilm.py:135-139; psnr is benchmark/psnr_ssim.py:133-135."""
