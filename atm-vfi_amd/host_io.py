@@ -69,6 +69,159 @@ def inference_2frame(img0, img1, model, isBGR: bool = True, divisor: int = 64):
     return pred
 
 
+class _Pending:
+    """One submitted forward of ``PairStreams``: ``result()`` -> (outputs, event), re-raising what the forward raised."""
+    __slots__ = ("_done", "out", "event", "error")
+
+    def __init__(self):
+        import threading
+        self._done, self.out, self.event, self.error = threading.Event(), None, None, None
+
+    def result(self):
+        self._done.wait()
+        if self.error is not None:
+            raise self.error
+        return self.out, self.event
+
+
+class PairStreams:
+    """K independent forwards in flight: K replicas of the model (``Network.replica()``: shared parameters and packed weights, own
+    workspace + launch plan each) on K streams, frame pairs handed out round-robin.  The hot path's parallel axis is the pair axis
+    (demo_2x.py:129-168: consecutive pairs; benchmark/test_vimeo90k.py:80-110: independent triplets), and a forward of a small frame
+    is a chain of ~116 short kernels that each fill a few dozen of the 256 CUs: K chains side by side fill the chip.  There is NO
+    cross-stream event inside a forward (a replica touches only its own buffers); the only ordering is at the ends -- the stream
+    waits for the caller's stream once before a forward (its inputs) and an event marks the outputs ready.  Every result is
+    bit-identical to ``model.forward`` on one stream.  Memory: K workspaces (13 GB each at 1080p, ~0.1 GB at 256 x 256).
+
+    ``threads=True``: every stream gets a worker thread that issues its forwards (a planned forward is ONE C call that issues ~116
+    kernel launches; ctypes drops the GIL for it).  Measured (tools/inflight_ab.py, profiles/r06_inflight_ab.txt): no consistent
+    gain over one issuing thread once the per-forward allocator bookkeeping is off the path (256 x 256, K = 4: 2 081 frames/s from
+    one thread, 1 720-2 180 with four), so it is off by default."""
+
+    def __init__(self, model, k: int = 3, threads: bool = False):
+        ops, dev = _hip_ops_of(model)
+        if ops is None:
+            raise RuntimeError("PairStreams needs an atm-vfi_amd Network on the GPU")
+        if k < 1:
+            raise ValueError("PairStreams: k >= 1")
+        self.model, self.dev, self.k = model, dev, int(k)
+        self.replicas = [model.replica() for _ in range(self.k)]
+        self.streams = [torch.cuda.Stream(dev) for _ in range(self.k)]
+        self._n = 0
+        self._queues, self._workers = None, []
+        if threads:
+            import queue
+            import threading
+            self._queues = [queue.SimpleQueue() for _ in range(self.k)]
+            for i in range(self.k):
+                t = threading.Thread(target=self._work, args=(i,), name=f"atmvfi-pairstream-{i}", daemon=True)
+                t.start()
+                self._workers.append(t)
+
+    def _sync_flags(self):
+        for r in self.replicas:        # the switches a caller flips on the model between calls (demo_2x.py:126, the ensemble flag)
+            r.global_motion, r.ensemble_global_motion = self.model.global_motion, self.model.ensemble_global_motion
+            for name in ("local_motion_args", "global_motion_args"):
+                getattr(r, name)["window_size"] = getattr(self.model, name)["window_size"]
+
+    def _forward_on(self, i, im0, im1, in_event, consumer):
+        st = self.streams[i]
+        if in_event is not None:
+            st.wait_event(in_event)
+        with torch.cuda.stream(st):
+            out = self.replicas[i].forward(im0, im1)
+            ev = torch.cuda.Event()
+            ev.record(st)
+        for t in (im0, im1):
+            t.record_stream(st)
+        if consumer is not None:       # the caller will use (and free) the outputs on its own stream
+            for v in out.values():
+                for t in (v if isinstance(v, (list, tuple)) else (v,)):
+                    if torch.is_tensor(t):
+                        t.record_stream(consumer)
+        return out, ev
+
+    def _work(self, i):
+        torch.cuda.set_device(self.dev)
+        torch.set_grad_enabled(False)
+        q = self._queues[i]
+        while True:
+            item = q.get()
+            if item is None:
+                return
+            pend, im0, im1, in_event, consumer = item
+            try:
+                pend.out, pend.event = self._forward_on(i, im0, im1, in_event, consumer)
+            except BaseException as e:          # handed to the caller by result()
+                pend.error = e
+            pend._done.set()
+
+    def submit(self, im0, im1, wait_inputs: bool = True, record_outputs: bool = True) -> "_Pending":
+        """Enqueue ``forward(im0, im1)`` on the next stream; ``.result()`` of the returned handle is ``(outputs, event)`` -- the outputs
+        may be read (by the host, or by a stream that waited for the event) once the event has completed.  ``wait_inputs``: order the
+        forward after everything queued so far on the caller's current stream (False when the frames are known to be resident and
+        ready).  ``record_outputs``: tell torch's allocator that the caller's stream will use the output tensors (needed when they are
+        consumed by kernels on that stream and freed while those are still queued; not when the host reads them)."""
+        i = self._n % self.k
+        self._n += 1
+        cur = torch.cuda.current_stream(self.dev)
+        in_event = None
+        if wait_inputs:
+            in_event = torch.cuda.Event()
+            in_event.record(cur)
+        pend = _Pending()
+        if self._queues is None:
+            try:
+                pend.out, pend.event = self._forward_on(i, im0, im1, in_event, cur if record_outputs else None)
+            except BaseException as e:
+                pend.error = e
+            pend._done.set()
+        else:
+            self._queues[i].put((pend, im0, im1, in_event, cur if record_outputs else None))
+        return pend
+
+    def map(self, pairs, wait_inputs: bool = True, record_outputs: bool = True):
+        """``forward`` over an iterable of (im0, im1) with up to 2 K forwards submitted (K executing, K queued behind them); yields the
+        output dicts in order, each complete."""
+        from collections import deque
+        self._sync_flags()
+        q = deque()
+        depth = 2 * self.k if self._queues is not None else self.k
+        for a, b in pairs:
+            if len(q) == depth:
+                out, ev = q.popleft().result()
+                ev.synchronize()
+                yield out
+            q.append(self.submit(a, b, wait_inputs, record_outputs))
+        while q:
+            out, ev = q.popleft().result()
+            ev.synchronize()
+            yield out
+
+    def synchronize(self):
+        for st in self.streams:
+            st.synchronize()
+
+    def release(self):
+        """Stop the workers, wait for the streams, free the K workspaces."""
+        if self._queues is not None:
+            for q in self._queues:
+                q.put(None)
+            for t in self._workers:
+                t.join()
+            self._queues, self._workers = None, []
+        self.synchronize()
+        for r in self.replicas:
+            r.release_workspace()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.release()
+        return False
+
+
 class FramePipeline:
     """uint8 frame pairs in host memory -> uint8 interpolated frames, with the transfers off the critical path.
 
@@ -79,11 +232,16 @@ class FramePipeline:
     pieces are small (H2D 1.0 ms, enqueue 2.8 ms of CPU, pre/post kernels < 0.1 ms) and at depth 3 the GPU queue never runs dry
     (gap between consecutive forwards 0.03 ms)."""
 
-    def __init__(self, model, height: int, width: int, isBGR: bool = True, divisor: int = 64, depth: int = 3):
+    def __init__(self, model, height: int, width: int, isBGR: bool = True, divisor: int = 64, depth: int = 3, streams: int = 1):
         ops, dev = _hip_ops_of(model)
         if ops is None:
             raise RuntimeError("FramePipeline needs an atm-vfi_amd Network on the GPU")
+        # streams > 1: K forwards in flight (PairStreams: K replicas on K streams); pair i's whole chain -- pre-kernels, forward,
+        # post-kernel -- runs on stream i % K, so nothing inside it crosses streams.  Small frames only fill the chip this way.
+        self.lanes = PairStreams(model, streams) if streams > 1 else None
+        depth = max(depth, streams + 1) if streams > 1 else depth
         self.model, self.ops, self.dev, self.bgr, self.depth = model, ops, dev, bool(isBGR), max(1, depth)
+        self._k = 0
         self.h, self.w = height, width
         pad = InputPadder((1, 3, height, width), divisor=divisor)
         self.pad_left, _, self.pad_top, _ = pad._pad
@@ -113,11 +271,20 @@ class FramePipeline:
             slot["in_ready"].record(self.copy_in)
 
     def _compute(self, slot):
+        if self.lanes is not None:
+            i = self._k % self.lanes.k
+            self._k += 1
+            with torch.cuda.stream(self.lanes.streams[i]):
+                self._compute_on(slot, self.lanes.replicas[i])
+        else:
+            self._compute_on(slot, self.model)
+
+    def _compute_on(self, slot, model):
         cur = torch.cuda.current_stream(self.dev)
         cur.wait_event(slot["in_ready"])
         self.ops.frame_u8_to_f32(slot["d_in"][0], slot["f0"][0], self.pad_top, self.pad_left, self.bgr)
         self.ops.frame_u8_to_f32(slot["d_in"][1], slot["f1"][0], self.pad_top, self.pad_left, self.bgr)
-        it = self.model.forward(slot["f0"], slot["f1"])["I_t"]
+        it = model.forward(slot["f0"], slot["f1"])["I_t"]
         self.ops.frame_f32_to_u8(it[0], slot["d_out"], self.pad_top, self.pad_left, self.bgr)
         slot["done"].record(cur)
         self.copy_out.wait_event(slot["done"])
@@ -126,6 +293,8 @@ class FramePipeline:
             slot["out_ready"].record(self.copy_out)
 
     def run(self, pairs):
+        if self.lanes is not None:
+            self.lanes._sync_flags()
         it = iter(pairs)
         inflight = []                      # slots whose compute has been enqueued, oldest first
         nxt = next(it, None)
@@ -151,9 +320,10 @@ class FramePipeline:
             yield old["h_out"].numpy().copy()
 
 
-def interpolate_video_2x(frames, model, isBGR: bool = True, divisor: int = 64, depth: int = 3):
+def interpolate_video_2x(frames, model, isBGR: bool = True, divisor: int = 64, depth: int = 3, streams: int = 1):
     """The frame loop of demo_2x.py:144-163 over any iterable of uint8 [H,W,3] frames (decoding / encoding stays with the caller):
-    yields f0, I(f0,f1), f1, I(f1,f2), ..., f_{n-1} -- 2n-1 frames -- with the pairs running through ``FramePipeline``."""
+    yields f0, I(f0,f1), f1, I(f1,f2), ..., f_{n-1} -- 2n-1 frames -- with the pairs running through ``FramePipeline``
+    (``streams`` > 1: that many forwards in flight on streams of their own, for frames too small to fill the GPU one at a time)."""
     from collections import deque
     it = iter(frames)
     first = next(it, None)
@@ -167,7 +337,7 @@ def interpolate_video_2x(frames, model, isBGR: bool = True, divisor: int = 64, d
             originals.append(cur)
             yield prev, cur
             prev = cur
-    pipe = FramePipeline(model, first.shape[0], first.shape[1], isBGR=isBGR, divisor=divisor, depth=depth)
+    pipe = FramePipeline(model, first.shape[0], first.shape[1], isBGR=isBGR, divisor=divisor, depth=depth, streams=streams)
     for pred in pipe.run(pairs()):
         yield originals.popleft()
         yield pred
@@ -189,7 +359,7 @@ def capture_frames(cap):
         yield np.array(frame, copy=True)
 
 
-def video_2x(cap, make_writer, model, isBGR: bool = True, divisor: int = 64, depth: int = 3, interpolator=None):
+def video_2x(cap, make_writer, model, isBGR: bool = True, divisor: int = 64, depth: int = 3, interpolator=None, **kw):
     """The video branch of demo_2x.py:129-168 end to end over a capture / writer pair: reads FPS, W, H from ``cap``
     (``cap.get(CAP_PROP_*)``, :130-133), opens the sink with ``make_writer(2 * FPS, (W, H))`` (:134-135: the processed video plays at
     twice the rate), writes f0, I(f0,f1), f1, ..., f_{n-1} -- every original once, the last frame once (:148-150, 160) -- and releases
@@ -210,7 +380,7 @@ def video_2x(cap, make_writer, model, isBGR: bool = True, divisor: int = 64, dep
             yield f
     n_out = 0
     try:
-        for frame in (interpolator or interpolate_video_2x)(counted(), model, isBGR=isBGR, divisor=divisor, depth=depth):
+        for frame in (interpolator or interpolate_video_2x)(counted(), model, isBGR=isBGR, divisor=divisor, depth=depth, **kw):
             out.write(frame)
             n_out += 1
     finally:

@@ -259,6 +259,7 @@ class Network(_ParamWatch, BlockRunner, nn.Module):
         self._plan_sig = None
         self._plist = None                          # cached parameter list of the per-forward currency check (_param_sig)
         self._pepoch = -1
+        self._primary: Optional["Network"] = None   # set on replicas (replica()): the model whose packed weights this one reads
 
     # ------------------------------------------------------------------ API parity
     def __set_local_window_size__(self, window_size):       # network_base.py:262-265
@@ -420,7 +421,41 @@ class Network(_ParamWatch, BlockRunner, nn.Module):
             pl = self._plist = [p for _, p in self.named_parameters()]
         return (tuple(map(_DATA_PTR_OF, pl)), tuple(map(_VERSION_OF, pl)), tuple(map(id, pl)))
 
+    def replica(self) -> "Network":
+        """A second front end on the SAME parameters: shares this model's parameter objects and its GEMM-layout weight copies, owns
+        its workspaces, window maps, launch plans and op backend.  What ``host_io.PairStreams`` builds K of to keep K independent
+        forwards in flight on K streams (the path's parallel axis is the pair axis: demo_2x.py:129-168,
+        benchmark/test_vimeo90k.py:80-110): no buffer is shared between two replicas, so no cross-stream event is needed inside a
+        forward.  Results are bit-identical to this model's.  Not part of the reference's API."""
+        import copy
+        rep = copy.copy(self)                     # nn.Module: _parameters / _buffers / _modules are shared by reference
+        rep._ops_obj = None
+        # (not through nn.Module.__setattr__: that would register the primary as a sub-module of its own replica)
+        object.__setattr__(rep, "_primary", self if self._primary is None else self._primary)
+        if rep._primary.__dict__.get("_prepare_lock") is None:
+            import threading
+            rep._primary._prepare_lock = threading.Lock()
+        rep.local_motion_args = dict(self.local_motion_args)
+        rep.global_motion_args = dict(self.global_motion_args)
+        rep._prepared, rep._prepared_sig = {}, None
+        rep._workspaces, rep._ws_key, rep._bufs, rep._geo = {}, None, {}, {}
+        rep._graphs, rep._graph_sig, rep._plans, rep._plan_sig = {}, None, {}, None
+        rep._frame_cache_on, rep._frame_cache, rep._reuse_first = False, None, False
+        rep._plist, rep._pepoch = None, -1
+        return rep
+
     def _prepare(self, ops):
+        if self._primary is not None:
+            # a replica reads the primary's packed weights; if they have to be (re)built now, that happens on THIS call's stream and
+            # the other replicas' streams must not read them early: wait for the packing kernels once (rare: a parameter changed)
+            pm = self._primary
+            with pm._prepare_lock:                 # replicas may run on worker threads (host_io.PairStreams)
+                before = pm._prepared_sig
+                P = pm._prepare(pm._ops(ops.device) if isinstance(ops, HipOps) else ops)
+                if pm._prepared_sig is not before and isinstance(ops, HipOps):
+                    torch.cuda.current_stream(ops.device).synchronize()
+                self._prepared, self._prepared_sig, self._plist = P, pm._prepared_sig, pm._plist
+            return P
         sig = self._param_sig()
         if sig == self._prepared_sig:
             return self._prepared

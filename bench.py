@@ -130,7 +130,7 @@ def parse():
     return args
 
 
-def time_config(pkg, host_io, pairs, dev, cname, steps, warmup, precision, shared=None, ensemble=False):
+def time_config(pkg, host_io, pairs, dev, cname, steps, warmup, precision, shared=None, ensemble=False, inflight=()):
     """One BASELINE.json configuration on one GPU, timed like the headline: resident synthetic pairs, ``warmup`` untimed forwards (they
     also record the launch plan), ``steps`` timed ones between synchronisations.  -> the entry of the bench line's ``configs`` block."""
     variant, height, width, g_on, desc = CONFIGS[cname]
@@ -167,6 +167,35 @@ def time_config(pkg, host_io, pairs, dev, cname, steps, warmup, precision, share
     if fl:
         out["forward_tflops"] = round(fl * fps / 1e12, 2)
         out["forward_frac_of_f16x3_peak"] = round(fl * fps / 1e12 / (PEAK_F16_MFMA_TFLOPS / 3.0), 4)
+    if inflight:
+        # K independent forwards in flight (host_io.PairStreams: K replicas -- shared weights, own workspace + launch plan -- on K
+        # streams, pairs round-robin, no cross-stream event inside a forward; outputs bit-identical to the single-stream forward:
+        # tests/test_gpu_e2e.py::test_pair_streams_equal_single_stream).  Reported BESIDE the single-stream value above, never
+        # instead of it.  Timed like it: resident pairs, the same number of forwards, one synchronisation at each end; every forward
+        # returns fresh output tensors.  (`record_outputs=False`: nothing here consumes the outputs on another stream, so the
+        # allocator's cross-stream bookkeeping -- ~25 record_stream calls per forward -- is not needed; `..._with_bookkeeping` has it.)
+        kin = {}
+        for k in inflight:
+            with host_io.PairStreams(net, k) as ps:
+                for _ in ps.map((frames[i & 1] for i in range(3 * k + 2)), wait_inputs=False, record_outputs=False):
+                    pass
+                ps.synchronize()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                n = sum(1 for _ in ps.map((frames[i & 1] for i in range(steps)), wait_inputs=False, record_outputs=False))
+                ps.synchronize()
+                kin[str(k)] = round(n / (time.perf_counter() - t0), 2)
+                if k == inflight[-1]:
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    n = sum(1 for _ in ps.map((frames[i & 1] for i in range(steps))))
+                    ps.synchronize()
+                    out["frames_per_s_k_inflight_with_bookkeeping"] = {str(k): round(n / (time.perf_counter() - t0), 2)}
+            torch.cuda.empty_cache()
+        out["frames_per_s_k_inflight"] = kin
+        if fl:
+            best = max(kin.values())
+            out["k_inflight_frac_of_f16x3_peak"] = round(fl * best / 1e12 / (PEAK_F16_MFMA_TFLOPS / 3.0), 4)
     net.release_workspace()
     del frames
     torch.cuda.empty_cache()
@@ -508,7 +537,8 @@ def main():
                                         "forward_frac_of_f16x3_peak": result.get("forward_frac_of_f16x3_peak")}}
             for cname, csteps, cwarm in (("c1", 200, 20), ("c2", 200, 20), ("c3", 60, 6), ("c5", 4, 3)):
                 result["configs"][cname] = time_config(pkg, host_io, pairs, dev, cname, csteps, cwarm, args.precision,
-                                                       shared=(net, sd) if CONFIGS[cname][0] == variant else None)
+                                                       shared=(net, sd) if CONFIGS[cname][0] == variant else None,
+                                                       inflight=(2, 3, 4) if cname in ("c1", "c2", "c3") else ())
             # the large-motion mode of the API on the c3 frame size: planned like every other mode since its pick moved
             # into the C ABI (atmvfi_ensemble_select)
             result["configs"]["c3_ensemble"] = time_config(pkg, host_io, pairs, dev, "c3", 40, 6, args.precision, shared=(net, sd), ensemble=True)

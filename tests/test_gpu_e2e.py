@@ -754,6 +754,63 @@ def test_lanes_equal_single_stream(dev, weights):
     torch.cuda.empty_cache()
 
 
+def test_pair_streams_equal_single_stream(dev, weights):
+    """host_io.PairStreams: K replicas (Network.replica(): shared parameters and packed weights, own
+    workspace + launch plan) on K streams, pairs round-robin, no cross-stream event inside a forward.  Every output of every pair is
+    bit for bit the single-stream forward's, at three shapes, K = 2..4, with one issuing thread and with a thread per stream, before
+    and after the plans exist; the model's switches follow; a bad pair raises in the caller; an in-place parameter update reaches
+    every replica; FramePipeline / interpolate_video_2x with streams > 1 deliver the sequential frames."""
+    cases = (("lite", pkg.NetworkLite, (1, 256, 256), True), ("lite", pkg.NetworkLite, (2, 256, 448), False),
+             ("base", pkg.NetworkBase, (1, 192, 320), True))
+    for variant, cls, (bsz, H, W), glob in cases:
+        net = cls()
+        net.load_state_dict(weights(variant), strict=True)
+        net.to(dev).eval()
+        net.global_motion = glob
+        frames = [[t.to(dev) for t in (pairs.random_pair if i % 2 else pairs.smooth_pair)(bsz, H, W, seed=30 + i)] for i in range(5)]
+        want = [[t.clone() for t in _flat(net(*f))] for f in frames]
+        for k, thr in ((2, False), (3, True), (4, False)):
+            with host_io.PairStreams(net, k, threads=thr) as ps:
+                assert len(ps.replicas) == k and all(next(r.parameters()) is next(net.parameters()) for r in ps.replicas)
+                for rep in range(3):            # 15 pairs per round: every replica sees eager, recording and replayed forwards
+                    outs = list(ps.map(frames[i % 5] for i in range(15)))
+                    assert len(outs) == 15
+                    for i, o in enumerate(outs):
+                        for t, r in zip(_flat(o), want[i % 5]):
+                            assert torch.equal(t, r), (variant, k, thr, rep, i)
+                assert all(any(not isinstance(p, (int, bool)) for p in r._plans.values()) for r in ps.replicas)
+                assert all(r._prepared is net._prepared for r in ps.replicas)          # one set of packed weights
+                if variant == "lite" and k == 2:
+                    net.global_motion = not glob                                          # the caller flips a switch on the model
+                    other = net(*frames[0])["I_t"].clone()
+                    got = list(ps.map([frames[0], frames[0], frames[0]]))
+                    assert all(torch.equal(o["I_t"], other) for o in got) and not torch.equal(other, want[0][0])
+                    net.global_motion = glob
+                    with pytest.raises(ValueError):                                       # a forward's error surfaces in the caller
+                        list(ps.map([(frames[0][0], frames[1][1][..., :64])]))
+                    bias = dict(net.named_parameters())["refine_head.1.0.bias"]
+                    keep = bias.detach().clone()
+                    with torch.no_grad():
+                        bias.add_(0.125)                                                  # in-place update: every replica repacks / re-records
+                    upd = net(*frames[1])["I_t"].clone()
+                    assert not torch.equal(upd, want[1][0])
+                    assert all(torch.equal(o["I_t"], upd) for o in ps.map([frames[1]] * 5))
+                    with torch.no_grad():
+                        bias.copy_(keep)
+                    assert all(torch.equal(o["I_t"], w[0]) for o, w in zip(ps.map(frames), want))
+        net.release_workspace()
+    # the uint8 pipeline and the video loop with several forwards in flight
+    net = pkg.NetworkLite()
+    net.load_state_dict(weights("lite"), strict=True)
+    net.to(dev).eval()
+    clip = pairs.uint8_video(9, 100, 150, seed=4)
+    seq = list(host_io.interpolate_video_2x(iter(clip), net))
+    for k in (2, 3):
+        got = list(host_io.interpolate_video_2x(iter(clip), net, streams=k))
+        assert len(got) == len(seq) == 17 and all(np.array_equal(a, b) for a, b in zip(got, seq)), k
+    torch.cuda.empty_cache()
+
+
 def test_lanes_on_a_fresh_workspace(dev, weights):
     """the FIRST forward of a shape with lanes on creates workspace inside a branch body (the global branch's plane
     buffers are zero-filled by torch on their first use).  That fill must be ordered with the lane's kernels -- the result of a
