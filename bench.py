@@ -177,18 +177,19 @@ def time_config(pkg, host_io, pairs, dev, cname, steps, warmup, precision, share
         kin = {}
         for k in inflight:
             with host_io.PairStreams(net, k) as ps:
-                for _ in ps.map((frames[i & 1] for i in range(3 * k + 2)), wait_inputs=False, record_outputs=False):
+                # every replica: two eager forwards, the recording one (+ its self-check replay), two replays -- all before the clock
+                for _ in ps.map((frames[i & 1] for i in range(6 * k)), wait_inputs=False, record_outputs=False):
                     pass
                 ps.synchronize()
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                n = sum(1 for _ in ps.map((frames[i & 1] for i in range(steps)), wait_inputs=False, record_outputs=False))
+                n = sum(1 for _ in ps.map((frames[i & 1] for i in range(3 * steps)), wait_inputs=False, record_outputs=False))
                 ps.synchronize()
                 kin[str(k)] = round(n / (time.perf_counter() - t0), 2)
                 if k == inflight[-1]:
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
-                    n = sum(1 for _ in ps.map((frames[i & 1] for i in range(steps))))
+                    n = sum(1 for _ in ps.map((frames[i & 1] for i in range(3 * steps))))
                     ps.synchronize()
                     out["frames_per_s_k_inflight_with_bookkeeping"] = {str(k): round(n / (time.perf_counter() - t0), 2)}
             torch.cuda.empty_cache()
