@@ -77,10 +77,37 @@ __device__ __forceinline__ void fp16_saturate_on() { asm volatile("s_setreg_imm3
 // fp32 bit patterns under FP16_OVFL = 1 (tools/probes/split_mix_probe.hip, profiles/r04_split_mix_probe.txt).  The epilogues and
 // operand stagings that split are VALU-bound.  (Until round 2 the saturation was four v_med3_f32: 5 per value.)  An infinite input
 // stays infinite in hi and makes lo' NaN: the fp32 reference has inf or NaN downstream of such a value as well.
+#ifdef ATMVFI_RANGE_CHECK
+// The CHECKED build (libatmvfi_hip_checked.so, `make checked`; Network.set_precision("f16x3-checked")): every activation that is
+// split counts, in a device word the caller attached (atmvfi_range_word_set), when its hi half comes out at the fp16 limit or
+// non-finite -- |x| >= 65488 (rounds or saturates to 65504), inf, NaN -- i.e. when the f16x3 engines' operand range contract
+// (deviation 2) is violated and the result silently differs from the fp32 reference.  One device variable
+// and one setter per translation unit (the library is not linked with relocatable device code); the default build has neither.
+namespace atmvfi {
+typedef int (*RangeWordSetter)(unsigned*, hipStream_t);
+void range_registry_add(RangeWordSetter s);
+}  // namespace atmvfi
+namespace {
+__device__ unsigned* g_range_word = nullptr;
+unsigned* g_range_word_host = nullptr;
+int range_word_set_tu(unsigned* p, hipStream_t s) {
+    g_range_word_host = p;           // (a source that outlives the asynchronous copy)
+    return (int)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_range_word), &g_range_word_host, sizeof(unsigned*), 0, hipMemcpyHostToDevice, s);
+}
+const int g_range_word_registered = (atmvfi::range_registry_add(&range_word_set_tu), 0);
+}  // namespace
+#endif
+
 __device__ __forceinline__ void split_pair(const f32x2 x, f16x2& hi, f16x2& lo) {
     hi = __builtin_convertvector(x, f16x2);
     const f32x2 xs = x * 1024.0f;
     const unsigned hb = __builtin_bit_cast(unsigned, hi);
+#ifdef ATMVFI_RANGE_CHECK
+    if ((hb & 0x7fffu) >= 0x7bffu || ((hb >> 16) & 0x7fffu) >= 0x7bffu) {
+        unsigned* w = g_range_word;
+        if (w) atomicAdd(w, 1u);
+    }
+#endif
     const float k = 1024.0f;
     unsigned lb;
     asm("v_fma_mixlo_f16 %0, %1, -%2, %3 op_sel_hi:[1,0,0]" : "=v"(lb) : "v"(hb), "v"(k), "v"(xs.x));

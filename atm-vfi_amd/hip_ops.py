@@ -21,6 +21,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libatmvfi_hip.so")
+CHECKED_LIB_PATH = os.path.join(_HERE, "libatmvfi_hip_checked.so")     # the same sources with -DATMVFI_RANGE_CHECK (csrc/Makefile)
 
 GEMM_CONV, GEMM_LINEAR, GEMM_DECONV = 0, 1, 2
 
@@ -79,6 +80,8 @@ SIGNATURES = {
     "atmvfi_version": (c_i, []),
     "atmvfi_last_error": (ctypes.c_char_p, []),
     "atmvfi_source_digest": (ctypes.c_char_p, []),
+    "atmvfi_range_word_set": (c_i, [c_f, c_f]),
+    "atmvfi_range_checked": (c_i, []),
     "atmvfi_gemm": (c_i, [ctypes.POINTER(GemmParams), c_f]),
     "atmvfi_gemm_workspace_floats": (c_l, [c_l, c_i, c_i]),
     "atmvfi_split_planes": (c_i, [c_f, c_i, c_l, c_i, c_f, c_f, c_f, c_i, c_f]),
@@ -513,9 +516,18 @@ class LaunchPlan:
 class HipOps:
     """The op vocabulary of the hot path, each a single HIP kernel launch."""
 
-    def __init__(self, device: torch.device):
-        self.lib = load_library()
+    def __init__(self, device: torch.device, checked: bool = False):
+        # checked: the build that counts operands beyond the f16x3 engines' fp16 range (libatmvfi_hip_checked.so, include/atmvfi.h
+        # atmvfi_range_word_set).  One device word per HipOps; attached at the top of every forward (begin_forward): the library has
+        # one attachment per device, so one checked model runs at a time on a device.
+        self.checked = bool(checked)
+        self.lib = load_library(CHECKED_LIB_PATH) if self.checked else load_library()
         self.device = device
+        self.range_word: Optional[torch.Tensor] = None
+        if self.checked:
+            if self.lib.atmvfi_range_checked() != 1:
+                raise HipLibraryMissing(f"{CHECKED_LIB_PATH} is not a checked build (make -C atm-vfi_amd/csrc checked)")
+            self.range_word = torch.zeros(1, dtype=torch.int32, device=device)
         self.profile: Optional[List] = None      # when a list: (name, meta, start_evt, end_evt) per launch
         # "f16x3": 3x3/s1 convs run split-precision on the 16-bit MFMA (hi*hi + hi*lo + lo*hi, fp32 accumulate);
         # "f32": everything on the exact-fp32 MFMA.
@@ -578,6 +590,8 @@ class HipOps:
         self.lane = 0
         self._lane0 = None
         self._next_event = 0
+        if self.checked:
+            self._check(self.lib.atmvfi_range_word_set(self.range_word.data_ptr(), self._stream()), "range_word_set")
 
     def _order(self, first: int, then: int):
         """Everything issued so far on lane ``first`` happens before whatever lane ``then`` is given from now on."""

@@ -222,6 +222,7 @@ class Network(_ParamWatch, BlockRunner, nn.Module):
         # ---- runtime state (not part of the state dict) ----
         self._init_runner()
         self._precision = "f16x3"
+        self._checked = False                        # "f16x3-checked": the library build that counts out-of-range operands
         self.use_plane_deconvs = os.environ.get("ATMVFI_PLANE_DECONV", "1") != "0"    # A/B switch: decoder deconvs from split planes
         self.use_plane_convs = os.environ.get("ATMVFI_PLANE_CONV", "1") != "0"        # A/B switch: 3x3 convs on split-plane input
         self.use_unet_planes = os.environ.get("ATMVFI_UNET_PLANES", "1") != "0"       # A/B switch: the refiner's strided convs on split planes
@@ -313,12 +314,34 @@ class Network(_ParamWatch, BlockRunner, nn.Module):
     def set_precision(self, precision: str):
         """"f16x3" (default): contractions as fp16 hi/lo split, three 16-bit MFMAs per product, fp32 accumulate
         (~22 significand bits, operands must stay within the fp16 range).  "f32": every contraction on the exact-fp32
-        MFMA (about 2.5x slower).  Not part of the reference's API."""
-        if precision not in ("f16x3", "f32"):
-            raise ValueError("precision must be 'f16x3' or 'f32'")
-        self._precision = precision
+        MFMA (about 2.5x slower).  "f16x3-checked": the f16x3 arithmetic, bit for bit, on the CHECKED build of the library
+        (libatmvfi_hip_checked.so), which counts every activation pair whose split hit the fp16 limit (|x| >= 65488, inf, NaN) --
+        ``range_violations()`` reads the count; launch plans and graphs are off in this mode.  Not part of the reference's API."""
+        if precision not in ("f16x3", "f32", "f16x3-checked"):
+            raise ValueError("precision must be 'f16x3', 'f32' or 'f16x3-checked'")
+        checked = precision == "f16x3-checked"
+        if checked != self._checked:
+            # another library: packed weights, workspaces, plans and the op backend belong to the one that made them
+            self._ops_obj = None
+            self._drop_device_state()
+        self._checked = checked
+        self._precision = "f16x3" if checked else precision
         if self._ops_obj is not None and hasattr(self._ops_obj, "precision"):
-            self._ops_obj.precision = precision
+            self._ops_obj.precision = self._precision
+
+    def range_violations(self, reset: bool = False) -> int:
+        """Activation pairs split beyond the fp16 operand range since the model entered "f16x3-checked" (or since the last
+        ``reset``): 0 means every contraction of every forward so far saw operands the f16x3 engines represent (DESIGN.md section 1,
+        deviation 2); anything else means results may differ from the fp32 reference -- use ``set_precision("f32")``.  Synchronises."""
+        if not self._checked:
+            raise RuntimeError("range_violations(): the model is not in 'f16x3-checked' precision")
+        ops = self._ops_obj
+        if ops is None or getattr(ops, "range_word", None) is None:
+            return 0
+        n = int(ops.range_word.item()) & 0xffffffff
+        if reset:
+            ops.range_word.zero_()
+        return n
 
     def _drop_device_state(self):
         """Everything that lives on one device or was derived there: packed weights, workspaces, window maps, captured graphs."""
@@ -344,7 +367,7 @@ class Network(_ParamWatch, BlockRunner, nn.Module):
             if device.type != "cuda":
                 raise RuntimeError("atm-vfi_amd.Network.forward runs on MI355X only: move the model and its inputs to "
                                    "'cuda' (HIP). There is no CPU implementation in the product; the CPU oracle lives in oracle/.")
-            self._ops_obj = HipOps(device)
+            self._ops_obj = HipOps(device, checked=self._checked)
             self._ops_obj.precision = self._precision
             self._ops_obj.gemm_workspace = self._gemm_scratch
         return self._ops_obj
@@ -829,7 +852,7 @@ class Network(_ParamWatch, BlockRunner, nn.Module):
         """max |I_t(f16x3) - I_t(exact fp32 engine)| on this frame pair: the run-time check that a checkpoint's activations stay inside
         the fp16 range of the split engines (an operand beyond 65504 saturates silently there; on the stress weights the largest
         |activation| is 24).  Costs one forward on each engine; expect ~1e-4, investigate above 1e-3."""
-        keep = self._precision
+        keep = "f16x3-checked" if self._checked else self._precision
         try:
             self.set_precision("f32")
             ref = self.forward(im0, im1)["I_t"].clone()
@@ -851,14 +874,14 @@ class Network(_ParamWatch, BlockRunner, nn.Module):
 
     def _mode_key(self, ops, im0, im1) -> Tuple:
         return (tuple(im0.shape), tuple(im1.shape), str(im0.device), self.global_motion, self.ensemble_global_motion,
-                self._precision, self.use_split_planes, self.use_plane_convs, self.use_unet_planes, self.use_plane_deconvs,
+                self._precision, self._checked, self.use_split_planes, self.use_plane_convs, self.use_unet_planes, self.use_plane_deconvs,
                 self.use_fused_stem, self.use_splitk, self.use_fused_tail, getattr(ops, "attention_f16x3", None), self.local_motion_args["window_size"],
                 self.global_motion_args["window_size"], getattr(ops, "warp_tiles", None), getattr(ops, "conv3_instance", None),
                 getattr(ops, "gemm_tile_wn", None), self.use_lanes, self._workspace_key(im0))
 
     def forward(self, im0: torch.Tensor, im1: torch.Tensor, reuse_first: bool = False):
         self._reuse_first = bool(reuse_first)
-        if not im0.is_cuda or self._frame_cache_on:
+        if not im0.is_cuda or self._frame_cache_on or self._checked:
             return self._forward_eager(im0, im1)
         if self.use_graphs:
             return self._forward_graph(im0, im1)

@@ -43,6 +43,16 @@ const char* atmvfi_last_error(void);
  * this header), baked in at build time: lets a caller prove that a shipped .so belongs to the shipped sources.  The reference has
  * no counterpart (pure Python, nothing is built). */
 const char* atmvfi_source_digest(void);
+/* The f16x3 engines' operand range contract at run time.  Contraction operands are split as x = hi + lo'/1024 in fp16: |x| beyond
+ * 65504 saturates silently (finite, but no longer what the fp32 reference computes).  The CHECKED build of this library
+ * (libatmvfi_hip_checked.so: the same sources with -DATMVFI_RANGE_CHECK, `make checked`) counts, in a device word the caller
+ * attaches, every pair of activations whose split produced a hi half at the fp16 limit or non-finite (|x| >= 65488, inf, NaN) --
+ * at every place an activation is split: the plane sinks of all producers and the in-kernel operand splits.  `word`: a zeroed
+ * device uint32 that must outlive the launches (NULL detaches); attached for the CURRENT device, ordered on `stream`.
+ * atmvfi_range_checked(): 1 in the checked build, 0 in the default one, where atmvfi_range_word_set fails with ATMVFI_EINVAL
+ * and no kernel carries an extra instruction.  The reference has no counterpart (it computes in fp32). */
+int atmvfi_range_word_set(uint32_t* word, void* stream);
+int atmvfi_range_checked(void);
 
 /* ------------------------------------------------------------------------------------
  * Implicit-GEMM contraction engine on fp32 MFMA (v_mfma_f32_16x16x4_f32).

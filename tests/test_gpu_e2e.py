@@ -592,6 +592,56 @@ def test_f16x3_deviation_and_weight_range_warning(dev, weights):
         net(a, b)
 
 
+def test_range_guard_of_the_checked_build(dev, weights):
+    """Network.set_precision("f16x3-checked"): the checked build of the library computes exactly what the
+    default one does and counts operands beyond the fp16 range at every activation split.  A clean run leaves the count at zero; an
+    activation of 1e5 (a bias pushed there; then an input frame scaled there) trips it; the count is sticky until reset; the default
+    precision is unaffected and carries no word."""
+    net = pkg.NetworkLite()
+    net.load_state_dict(weights("lite"), strict=True)
+    net.to(dev).eval()
+    a, b = [t.to(dev) for t in pairs.smooth_pair(1, 128, 192, seed=77)]
+    want = [t.clone() for t in _flat(net(a, b))]
+    with pytest.raises(RuntimeError):
+        net.range_violations()
+    net.set_precision("f16x3-checked")
+    for rep in range(4):                                   # (no plans in this mode: every call is a sequence of direct launches)
+        for t, r in zip(_flat(net(a, b)), want):
+            assert torch.equal(t, r)
+    assert net._ops_obj.checked and net._ops_obj.lib.atmvfi_range_checked() == 1 and not net._plans
+    assert net.range_violations() == 0
+    # (1) a bias of 1e5 in the refiner's first conv: its output is split for the next contraction
+    bias = dict(net.named_parameters())["proj.0.bias"]
+    keep = bias.detach().clone()
+    with torch.no_grad():
+        bias[3] = 1.0e5
+    out = net(a, b)["I_t"]
+    n1 = net.range_violations()
+    assert n1 > 0 and torch.isfinite(out).all()            # saturates (finite), and says so
+    with torch.no_grad():
+        bias.copy_(keep)
+    net(a, b)
+    assert net.range_violations() == n1                     # sticky: a clean forward does not clear it
+    assert net.range_violations(reset=True) == n1 and net.range_violations() == 0
+    # (2) an input frame beyond the range (the stem splits the frame patch itself)
+    net(a * 3.0e5, b)
+    assert net.range_violations(reset=True) > 0
+    # (3) inf / NaN count too
+    c = a.clone()
+    c[0, 1, 5, 7] = float("inf")
+    net(c, b)
+    assert net.range_violations(reset=True) > 0
+    # back on the default build: same results, no word, plans again
+    net.set_precision("f16x3")
+    for rep in range(4):
+        for t, r in zip(_flat(net(a, b)), want):
+            assert torch.equal(t, r)
+    assert not net._ops_obj.checked and net._ops_obj.range_word is None
+    assert net._ops_obj.lib.atmvfi_range_checked() == 0
+    rc = net._ops_obj.lib.atmvfi_range_word_set(None, None)
+    assert rc != 0 and b"default build" in net._ops_obj.lib.atmvfi_last_error()
+
+
 def _flat(out):
     return [out[k] for k in ("I_t", "opt_flow_0", "opt_flow_1", "I_t_0", "I_t_1", "occ_mask1", "occ_mask2")] + list(out["im_t_list"]) + \
         list(out["im0_warped_list"]) + list(out["im1_warped_list"])

@@ -422,8 +422,14 @@ def test_library_is_built_from_these_sources():
     import source_digest
     lib = hip_ops.load_library()
     assert lib.atmvfi_source_digest().decode() == source_digest.digest(), "rebuild: python -c 'import __graft_entry__ as g; g.build()'"
-    assert not [f for f in os.listdir(os.path.join(ROOT, "atm-vfi_amd")) if f.endswith(".so") and f != "libatmvfi_hip.so"], \
+    assert not [f for f in os.listdir(os.path.join(ROOT, "atm-vfi_amd")) if f.endswith(".so") and f not in ("libatmvfi_hip.so", "libatmvfi_hip_checked.so")], \
         "diagnostic libraries belong in tools/lib/, not in the package"
+    # the checked build (Network.set_precision("f16x3-checked")) is the same sources with one -D: same digest, same symbols, and it
+    # says what it is; the default build refuses the range word (no kernel of it carries the check)
+    chk = hip_ops.load_library(hip_ops.CHECKED_LIB_PATH)
+    assert chk.atmvfi_source_digest().decode() == source_digest.digest()
+    assert chk.atmvfi_range_checked() == 1 and lib.atmvfi_range_checked() == 0
+    assert lib.atmvfi_range_word_set(None, None) == -1 and b"default build" in lib.atmvfi_last_error()
 
 
 def test_bench_launcher_reports_a_failed_rank():

@@ -4,6 +4,9 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT]
 hip_ops = importlib.import_module("atm-vfi_amd.hip_ops")
+if os.environ.get("ATMVFI_LIB"):          # A/B of two builds on one box: ATMVFI_LIB=tools/lib/libatmvfi_hip_base.so
+    hip_ops.LIB_PATH = os.path.join(ROOT, os.environ["ATMVFI_LIB"])
+    hip_ops.load_library.__defaults__ = (hip_ops.LIB_PATH,)
 dev = torch.device("cuda:0")
 ops = hip_ops.HipOps(dev)
 g = torch.Generator().manual_seed(0)
