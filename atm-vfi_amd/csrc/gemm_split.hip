@@ -17,6 +17,15 @@
 #include "common.h"
 #include "gemm_common.h"
 
+// The kernel of THIS file is the REFERENCE SCHEDULE of the plane-input GEMM: the first form of the engine, kept as the yardstick the
+// ping-pong kernels (gemm_pp.hip, gemm_duo.hip) are held to bit for bit (tests/test_gpu_ops.py::test_gemm_pp_matches_reference_schedule)
+// and for the stamp / ablation tools.  The default forward never launches it, so the product library does not carry it (round 6):
+// it is compiled only into the diagnostic libraries (`make ref`, `make stamp`, `make ablate` -> tools/lib/).  What the product
+// keeps from this file: the engine selection (launch_gemm_split), split_planes, head1x1_planes, the split-K plan.
+#if defined(ATMVFI_REFSCHED) || defined(ATMVFI_STAMP) || defined(ATMVFI_ABLATE)
+#define ATMVFI_HAVE_REFSCHED 1
+#endif
+
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 #ifdef ATMVFI_STAMP
@@ -63,6 +72,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 #define SABL(bit) false
 #endif
 
+#ifdef ATMVFI_HAVE_REFSCHED
 template <int WGM, int WGN, bool CONVM>
 __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_split_kernel(const GemmDev a) {
     fp16_saturate_on();
@@ -321,6 +331,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_split_kernel(const Gem
     }
 #endif
 }
+#endif  // ATMVFI_HAVE_REFSCHED
 
 // fp32 rows -> (hi, lo') planes in the chunk-major layout; one thread per 8 channels, pad channels of the last chunk written as
 // zero.  An optional per-channel PReLU is applied first (the leading nn.PReLU of the decoder stages, network_base.py:209,215).
@@ -415,6 +426,7 @@ __global__ __launch_bounds__(256) void head1x1_planes_kernel(const _Float16* __r
     }
 }
 
+#ifdef ATMVFI_HAVE_REFSCHED
 template <int WGM, int WGN, bool CONVM>
 int launch_split(const GemmDev& d, int ngemm, hipStream_t s) {
     constexpr int BM = 64 * WGM, BN = 64 * WGN;
@@ -438,6 +450,7 @@ int launch_split(const GemmDev& d, int ngemm, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3((unsigned)(mgroups * 8 * dd.nblocks)), dim3(64 * WGM * WGN), lds, s, dd);
     return atmvfi::check_launch("gemm_split");
 }
+#endif  // ATMVFI_HAVE_REFSCHED
 
 }  // namespace
 
@@ -512,7 +525,11 @@ int atmvfi::launch_gemm_split(const GemmDev& d, int ngemm, hipStream_t s) {
         return duo_rounds < (double)pp_rounds ? launch_gemm_duo(d, ngemm, s) : launch_gemm_pp(d, ngemm, s);
     }
     if (d.force_wn != -1) return launch_gemm_pp(d, ngemm, s);
+#ifdef ATMVFI_HAVE_REFSCHED
     return d.mode == ATMVFI_GEMM_CONV ? launch_split<4, 2, true>(d, ngemm, s) : launch_split<4, 2, false>(d, ngemm, s);
+#else
+    ATMVFI_REQUIRE(false, ATMVFI_EINVAL, "gemm: tile_wn = -1 (the reference schedule) is not in the product library: load tools/lib/libatmvfi_hip_ref.so (make -C atm-vfi_amd/csrc ref)");
+#endif
 }
 
 extern "C" int atmvfi_split_planes_at(const float* in, int in_ld, int64_t M, int C, const float* prelu, void* hi, void* lo, int plane_rows,

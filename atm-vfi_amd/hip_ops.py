@@ -317,6 +317,8 @@ class LaunchPlan:
     ``HipOps.empty`` becomes an output slot; pointer arguments (by the entry point's declared types) that fall inside a slot's
     memory become patches.  A pointer field of a GEMM parameter block inside per-call memory cannot be patched: PlanUnsupported."""
 
+    debug = False      # diagnostic: replay one op per call, synchronised, announced on stderr first (finds the op that faults)
+
     def __init__(self, lib, inputs):
         self.lib = lib
         self.ops_list = []                 # (fn id, [values], [is_float])
@@ -473,7 +475,7 @@ class LaunchPlan:
         base = self.n_inputs
         for k, t in enumerate(outs):
             sl[base + k] = t.data_ptr()
-        if os.environ.get("ATMVFI_PLAN_DEBUG") == "1":          # diagnostic: one op per call, synchronised, announced on stderr first
+        if LaunchPlan.debug:          # diagnostic (set LaunchPlan.debug = True): one op per call, synchronised, announced on stderr first
             import sys
             names = {v: k for k, v in self._fn_ids.items()}
             for k, j, slot, off in self.patches:
@@ -516,12 +518,13 @@ class LaunchPlan:
 class HipOps:
     """The op vocabulary of the hot path, each a single HIP kernel launch."""
 
-    def __init__(self, device: torch.device, checked: bool = False):
+    def __init__(self, device: torch.device, checked: bool = False, lib_path: Optional[str] = None):
         # checked: the build that counts operands beyond the f16x3 engines' fp16 range (libatmvfi_hip_checked.so, include/atmvfi.h
         # atmvfi_range_word_set).  One device word per HipOps; attached at the top of every forward (begin_forward): the library has
         # one attachment per device, so one checked model runs at a time on a device.
         self.checked = bool(checked)
-        self.lib = load_library(CHECKED_LIB_PATH) if self.checked else load_library()
+        # lib_path: another build of the same ABI (tests and tools: the diagnostic libraries under tools/lib/)
+        self.lib = load_library(lib_path) if lib_path else load_library(CHECKED_LIB_PATH) if self.checked else load_library()
         self.device = device
         self.range_word: Optional[torch.Tensor] = None
         if self.checked:
@@ -537,7 +540,7 @@ class HipOps:
         # fp32-input f16x3 GEMM; None / 0 = the library's cost model
         self.conv3_instance = None
         self.gemm_tile_wn = 0
-        self.warp_tiles = os.environ.get("ATMVFI_WARP_TILES", "1") != "0"     # A/B switch: planar warps with LDS-staged source tiles
+        self.warp_tiles = True             # planar warps with LDS-staged source tiles (False: the direct gathers; bit-identical)
         self.recording: Optional[LaunchPlan] = None     # when set: every launch is also appended to this plan
         # Lanes: independent branches of a forward on side streams (HipOps.branch / join; include/atmvfi.h "LANES").  lane 0 = the
         # caller's current stream; lanes 1.. = side streams of this object, created on first use.

@@ -23,7 +23,6 @@ from __future__ import annotations
 
 import math
 import operator
-import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -95,7 +94,7 @@ class BlockRunner:
 
     def _init_runner(self):
         self._ops_obj = None
-        self.use_split_planes = os.environ.get("ATMVFI_SPLIT_PLANES", "1") != "0"     # A/B switch (tools/profile_layers.py)
+        self.use_split_planes = True       # kernel selection (Network's `selections` argument): split planes between contraction layers
         self._bufs: Dict[Tuple, object] = {}
         self._geo: Dict[Tuple, Tuple[WindowGeometry, torch.Tensor, Optional[torch.Tensor]]] = {}
 
@@ -184,7 +183,13 @@ class BlockRunner:
 class Network(_ParamWatch, BlockRunner, nn.Module):
     VARIANT = "base"
 
-    def __init__(self, global_motion: bool = True, ensemble_global_motion: bool = False, variant: Optional[str] = None):
+    SELECTIONS = ("use_split_planes", "use_plane_deconvs", "use_plane_convs", "use_unet_planes", "use_fused_stem", "use_fused_tail",
+                  "use_splitk", "use_lanes", "use_plans")
+
+    def __init__(self, global_motion: bool = True, ensemble_global_motion: bool = False, variant: Optional[str] = None,
+                 selections: Optional[Dict[str, bool]] = None):
+        """``global_motion`` / ``ensemble_global_motion``: the reference's constructor (network_base.py:89).  ``selections`` (not in
+        the reference): overrides of the kernel-selection attributes in ``SELECTIONS`` (all default to the measured-best choice)."""
         super().__init__()
         self.variant_name = variant or self.VARIANT
         v = S.VARIANTS[self.variant_name]
@@ -223,17 +228,21 @@ class Network(_ParamWatch, BlockRunner, nn.Module):
         self._init_runner()
         self._precision = "f16x3"
         self._checked = False                        # "f16x3-checked": the library build that counts out-of-range operands
-        self.use_plane_deconvs = os.environ.get("ATMVFI_PLANE_DECONV", "1") != "0"    # A/B switch: decoder deconvs from split planes
-        self.use_plane_convs = os.environ.get("ATMVFI_PLANE_CONV", "1") != "0"        # A/B switch: 3x3 convs on split-plane input
-        self.use_unet_planes = os.environ.get("ATMVFI_UNET_PLANES", "1") != "0"       # A/B switch: the refiner's strided convs on split planes
-        self.use_fused_stem = os.environ.get("ATMVFI_FUSED_STEM", "1") != "0"         # A/B switch: the encoder's first three layers in one launch
-        self.use_fused_tail = os.environ.get("ATMVFI_FUSED_TAIL", "1") != "0"         # A/B switch: refine_head.1 folded into refine_head.0's epilogue
-        self.use_splitk = os.environ.get("ATMVFI_SPLITK", "1") != "0"                 # A/B switch: split-K of under-filled long-K 3x3 launches
-        # independent branches of a forward on side streams (HipOps.branch; ATMVFI_LANES=1).  OFF by default: bit-identical and planned
+        # Kernel selections: every one of these has been "on" since round 2 and is bit-compatible with its alternative inside the
+        # parity budget (tests/test_gpu_e2e.py::test_fallback_kernel_selections_end_to_end runs each alternative).  They are plain
+        # attributes / constructor arguments (`Network(selections={"use_fused_stem": False})`), not environment variables: the
+        # product reads no environment variable.
+        self.use_plane_deconvs = True     # decoder deconvs from split planes
+        self.use_plane_convs = True       # 3x3 convs on split-plane input
+        self.use_unet_planes = True       # the refiner's strided convs on split planes
+        self.use_fused_stem = True        # the encoder's first three layers in one launch
+        self.use_fused_tail = True        # refine_head.1 folded into refine_head.0's epilogue
+        self.use_splitk = True            # split-K of under-filled long-K 3x3 launches
+        # independent branches of a forward on side streams (HipOps.branch).  OFF by default: bit-identical and planned
         # like everything else, but not faster -- 256x256 860.7 -> 853.3 frames/s, 256x448 1062.6 -> 1063.0, 576x960 169.9 -> 170.7,
         # 1088x1920 51.9 -> 52.0 (profiles/r05_lanes_ab.txt): what the overlapped launches save (~100 us of 1.2 ms at 256x256) the four
-        # cross-queue event waits of a forward cost again
-        self.use_lanes = os.environ.get("ATMVFI_LANES", "0") == "1"
+        # cross-queue event waits of a forward cost again.  Independent FORWARDS on streams of their own do pay: host_io.PairStreams.
+        self.use_lanes = False
         self._prepared: Dict[str, object] = {}
         self._prepared_sig = None
         # Workspaces: one dict of named buffers per (device, input shape, mode) key, least recently used first.  The reference's
@@ -254,13 +263,17 @@ class Network(_ParamWatch, BlockRunner, nn.Module):
         self._graphs: Dict[Tuple, Tuple] = {}
         self._graph_sig = None
         # launch plans (hip_ops.LaunchPlan): from the third forward with one (shape, mode, weights) key on, a forward is ONE
-        # atmvfi_plan_run call with fresh output tensors; A/B switch ATMVFI_PLANS=0 / enable_plans(False)
-        self.use_plans = os.environ.get("ATMVFI_PLANS", "1") != "0"
+        # atmvfi_plan_run call with fresh output tensors; enable_plans(False) turns it off
+        self.use_plans = True
         self._plans: Dict[Tuple, object] = {}       # key -> LaunchPlan | int (eager forwards seen so far) | False (cannot be planned)
         self._plan_sig = None
         self._plist = None                          # cached parameter list of the per-forward currency check (_param_sig)
         self._pepoch = -1
         self._primary: Optional["Network"] = None   # set on replicas (replica()): the model whose packed weights this one reads
+        for name, flag in (selections or {}).items():
+            if name not in self.SELECTIONS:
+                raise ValueError(f"unknown kernel selection {name!r}; one of {self.SELECTIONS}")
+            setattr(self, name, bool(flag))
 
     # ------------------------------------------------------------------ API parity
     def __set_local_window_size__(self, window_size):       # network_base.py:262-265

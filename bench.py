@@ -119,6 +119,7 @@ def parse():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip timing BASELINE.json's other configurations (c1, c2, c3, c5) after the headline one")
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f32"])
+    ap.add_argument("--no-plans", action="store_true", help="direct launches (one C-ABI call per op) instead of launch-plan replay: the A/B of tools/small_configs.sh")
     ap.add_argument("--no-host-io", action="store_true", help="skip the PCIe-inclusive measurement (uint8 frames in host memory in and out)")
     ap.add_argument("--gather-u8", action="store_true", help="N > 1: all-gather the output frames rounded to uint8 (4x fewer bytes over xGMI)")
     ap.add_argument("--graph", action="store_true", help="replay the forward from a captured HIP graph (Network.enable_graphs); measured "
@@ -345,6 +346,8 @@ def main():
         return out
 
     net.set_precision(args.precision)
+    if args.no_plans:
+        net.enable_plans(False)
     net.enable_graphs(args.graph)             # one hipGraphLaunch per forward; the collective stays outside the graph
     # Set-up, before the W warm-up steps: forwards until this shape's launch plan is recorded and has replayed once (workspace, window
     # maps, packed weights, kernel attributes, the plan's record-time self-check, first-use allocations of the output tensors) -- so

@@ -1352,7 +1352,12 @@ def test_gemm_pp_matches_reference_schedule(case, engine, dev):
     gemm_split.hip (tile_wn = -1): same arithmetic, so bit-identical outputs, on shapes with several tiles per workgroup (the op tests
     above fit one round of 256 workgroups)."""
     kind, geom, cin, cout, ex = case
-    hp, hr = hip_ops.HipOps(dev), hip_ops.HipOps(dev)
+    # the reference schedule lives in the diagnostic library (round 6: the product library does not carry engines its forward never
+    # launches); __graft_entry__.build() / `make` produce it next to the product
+    ref_lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "lib", "libatmvfi_hip_ref.so")
+    assert os.path.exists(ref_lib), f"{ref_lib} missing: python -c 'import __graft_entry__ as g; g.build()'"
+    hp, hr = hip_ops.HipOps(dev), hip_ops.HipOps(dev, lib_path=ref_lib)
+    assert hr.lib.atmvfi_source_digest() == hp.lib.atmvfi_source_digest()          # the same sources
     hp.gemm_tile_wn = engine
     hr.gemm_tile_wn = -1
     g = torch.Generator().manual_seed(cin * 1000 + cout)

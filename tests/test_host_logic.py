@@ -310,6 +310,22 @@ def test_product_library_reads_no_environment():
     assert not re.search(r"atmvfi_\w*set_(schedule|tile_width)", defd)
 
 
+def test_product_package_reads_no_environment_and_selections_are_arguments():
+    """the kernel-selection switches are attributes / constructor arguments, not ATMVFI_* environment
+    variables -- no module of the package touches os.environ."""
+    pkg_dir = os.path.join(ROOT, "atm-vfi_amd")
+    for fn in sorted(os.listdir(pkg_dir)):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg_dir, fn)).read()
+            assert "os.environ" not in src and "getenv" not in src, f"{fn} reads the environment"
+    net = pkg.NetworkLite(selections={"use_fused_stem": False, "use_plans": False})
+    assert net.use_fused_stem is False and net.use_plans is False and net.use_plane_convs is True and net.use_lanes is False
+    assert all(hasattr(net, name) for name in net.SELECTIONS)
+    with pytest.raises(ValueError):
+        pkg.NetworkLite(selections={"use_magic": True})
+    assert pkg.NetworkBase(global_motion=False).global_motion is False       # the reference's positional / keyword arguments unchanged
+
+
 def test_reference_callers_import_lines_resolve():
     """The reference's own import lines, verbatim, in fresh interpreters: demo_2x.py:7-12 (cwd = repo root), README.md:31, and
     benchmark/test_*.py:12-16 (cwd = benchmark/, `sys.path.append('../')`).  They must resolve to this package's Network."""

@@ -16,7 +16,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "duo":
 elif len(sys.argv) > 1:
     opsA.lib = hip_ops.load_library(os.path.join(ROOT, sys.argv[1]))
 else:
-    opsA.gemm_tile_wn = -1          # A = the reference schedule (gemm_split.hip) of the same library
+    opsA = hip_ops.HipOps(dev, lib_path=os.path.join(ROOT, "tools", "lib", "libatmvfi_hip_ref.so"))
+    opsA.gemm_tile_wn = -1          # A = the reference schedule (gemm_split.hip; in the diagnostic library since round 6)
 g = torch.Generator().manual_seed(0)
 
 

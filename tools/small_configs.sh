@@ -6,7 +6,7 @@ cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 F="--no-cpu-baseline --no-host-io --no-profile"
 for c in c1 c2 c3; do
   python bench.py --config $c --steps 100 --warmup 20 $F > gpurun_out/${TAG}_${c}_plan.json 2>/dev/null
-  ATMVFI_PLANS=0 python bench.py --config $c --steps 100 --warmup 20 $F > gpurun_out/${TAG}_${c}_direct.json 2>/dev/null
+  python bench.py --config $c --steps 100 --warmup 20 --no-plans $F > gpurun_out/${TAG}_${c}_direct.json 2>/dev/null
   python bench.py --config $c --steps 100 --warmup 20 --graph $F > gpurun_out/${TAG}_${c}_graph.json 2>/dev/null
 done
 for c in c1 c2; do
