@@ -216,7 +216,9 @@ def self_launch(args) -> int:
         port = sk.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL's intra-node transport needs it on this driver
-    env.setdefault("OMP_NUM_THREADS", "8")
+    # host budget per rank: the ranks' CPU work is launching (one thread each); OpenMP pools of every rank's
+    # torch are capped so that N ranks never oversubscribe the node's CPU quota
+    env.setdefault("OMP_NUM_THREADS", str(max(1, min(8, host_cores()[0] // max(1, args.gpus)))))
     env["MASTER_ADDR"], env["MASTER_PORT"] = "127.0.0.1", str(port)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
@@ -500,6 +502,12 @@ def main():
                         if rows:
                             fam_out[fam]["traffic"] = round(sum(r["traffic_GB_per_launch"] * r["launches"] for r in rows) /
                                                             sum(r["launches"] for r in rows) * 1e9)
+                            # measured HBM bytes (PMC) over the algorithmic bytes of the same launches ("each layer reads its
+                            # input once and writes its output once"): > 1 = re-reads (halo, column blocks, L2 misses)
+                            alg = sum(agg[n]["bytes"] for n in families.get(fam, ([], 0))[0] if n in agg)
+                            if alg > 0:
+                                fam_out[fam]["algorithmic_bytes_per_forward"] = round(alg)
+                                fam_out[fam]["traffic_ratio"] = round(sum(r["traffic_GB_per_launch"] * r["launches"] for r in rows) * 1e9 / alg, 3)
                             fam_out[fam]["traffic_unit"] = f"bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/{pmc_file}, taken on this build: same source digest)"
                         else:
                             fam_out[fam]["traffic_unit"] = "null: no committed PMC pass was taken on this build (source digest differs)"
