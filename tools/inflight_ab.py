@@ -21,6 +21,7 @@ CFG = {"c1": ("lite", 256, 256, True, 400), "c2": ("lite", 256, 448, False, 400)
 def main():
     names = [a for a in sys.argv[1:] if a in CFG] or ["c1", "c2", "c3"]
     ks = [1, 2, 3, 4]
+    graphs = "--graphs" in sys.argv[1:]      # every replica replays a captured HIP graph (static outputs per replica) instead of its launch plan
     for a in sys.argv[1:]:
         if a.startswith("--ks="):
             ks = [int(x) for x in a[5:].split(",")]
@@ -46,10 +47,14 @@ def main():
         base = steps / (time.perf_counter() - t0)
         want = [net(*f)["I_t"].clone() for f in frames]
         line = f"{name} {v} {h}x{w} global {'on' if g else 'off'}: single stream {base:8.1f} frames/s |"
-        for k, thr in [(k, t) for t in (False, True) for k in ks]:
+        for k, thr in [(k, t) for t in ((False,) if graphs else (False, True)) for k in ks]:
             ps = host_io.PairStreams(net, k, threads=thr)
-            outs = list(ps.map(frames[i % 4] for i in range(4 * k + 4)))           # workspaces, plans
-            ok = all(torch.equal(o["I_t"], want[i % 4]) for i, o in enumerate(outs))
+            if graphs:
+                for r in ps.replicas:
+                    r.enable_graphs(True)
+            ok = True
+            for i, o in enumerate(ps.map(frames[i % 4] for i in range(4 * k + 4))):           # workspaces, plans
+                ok = ok and torch.equal(o["I_t"], want[i % 4])
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             n = 0
@@ -57,8 +62,8 @@ def main():
                 n += 1
             ps.synchronize()
             fps = n / (time.perf_counter() - t0)
-            outs = list(ps.map(frames[i % 4] for i in range(8)))
-            ok = ok and all(torch.equal(o["I_t"], want[i % 4]) for i, o in enumerate(outs))
+            for i, o in enumerate(ps.map(frames[i % 4] for i in range(8))):
+                ok = ok and torch.equal(o["I_t"], want[i % 4])
             line += f" K={k}{'t' if thr else ''}: {fps:7.1f}{'' if ok else ' DIFFERS'}"
             ps.release()
             del ps
