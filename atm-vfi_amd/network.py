@@ -270,6 +270,7 @@ class Network(_ParamWatch, BlockRunner, nn.Module):
         self._plist = None                          # cached parameter list of the per-forward currency check (_param_sig)
         self._pepoch = -1
         self._primary: Optional["Network"] = None   # set on replicas (replica()): the model whose packed weights this one reads
+        self._prepare_lock = None                   # created on the primary with its first replica
         for name, flag in (selections or {}).items():
             if name not in self.SELECTIONS:
                 raise ValueError(f"unknown kernel selection {name!r}; one of {self.SELECTIONS}")
@@ -457,6 +458,24 @@ class Network(_ParamWatch, BlockRunner, nn.Module):
             pl = self._plist = [p for _, p in self.named_parameters()]
         return (tuple(map(_DATA_PTR_OF, pl)), tuple(map(_VERSION_OF, pl)), tuple(map(id, pl)))
 
+    _RUNTIME_RESET = {"_ops_obj": None, "_prepared_sig": None, "_ws_key": None, "_graph_sig": None, "_plan_sig": None, "_plist": None,
+                      "_pepoch": -1, "_frame_cache": None, "_primary": None, "_prepare_lock": None, "_reuse_first": False}
+    _RUNTIME_DICTS = ("_bufs", "_geo", "_prepared", "_workspaces", "_graphs", "_plans")
+
+    def __getstate__(self):
+        """copy.deepcopy / pickle / torch.save(module): parameters, buffers and settings travel; device-side runtime state
+        (workspaces, packed weights, plans, graphs, the op backend, a replica's link to its primary and its lock) does not -- the copy
+        is a stand-alone model that builds its own on first use."""
+        d = dict(self.__dict__)
+        d.update(self._RUNTIME_RESET)
+        for k in self._RUNTIME_DICTS:
+            d[k] = {}
+        return d
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        _PARAM_EPOCH[0] += 1
+
     def replica(self) -> "Network":
         """A second front end on the SAME parameters: shares this model's parameter objects and its GEMM-layout weight copies, owns
         its workspaces, window maps, launch plans and op backend.  What ``host_io.PairStreams`` builds K of to keep K independent
@@ -470,7 +489,7 @@ class Network(_ParamWatch, BlockRunner, nn.Module):
         object.__setattr__(rep, "_primary", self if self._primary is None else self._primary)
         if rep._primary.__dict__.get("_prepare_lock") is None:
             import threading
-            rep._primary._prepare_lock = threading.Lock()
+            object.__setattr__(rep._primary, "_prepare_lock", threading.Lock())
         rep.local_motion_args = dict(self.local_motion_args)
         rep.global_motion_args = dict(self.global_motion_args)
         rep._prepared, rep._prepared_sig = {}, None

@@ -861,6 +861,29 @@ def test_pair_streams_equal_single_stream(dev, weights):
     torch.cuda.empty_cache()
 
 
+def test_deepcopy_of_a_used_model_is_standalone(dev, weights):
+    """copy.deepcopy of a model that has run (workspace, packed weights, plans) and has replicas: an independent model with its own
+    parameters and NO device-side runtime state; it builds its own on first use and computes the same frames."""
+    import copy
+    net = pkg.NetworkLite()
+    net.load_state_dict(weights("lite"), strict=True)
+    net.to(dev).eval()
+    a, b = [t.to(dev) for t in pairs.smooth_pair(1, 128, 192, seed=88)]
+    for _ in range(4):
+        want = net(a, b)["I_t"].clone()
+    with host_io.PairStreams(net, 2) as ps:
+        assert all(torch.equal(o["I_t"], want) for o in ps.map([(a, b)] * 4))
+        twin = copy.deepcopy(net)
+        rep_twin = copy.deepcopy(ps.replicas[0])
+    for m in (twin, rep_twin):
+        assert m.workspace_bytes() == 0 and m._ops_obj is None and m._primary is None and not m._plans
+        assert next(m.parameters()) is not next(net.parameters()) and next(m.parameters()).device == next(net.parameters()).device
+        assert torch.equal(m(a, b)["I_t"], want)
+    with torch.no_grad():
+        dict(twin.named_parameters())["refine_head.1.0.bias"].add_(0.5)          # the copies do not share storage
+    assert not torch.equal(twin(a, b)["I_t"], want) and torch.equal(net(a, b)["I_t"], want)
+
+
 def test_lanes_on_a_fresh_workspace(dev, weights):
     """the FIRST forward of a shape with lanes on creates workspace inside a branch body (the global branch's plane
     buffers are zero-filled by torch on their first use).  That fill must be ordered with the lane's kernels -- the result of a

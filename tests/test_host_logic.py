@@ -326,6 +326,33 @@ def test_product_package_reads_no_environment_and_selections_are_arguments():
     assert pkg.NetworkBase(global_motion=False).global_motion is False       # the reference's positional / keyword arguments unchanged
 
 
+def test_model_copies_and_pickles_without_runtime_state(nets):
+    """copy.deepcopy / torch.save(module) of a model -- also one that has replicas (a lock, a link to its primary) and a workspace --
+    carries parameters, buffers and settings, and none of the device-side runtime state."""
+    import copy
+    import io
+    net = nets["lite"]
+    G_case = [c for c in G.e2e_cases() if c["name"] == "lite_64x64_g"][0]
+    im0, im1 = G.case_inputs(G_case)
+    net.global_motion = True
+    net.ensemble_global_motion = False
+    net(im0, im1)                                            # (through the CPU test double: fills _bufs, _geo, _prepared)
+    rep = net.replica()
+    assert rep._primary is net and net._prepare_lock is not None and next(rep.parameters()) is next(net.parameters())
+    assert list(rep.state_dict()) == list(net.state_dict()) and "_primary" not in rep._modules
+    for obj in (net, rep):
+        c = copy.deepcopy(obj)
+        assert c._primary is None and c._prepare_lock is None and c._ops_obj is None and not c._bufs and not c._prepared and not c._plans
+        assert all(torch.equal(a, b) and a is not b for a, b in zip(c.state_dict().values(), net.state_dict().values()))
+        assert c.global_motion is True and c.local_motion_args == net.local_motion_args
+    buf = io.BytesIO()
+    torch.save(net, buf)
+    buf.seek(0)
+    back = torch.load(buf, weights_only=False)
+    assert type(back) is type(net) and all(torch.equal(a, b) for a, b in zip(back.state_dict().values(), net.state_dict().values()))
+    assert net._bufs and net._ops_obj is not None            # the original keeps its state
+
+
 def test_reference_callers_import_lines_resolve():
     """The reference's own import lines, verbatim, in fresh interpreters: demo_2x.py:7-12 (cwd = repo root), README.md:31, and
     benchmark/test_*.py:12-16 (cwd = benchmark/, `sys.path.append('../')`).  They must resolve to this package's Network."""
