@@ -506,11 +506,18 @@ class Network(_ParamWatch, BlockRunner, nn.Module):
             pm = self._primary
             with pm._prepare_lock:                 # replicas may run on worker threads (host_io.PairStreams)
                 before = pm._prepared_sig
-                P = pm._prepare(pm._ops(ops.device) if isinstance(ops, HipOps) else ops)
+                P = pm._prepare_unlocked(pm._ops(ops.device) if isinstance(ops, HipOps) else ops)
                 if pm._prepared_sig is not before and isinstance(ops, HipOps):
                     torch.cuda.current_stream(ops.device).synchronize()
                 self._prepared, self._prepared_sig, self._plist = P, pm._prepared_sig, pm._plist
             return P
+        lock = self._prepare_lock
+        if lock is None:
+            return self._prepare_unlocked(ops)
+        with lock:                                 # a model with replicas: they may be preparing on other threads right now
+            return self._prepare_unlocked(ops)
+
+    def _prepare_unlocked(self, ops):
         sig = self._param_sig()
         if sig == self._prepared_sig:
             return self._prepared
