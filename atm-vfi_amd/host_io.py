@@ -488,6 +488,80 @@ def forward_tta(model, im0, im1):
     return (pred + pred_flip.flip(2).flip(3)) / 2
 
 
+def tile_plan(height: int, width: int, tile: tuple, overlap: int):
+    """The tiles of ``forward_tiled``: the frame is cut into a grid of CORE rectangles of at most ``tile`` = (th, tw) pixels (equal
+    sizes up to rounding, rows x columns = ceil(H / th) x ceil(W / tw)); a tile is its core grown by ``overlap`` pixels on every
+    side that has a neighbour (clipped to the frame).  Returns [(y0, y1, x0, x1, cy0, cy1, cx0, cx1)]: the tile's rectangle in
+    the frame and its core's rectangle in the frame, row-major."""
+    th, tw = tile
+    if th <= 0 or tw <= 0 or overlap < 0:
+        raise ValueError("tile_plan: tile sizes must be positive and the overlap non-negative")
+    ny, nx = -(-height // th), -(-width // tw)
+    ys = [round(i * height / ny) for i in range(ny + 1)]
+    xs = [round(j * width / nx) for j in range(nx + 1)]
+    plan = []
+    for i in range(ny):
+        for j in range(nx):
+            cy0, cy1, cx0, cx1 = ys[i], ys[i + 1], xs[j], xs[j + 1]
+            plan.append((max(cy0 - overlap, 0), min(cy1 + overlap, height), max(cx0 - overlap, 0), min(cx1 + overlap, width),
+                         cy0, cy1, cx0, cx1))
+    return plan
+
+
+def forward_tiled(forward, im0, im1, tile=(1088, 2048), overlap: int = 64, divisor: int = 64, streams: int = 1):
+    """TILED inference for frames too large to run at once (BASELINE.json configs[4]: "Xiph-4K 2160x4096 tiled").  The reference
+    has no tiling (its "4K" is a centre crop, test_xiph.py:115-123), so the mode is defined HERE, and its parity
+    oracle is the reference's forward run on the identical tiles with the identical stitching -- which is what the tests
+    do by passing the oracle's forward as ``forward``:
+      * tiles = ``tile_plan(H, W, tile, overlap)``; every tile of both frames is replicate-padded to a multiple of ``divisor`` with
+        the reference's own InputPadder (benchmark/utils.py:57-80), run through ``forward`` and un-padded;
+      * the prediction's CORE rectangle is written into the output frame (cores partition the frame: no blending, no seams in the
+        sense of double coverage; the overlap only gives every core pixel ``overlap`` pixels of real context).
+    ``forward``: a ``Network`` (its ``I_t`` is taken; ``streams`` > 1 keeps that many tiles in flight through a ``PairStreams`` made
+    for this call -- its replicas build their workspaces and plans first, so for repeated use pass a ``PairStreams`` you keep as
+    ``forward`` instead), a ``PairStreams``, or any callable (im0, im1) -> I_t or the output dict.  Returns ``I_t`` [B,3,H,W] on the frames' device.  Per tile the workspace is that of the tile's
+    size (14 GB at 1152 x 2112) instead of the whole frame's (52 GB at 2176 x 4096)."""
+    if im0.shape != im1.shape or im0.dim() != 4:
+        raise ValueError(f"forward_tiled: two [B,3,H,W] frames expected, got {tuple(im0.shape)} and {tuple(im1.shape)}")
+    b, c, h, w = im0.shape
+    plan = tile_plan(h, w, tile, overlap)
+    out = torch.empty_like(im0, memory_format=torch.contiguous_format)
+    is_net = hasattr(forward, "replica") and hasattr(forward, "forward")
+
+    def pieces():
+        for (y0, y1, x0, x1, *_core) in plan:
+            a, bb = im0[..., y0:y1, x0:x1], im1[..., y0:y1, x0:x1]
+            padder = InputPadder(a.shape, divisor=divisor)
+            pa, pb = padder.pad(a, bb)
+            yield padder, pa.contiguous(), pb.contiguous()
+
+    def place(k, padder, pred):
+        y0, y1, x0, x1, cy0, cy1, cx0, cx1 = plan[k]
+        pred = padder.unpad(pred)
+        out[..., cy0:cy1, cx0:cx1] = pred[..., cy0 - y0:cy1 - y0, cx0 - x0:cx1 - x0]
+
+    own = is_net and streams > 1 and im0.is_cuda
+    if own or isinstance(forward, PairStreams):
+        padders = []
+
+        def pairs_():
+            for padder, pa, pb in pieces():
+                padders.append(padder)
+                yield pa, pb
+        ps = PairStreams(forward, min(streams, len(plan))) if own else forward
+        try:
+            for k, res in enumerate(ps.map(pairs_())):
+                place(k, padders[k], res["I_t"])
+        finally:
+            if own:
+                ps.release()
+        return out
+    for k, (padder, pa, pb) in enumerate(pieces()):
+        res = forward(pa, pb)
+        place(k, padder, res["I_t"] if isinstance(res, dict) else res)
+    return out
+
+
 def psnr(a, b) -> float:
     """-10 log10(mean((a - b)^2)) on [0,1] images (benchmark/psnr_ssim.py:133-135, test_snufilm.py:147)."""
     a = torch.as_tensor(a, dtype=torch.float64)

@@ -556,6 +556,32 @@ def main():
             c4k = time_config(pkg, host_io, pairs, dev, "c4", args.steps, 3, args.precision, shared=(net, sd), inflight=(2,))
             result["configs"]["c4"]["frames_per_s_k_inflight"] = c4k.get("frames_per_s_k_inflight")
             result["configs"]["c4"]["k_inflight_frac_of_f16x3_peak"] = c4k.get("k_inflight_frac_of_f16x3_peak")
+            # configs[4] as BASELINE words it -- "2160x4096 TILED": host_io.forward_tiled (four 1144 x 2112 tiles = 1080 x 2048 cores + 64 px
+            # of context, padded to 1152 x 2112; the build-defined mode whose parity oracle is the oracle on the same tiles,
+            # tests/test_gpu_e2e.py::test_tiled_inference_vs_oracle_on_identical_tiles), one tile at a time and with two in flight
+            try:
+                a5, b5 = (t.to(dev) for t in pairs.random_pair(1, 2160, 4096, seed=2005))
+                tiled = {}
+                for k in (1, 2):
+                    fwd = net if k == 1 else host_io.PairStreams(net, k)       # kept across calls: the replicas' workspaces and plans
+                    for _ in range(4):
+                        host_io.forward_tiled(fwd, a5, b5, tile=(1088, 2048), overlap=64)
+                    torch.cuda.synchronize()
+                    t5 = time.perf_counter()
+                    for _ in range(4):
+                        host_io.forward_tiled(fwd, a5, b5, tile=(1088, 2048), overlap=64)
+                    torch.cuda.synchronize()
+                    tiled[str(k)] = round(4.0 / (time.perf_counter() - t5), 3)
+                    if k > 1:
+                        fwd.release()
+                    net.release_workspace()
+                    torch.cuda.empty_cache()
+                result["configs"]["c5_tiled"] = {"workload": "network_base 2160x4096, host_io.forward_tiled: 4 tiles of 1144x2112 (1080x2048 cores, 64 px overlap) padded to 1152x2112, stitched on the device",
+                                                 "value": tiled["1"], "unit": "frames/s", "frames_per_s_k_inflight": {"2": tiled["2"]},
+                                                 "steps": 4, "warmup": 4}
+                del a5, b5
+            except Exception as e:          # never lose the headline line to an auxiliary configuration
+                result["configs"]["c5_tiled"] = {"error": repr(e)}
             # the large-motion mode of the API on the c3 frame size: planned like every other mode since its pick moved
             # into the C ABI (atmvfi_ensemble_select)
             result["configs"]["c3_ensemble"] = time_config(pkg, host_io, pairs, dev, "c3", 40, 6, args.precision, shared=(net, sd), ensemble=True)

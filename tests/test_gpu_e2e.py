@@ -861,6 +861,33 @@ def test_pair_streams_equal_single_stream(dev, weights):
     torch.cuda.empty_cache()
 
 
+def test_tiled_inference_vs_oracle_on_identical_tiles(nets, dev, weights):
+    """host_io.forward_tiled (BASELINE configs[4], "tiled"; SURVEY 8d: the parity oracle of a build-defined tiled mode is the reference's
+    forward on the IDENTICAL tiles with the IDENTICAL stitching): the HIP path tile by tile and with two tiles in flight against the
+    CPU oracle run through the same tiling; and tiling matters (borders and windows change), so the tiled frame is not the untiled one."""
+    for variant, (H, W), tile, ov in (("lite", (200, 300), (128, 160), 32), ("base", (160, 224), (96, 128), 16)):
+        net = nets[variant]
+        net.global_motion, net.ensemble_global_motion = True, False
+        sd = weights(variant)
+        im0, im1 = pairs.smooth_pair(1, H, W, seed=61)
+        want = host_io.forward_tiled(lambda a, b: O.forward(sd, a, b, global_motion=True)["I_t"], im0, im1, tile=tile, overlap=ov)
+        got1 = host_io.forward_tiled(net, im0.to(dev), im1.to(dev), tile=tile, overlap=ov)
+        got2 = host_io.forward_tiled(net, im0.to(dev), im1.to(dev), tile=tile, overlap=ov, streams=2)
+        assert tuple(got1.shape) == (1, 3, H, W) and got1.is_cuda
+        assert (got1.cpu() - want).abs().max().item() <= TOL, variant
+        assert torch.equal(got1, got2)
+        with host_io.PairStreams(net, 3) as ps:              # a PairStreams the caller keeps, for repeated use
+            for _ in range(2):
+                assert torch.equal(host_io.forward_tiled(ps, im0.to(dev), im1.to(dev), tile=tile, overlap=ov), got1)
+        pad = host_io.InputPadder(im0.shape, divisor=64)
+        a, b = pad.pad(im0.to(dev), im1.to(dev))
+        whole = pad.unpad(net(a, b)["I_t"])
+        # a different computation (borders, window contents, the global branch's context): on the stress weights -- not a trained
+        # interpolator -- far from the untiled frame, which is why the oracle of this mode is the oracle on the same tiles
+        assert (whole - got1).abs().max().item() > 1e-3
+    net.release_workspace()
+
+
 def test_deepcopy_of_a_used_model_is_standalone(dev, weights):
     """copy.deepcopy of a model that has run (workspace, packed weights, plans) and has replicas: an independent model with its own
     parameters and NO device-side runtime state; it builds its own on first use and computes the same frames."""

@@ -353,6 +353,33 @@ def test_model_copies_and_pickles_without_runtime_state(nets):
     assert net._bufs and net._ops_obj is not None            # the original keeps its state
 
 
+def test_tile_plan_and_tiled_stitching():
+    """host_io.tile_plan / forward_tiled (the build-defined tiled mode of BASELINE configs[4]): cores partition the frame, every tile
+    is its core grown by the overlap where it has a neighbour, and stitching a pixel-wise forward reproduces it exactly."""
+    for (h, w, tile, ov) in ((2160, 4096, (1088, 2048), 64), (100, 150, (64, 64), 8), (37, 53, (16, 100), 5), (64, 64, (64, 64), 32)):
+        plan = host_io.tile_plan(h, w, tile, ov)
+        cover = np.zeros((h, w), np.int32)
+        for (y0, y1, x0, x1, cy0, cy1, cx0, cx1) in plan:
+            cover[cy0:cy1, cx0:cx1] += 1
+            assert 0 <= y0 <= cy0 < cy1 <= y1 <= h and 0 <= x0 <= cx0 < cx1 <= x1 <= w
+            assert cy1 - cy0 <= tile[0] and cx1 - cx0 <= tile[1]
+            assert y0 == max(cy0 - ov, 0) and y1 == min(cy1 + ov, h) and x0 == max(cx0 - ov, 0) and x1 == min(cx1 + ov, w)
+        assert (cover == 1).all()
+        assert len(plan) == -(-h // tile[0]) * -(-w // tile[1])
+    assert len(host_io.tile_plan(2160, 4096, (1088, 2048), 64)) == 4
+    a, b = torch.rand(2, 3, 100, 150), torch.rand(2, 3, 100, 150)
+    seen = []
+
+    def mean(x, y):
+        seen.append(tuple(x.shape[-2:]))
+        return {"I_t": (x + y) / 2}
+    out = host_io.forward_tiled(mean, a, b, tile=(64, 64), overlap=8, divisor=16)
+    assert torch.equal(out, (a + b) / 2)
+    assert len(seen) == 6 and all(hh % 16 == 0 and ww % 16 == 0 for hh, ww in seen)          # every tile padded to the divisor
+    with pytest.raises(ValueError):
+        host_io.forward_tiled(mean, a, b[:, :, :50], tile=(64, 64))
+
+
 def test_reference_callers_import_lines_resolve():
     """The reference's own import lines, verbatim, in fresh interpreters: demo_2x.py:7-12 (cwd = repo root), README.md:31, and
     benchmark/test_*.py:12-16 (cwd = benchmark/, `sys.path.append('../')`).  They must resolve to this package's Network."""
