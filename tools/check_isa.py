@@ -236,6 +236,151 @@ def file_flags(src):
     return []
 
 
+def _kernel_body(lines, pattern):
+    starts = [i for i, l in enumerate(lines) if re.match(pattern, l)]
+    if not starts:
+        return None
+    end = next(i for i in range(starts[0], len(lines)) if "s_endpgm" in lines[i])
+    return [l.split(";")[0].rstrip() for l in lines[starts[0]:end + 1]]
+
+
+def _blocks(body, first):
+    """Basic blocks of body[first:]: (label or None, [instructions]); a block ends at a label or behind a branch."""
+    out, cur, name = [], [], None
+    for l in body[first:]:
+        t = l.strip()
+        if not t or t.startswith(".") and not re.match(r"^\.LBB\S+:", t):
+            continue
+        if re.match(r"^\.LBB\S+:", t):
+            if cur:
+                out.append((name, cur))
+            name, cur = t[:-1], []
+            continue
+        cur.append(t)
+        if re.match(r"s_(c?branch|endpgm)", t):
+            out.append((name, cur))
+            name, cur = None, []
+    if cur:
+        out.append((name, cur))
+    return out
+
+
+def _count(insts):
+    c = {"valu": 0, "pk": 0, "cvt_split": 0, "swap": 0, "vmax": 0, "cndmask": 0, "store": 0, "store_b128": 0, "ds": 0, "salu": 0, "mfma": 0, "waits": 0}
+    for t in insts:
+        t = t.strip()
+        if not t or t.startswith(".") or t.endswith(":"):
+            continue
+        op = t.split()[0]
+        if op.startswith("v_mfma"):
+            c["mfma"] += 1
+        elif op.startswith("v_"):
+            c["valu"] += 1
+            c["pk"] += op.startswith("v_pk_")
+            c["cvt_split"] += op.startswith("v_cvt_pk") or op.startswith("v_fma_mix")
+            c["swap"] += op.startswith("v_permlane")
+            c["vmax"] += op.startswith("v_max_f32")
+            c["cndmask"] += op.startswith("v_cndmask")
+        elif op.startswith("global_store") or op.startswith("buffer_store"):
+            c["store"] += 1
+            c["store_b128"] += op.endswith("dwordx4")
+        elif op.startswith("ds_"):
+            c["ds"] += 1
+        elif op == "s_waitcnt" or op == "s_nop":
+            c["waits"] += 1
+        elif op.startswith("s_"):
+            c["salu"] += 1
+    return c
+
+
+def epilogue_budget(planes_asm, pp_asm):
+    """the vector-instruction budget of the contraction kernels' epilogues, counted on the ISA that ships.
+    Static: the instructions behind the k-loop's last MFMA phase, per basic block (the epilogue forms are uniform branches: fold +
+    bias + PReLU in its three forms, fp32 rows, each plane sink in its forms), classified by what they contain; per block the
+    counts and, for the blocks that handle a whole tile's values, instructions per output element (a lane of conv3x3_planes<WN>
+    owns 2 pixels x 16 WN channels / 4 lane groups = 8 WN outputs of a tile; a lane of gemm_pp 64 x 64 / 64 = 64)."""
+    rows = ["# Epilogue instruction budget (static count on the shipped ISA; tools/check_isa.py --budget)", ""]
+    lines = planes_asm.splitlines()
+    for wn in (4, 7, 8):
+        body = _kernel_body(lines, rf"^_ZN\S*conv3x3_planes_kernelILi{wn}E\S*:")
+        if body is None:
+            continue
+        p0 = [i for i, l in enumerate(body) if re.search(r"\bs_setprio 0\b", l)]
+        outs = 8 * wn
+        kloop = _count(body[:p0[-1]])
+        rows.append(f"## conv3x3_planes_kernel<{wn}>: {outs} outputs per lane and tile; k-loop region: {kloop['mfma']} MFMAs in 21 unrolled k-steps "
+                    f"({6 * wn} per k-step), {kloop['valu']} other vector instructions, {kloop['ds']} LDS, {kloop['salu']} scalar")
+        rows.append("| stage (all basic blocks of that kind) | blocks | VALU | of which packed | split (cvt_pk / fma_mix) | permlane swap | v_max | v_cndmask | stores | copies of the stage in the code | VALU per output and copy |")
+        rows.append("|---|---|---|---|---|---|---|---|---|---|---|")
+        groups = {}
+        for name, insts in _blocks(body, p0[-1] + 1):
+            c = _count(insts)
+            if c["valu"] + c["store"] == 0:
+                continue
+            if c["mfma"]:
+                kind = "fused read-out (refine_head.1): split + MFMAs + stores"
+            elif c["swap"] and c["vmax"]:
+                kind = "plane sink with its own PReLU, max form (split, swap, 16-byte stores)"
+            elif c["swap"] and c["cndmask"]:
+                kind = "plane sink with its own PReLU, select form"
+            elif c["swap"]:
+                kind = "plane sink, no activation (split, swap, 16-byte stores)"
+            elif c["store"]:
+                kind = "fp32 rows (and the stores of masked sink lanes)"
+            elif c["vmax"] >= outs // 2:
+                kind = "fold (acc + cor / 1024) + bias + PReLU, max form"
+            elif c["cndmask"] >= outs // 2:
+                kind = "fold + bias + PReLU, select form"
+            elif c["pk"] >= outs // 2:
+                kind = "fold + bias, no activation"
+            else:
+                kind = "addresses, predicates, slope-range check, next-tile bookkeeping"
+            g = groups.setdefault(kind, dict(blocks=0, valu=0, pk=0, cvt_split=0, swap=0, vmax=0, cndmask=0, store=0))
+            g["blocks"] += 1
+            for k in ("valu", "pk", "cvt_split", "swap", "vmax", "cndmask", "store"):
+                g[k] += c[k]
+        npair = (wn + 1) // 2
+        for kind, g in groups.items():
+            copies = 1
+            if kind.startswith("plane sink"):
+                copies = max(1, round(g["swap"] / (8 * npair)))          # 4 swaps per (n-tile pair, pixel row): 8 npair per copy
+            per = f"{g['valu'] / (copies * outs):.2f}" if not kind.startswith(("addresses", "fp32", "fused")) else "-"
+            rows.append(f"| {kind} | {g['blocks']} | {g['valu']} | {g['pk']} | {g['cvt_split']} | {g['swap']} | {g['vmax']} | {g['cndmask']} | {g['store']} | {copies} | {per} |")
+        rows.append("")
+    lines = pp_asm.splitlines()
+    for tag, nm in (("Lb0", "LINEAR / DECONV"), ("Lb1", "CONV")):
+        body = _kernel_body(lines, rf"^_ZN\S*gemm_pp_kernelI{tag}E\S*:")
+        if body is None:
+            continue
+        p0 = [i for i, l in enumerate(body) if re.search(r"\bs_setprio 0\b", l)]
+        rows.append(f"## gemm_pp_kernel<{nm}>: 64 outputs per lane and tile (16 vectors of 4); every epilogue form is a separate copy of the row loop")
+        rows.append("| stage (all basic blocks of that kind) | blocks | VALU | of which packed | split (cvt_pk / fma_mix) | v_cndmask | stores | LDS | VALU per output (by the stores: 4 outputs per 16-byte fp32 store, 2 per 8-byte plane store) |")
+        rows.append("|---|---|---|---|---|---|---|---|---|")
+        groups = {}
+        for name, insts in _blocks(body, p0[-1] + 1):
+            c = _count(insts)
+            if c["valu"] + c["store"] + c["ds"] == 0:
+                continue
+            if c["ds"] >= 8 and not c["store"]:
+                kind = "fold + transposition through LDS (ds_write_b128 / ds_read_b128)"
+            elif c["cvt_split"] and c["store"]:
+                kind = "plane-sink rows (split + 8-byte stores): strided / 1x1 convs, deconvs, fc2's sink -- all copies"
+            elif c["store"]:
+                kind = "fp32 rows (bias, PReLU, residual, 16-byte stores) -- all copies"
+            else:
+                kind = "constants, row maps, residual batch, addresses, next-tile bookkeeping"
+            g = groups.setdefault(kind, dict(blocks=0, valu=0, pk=0, cvt_split=0, cndmask=0, store=0, ds=0))
+            g["blocks"] += 1
+            for k in ("valu", "pk", "cvt_split", "cndmask", "store", "ds"):
+                g[k] += c[k]
+        for kind, g in groups.items():
+            per = (f"{g['valu'] / (4 * g['store']):.2f}" if kind.startswith("fp32") else f"{g['valu'] / (2 * g['store']):.2f}" if kind.startswith("plane") else
+                   f"{g['valu'] / 64:.2f}" if kind.startswith("fold") else "-")
+            rows.append(f"| {kind} | {g['blocks']} | {g['valu']} | {g['pk']} | {g['cvt_split']} | {g['cndmask']} | {g['store']} | {g['ds']} | {per} |")
+        rows.append("")
+    return "\n".join(rows)
+
+
 def compile_asm(src, out):
     cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", *makefile_flags(), *file_flags(src), f"-I{ROOT}/include",
            "-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", out]
@@ -244,6 +389,10 @@ def compile_asm(src, out):
 
 
 def main():
+    if "--budget" in sys.argv[1:]:
+        with tempfile.TemporaryDirectory() as td:
+            print(epilogue_budget(compile_asm("conv3x3_planes.hip", os.path.join(td, "planes.s")), compile_asm("gemm_pp.hip", os.path.join(td, "pp.s"))))
+        return 0
     with tempfile.TemporaryDirectory() as td:
         problems = check(compile_asm("conv3x3_f16x3_row.hip", os.path.join(td, "row.s")))
         planes = compile_asm("conv3x3_planes.hip", os.path.join(td, "planes.s"))
