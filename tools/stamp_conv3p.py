@@ -41,6 +41,13 @@ else:                                         # the default stamp build: whole t
     names = ["prologue (first tile only)", "k-loop", "boundary: partner's last MFMA + DMA wait", "next decode + re-stagger barrier",
              "-", "-", "-", "-", "epilogue (VALU + stores)"]
 nk = t[0, 0, 9].item()
+# spread over WORKGROUPS of the time per tile (wave 0 of each group; prologue excluded): with the static tile walk every workgroup gets the
+# same number of tiles, so the kernel lasts as long as its slowest workgroup -- max / mean - 1 is what a dynamic tile queue could recover
+per_wg = t[:, 0, 1:9].sum(1)
+xcd = torch.arange(per_wg.numel()) % 8
+print(f"per-tile ticks over {per_wg.numel()} workgroups: min {per_wg.min().item():.0f} mean {per_wg.mean().item():.0f} max {per_wg.max().item():.0f} "
+      f"(max / mean - 1 = {100 * (per_wg.max() / per_wg.mean() - 1).item():.1f} %, p95 / mean - 1 = {100 * (per_wg.quantile(0.95) / per_wg.mean() - 1).item():.1f} %); "
+      "by XCD (block % 8): " + " ".join(f"{per_wg[xcd == k].mean().item():.0f}" for k in range(8)))
 for grp in (0, 1):
     tg = t[:, 4 * grp:4 * grp + 4, :9].reshape(-1, 9)
     tot = tg.sum(1).mean().item()
