@@ -529,16 +529,20 @@ def main():
             u8 = [rng.integers(0, 256, (args.height, args.width, 3), dtype=np.uint8) for _ in range(3)]
             pairs_u8 = [(u8[i % 3], u8[(i + 1) % 3]) for i in range(max(args.steps, 30))]      # long enough to amortise fill and drain
             hio = {}
-            for depth in (1, 3):
-                pipe = host_io.FramePipeline(net, args.height, args.width, isBGR=True, divisor=64, depth=depth)
-                for _ in pipe.run(pairs_u8[:2]):
+            for depth, nstreams in ((1, 1), (3, 1), (3, 2)):
+                pipe = host_io.FramePipeline(net, args.height, args.width, isBGR=True, divisor=64, depth=depth, streams=nstreams)
+                for _ in pipe.run(pairs_u8[:2 if nstreams == 1 else 10]):      # (with streams: every replica builds its workspace and plan)
                     pass
                 torch.cuda.synchronize()
                 tp = time.perf_counter()
                 n_out = sum(1 for _ in pipe.run(pairs_u8))
                 torch.cuda.synchronize()
                 tp = time.perf_counter() - tp
-                hio["sequential" if depth == 1 else "overlapped_depth3"] = round(n_out / tp, 3)
+                hio["sequential" if depth == 1 else "overlapped_depth3" if nstreams == 1 else "overlapped_depth3_two_forwards_in_flight"] = round(n_out / tp, 3)
+                if pipe.lanes is not None:
+                    pipe.lanes.release()
+                del pipe
+                torch.cuda.empty_cache()
             result["host_io"] = {"unit": "frames/s, uint8 HWC BGR frames in pageable host memory in and out (pre/post kernels, pinned staging, PCIe both ways)",
                                  **hio, "bytes_over_pcie_per_frame": 3 * args.height * args.width * 3}
         # ---- the other BASELINE.json configurations, timed the same way (default run only: N = 1, config c4) ----
